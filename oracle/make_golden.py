@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE'S OWN PYTHON PATH in this container.
+
+What runs: /root/reference/rednose/helpers/ekf_sym.py `EKF_sym` (the pure-Python orchestrator) with
+its numpy math selected (`_predict_python` :533-559, `_update_python` :561-624 -- the two lines the
+reference leaves commented at :346-349), `rts_smooth` :651-690 and `maha_test` :626-649, on top of
+the reference-GENERATED sympy C (oracle/_ref/lib{name}.so; the f/F/h/H/H_mod/err functions are the
+reference's own codegen output).  cffi is absent, so oracle/cffi_shim provides the three cffi calls
+the class uses.  Nothing of ours is in the numerical path of these vectors except gcc.
+
+The fixtures pin: (1) oracle/ekf_oracle.c (tests/test_oracle.py) and (2) the HIP kernels
+(tests/test_gpu_parity.py).  /root/reference does not exist on the GPU box, hence committed vectors.
+
+Run:  python oracle/make_golden.py        (needs /root/reference; rewrites tests/golden/)
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = "/root/reference"
+sys.path[:0] = [os.path.join(HERE, "cffi_shim"), REF, HERE, REPO]
+
+import build_oracle  # noqa: E402
+from rednose.helpers.ekf_sym import EKF_sym as RefEKF  # noqa: E402  (the reference class)
+
+GOLD = os.path.join(REPO, "tests", "golden")
+REFDIR = os.path.join(HERE, "_ref")
+
+
+def ref_filter(name, Q, x0, P0, D, E, numpy_math=True, **kw):
+  if not os.path.exists(os.path.join(REFDIR, f"lib{name}.so")):
+    build_oracle.build(name, "ref")
+  f = RefEKF(REFDIR, name, Q, x0, P0, D, E, **kw)
+  if numpy_math:
+    f._predict = f._predict_python   # pylint: disable=protected-access
+    f._update = f._update_python     # pylint: disable=protected-access
+  return f
+
+
+def kinematic_stream():
+  """The known-answer scenario of /root/reference/examples/test_kinematic_kf.py:11-48, full trajectory."""
+  Q = np.diag([0.1**2, 2.0**2]); x0 = np.array([0.5, 0.0]); P0 = np.diag([1.0, 1.0]); R = np.array([[[0.1**2]]])
+  out = {}
+  for tag, numpy_math in (("numpy", True), ("c", False)):
+    np.random.seed(0)
+    f = ref_filter("kinematic", Q, x0, P0, 2, 2, numpy_math=numpy_math)
+    dt = 0.01
+    ts = np.arange(0, 5, step=dt)
+    xs, Ps, zs = [], [], []
+    x = 0.0
+    for t, v in zip(ts, np.sin(ts * 5)):
+      meas = np.random.normal(x, 0.1)
+      zs.append(meas)
+      f.predict_and_update_batch(t, 1, np.array([[meas]]), R)
+      xs.append(f.state().copy()); Ps.append(f.covs().copy())
+      x += v * dt
+    out[tag] = (np.array(xs), np.array(Ps))
+    out["ts"], out["zs"] = ts, np.array(zs)
+  xs, Ps = out["numpy"]
+  print("kinematic final (reference numpy path):", xs[-1], np.sqrt(np.diag(Ps[-1])))
+  print("  literals in test_kinematic_kf.py:52-55: -0.010866289677966417 0.04477103863330089 -0.8553720537261753 0.6695762270974388")
+  print("  |numpy - C restatement| max:", np.abs(out["numpy"][0] - out["c"][0]).max(), np.abs(out["numpy"][1] - out["c"][1]).max())
+  np.savez_compressed(os.path.join(GOLD, "kinematic_stream.npz"), ts=out["ts"], zs=out["zs"], xs=xs, Ps=Ps,
+                      literals=np.array([-0.010866289677966417, 0.04477103863330089, -0.8553720537261753, 0.6695762270974388]))
+
+
+def compare_rewind():
+  """/root/reference/examples/test_compare.py:88-120: samples 20 and 40 swapped => rewind + fast-forward."""
+  Q = np.diag([0.1**2, 2.0**2]); x0 = np.array([0.5, 0.0]); P0 = np.diag([1.0, 1.0]); R = np.array([[[0.1**2]]])
+  np.random.seed(0)
+  f = ref_filter("compare", Q, x0, P0, 2, 2)
+  dt = 0.01
+  ts = np.arange(0, 5, step=dt)
+  xs_true = np.empty(ts.shape)
+  x = 0.0
+  for i, v in enumerate(np.sin(ts * 5)):
+    xs_true[i] = x
+    x += v * dt
+  a, b = 20, 40
+  ts[a], ts[b] = ts[b], ts[a]
+  xs_true[a], xs_true[b] = xs_true[b], xs_true[a]
+  xs, Ps, fts, zs = [], [], [], []
+  for t, xt in zip(ts, xs_true):
+    meas = np.random.normal(xt, 0.1)
+    zs.append(meas)
+    f.predict_and_update_batch(t, 1, np.array([[meas]]), R)
+    xs.append(f.state().copy()); Ps.append(f.covs().copy()); fts.append(f.get_filter_time())
+  np.savez_compressed(os.path.join(GOLD, "compare_rewind.npz"), ts=ts, zs=np.array(zs), xs=np.array(xs), Ps=np.array(Ps),
+                      filter_times=np.array(fts))
+
+
+def _live_setup():
+  sys.path.insert(0, REPO)
+  from examples.live_kf import LiveKalman  # our restatement of the model constants (x0, P0, Q, R)
+  return LiveKalman
+
+
+def _random_spd(rng, diag):
+  E = diag.shape[0]
+  A = rng.normal(size=(E, E)) * 0.15
+  C = np.eye(E) + A @ A.T
+  s = np.sqrt(diag)
+  return (C * s[:, None]) * s[None, :]
+
+
+def live_single_steps():
+  """Random state / covariance, one predict and one update per kind: reference numpy math, single calls."""
+  L = _live_setup()
+  rng = np.random.default_rng(7)
+  f = ref_filter("live", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22)
+  kinds = [3, 4, 9, 10, 12, 13, 14, 19]
+  recs = {}
+  n = 6
+  X = np.tile(L.initial_x, (n, 1))
+  X[:, 0:3] += rng.normal(size=(n, 3)) * 100
+  q = rng.normal(size=(n, 4)) * 0.3 + np.array([1, 0, 0, 0]); X[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+  X[:, 7:10] = rng.normal(size=(n, 3)) * 5
+  X[:, 10:13] = rng.normal(size=(n, 3)) * 0.1
+  X[:, 13:16] = rng.normal(size=(n, 3)) * 0.01
+  X[:, 16] = 1 + rng.normal(size=n) * 0.01
+  X[:, 17:20] = rng.normal(size=(n, 3)) * 0.5
+  X[:, 20:23] = rng.normal(size=(n, 3)) * 0.02
+  Pdiag = np.array(L.initial_P_diag) * np.array([1e-4] * 3 + [1e-3] * 3 + [1e-2] * 3 + [1.0] * 13)
+  Ps = np.stack([_random_spd(rng, Pdiag) for _ in range(n)])
+  recs["x_in"], recs["P_in"] = X, Ps
+  dts = np.array([0.0, 0.01, 0.05, 0.1, 0.01, 0.02])
+  xo, Po = [], []
+  for i in range(n):
+    x, P = f._predict_python(X[i].reshape(-1, 1).copy(), Ps[i].copy(), dts[i])  # pylint: disable=protected-access
+    xo.append(x.flatten()); Po.append(P)
+  recs["predict_dt"], recs["predict_x"], recs["predict_P"] = dts, np.array(xo), np.array(Po)
+  for k in kinds:
+    Z = 1 if k == 3 else 3
+    R = np.atleast_2d(L.obs_noise.get(k, np.eye(Z) * 0.1))
+    zs = rng.normal(size=(n, Z))
+    xo, Po, yo = [], [], []
+    for i in range(n):
+      h = np.zeros((Z, 1)); f.hs[k](X[i].copy(), np.zeros(1), h)
+      z = h.flatten() + zs[i] * np.sqrt(np.diag(R)) * 2
+      zs[i] = z
+      x, P, y = f._update_python(X[i].reshape(-1, 1).copy(), Ps[i].copy(), k, z.copy(), R.copy(), extra_args=np.zeros(1))  # pylint: disable=protected-access
+      xo.append(np.asarray(x).flatten()); Po.append(P); yo.append(y)
+    recs[f"upd{k}_z"], recs[f"upd{k}_R"] = zs, R
+    recs[f"upd{k}_x"], recs[f"upd{k}_P"], recs[f"upd{k}_y"] = np.array(xo), np.array(Po), np.array(yo)
+  np.savez_compressed(os.path.join(GOLD, "live_single_steps.npz"), **recs)
+
+
+def live_stream(n_ticks=40):
+  """IMU@100 Hz (gyro then accel at the same t) + ECEF_POS every 10th tick, stationary device, reference numpy
+  path with quaternion_idxs=[3].  To get the C++ orchestrator's behaviour (renormalise after predict AND after
+  update, /root/reference/rednose/helpers/ekf_sym.cc:207,213) from the Python class, each observation is applied
+  as  f.predict(t)  [normalises, ekf_sym.py:461]  followed by predict_and_update_batch(t, ...) whose internal
+  predict then has dt == 0 and is an exact identity (F = I, dt*Q = 0)."""
+  L = _live_setup()
+  rng = np.random.default_rng(2025)
+  f = ref_filter("live", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22, quaternion_idxs=[3])
+  x_true = L.initial_x.copy()
+  x0 = L.initial_x.copy()
+  e = rng.uniform(-0.05, 0.05, size=3)
+  q = np.array([1.0, e[0] / 2, e[1] / 2, e[2] / 2]); x0[3:7] = q / np.linalg.norm(q)
+  P0 = np.diag(L.initial_P_diag)
+  f.init_state(x0, P0, None)
+  hacc = np.zeros((3, 1)); f.hs[10](x_true.copy(), np.zeros(1), hacc)
+  sched, zs, ts = [], [], []
+  for tick in range(n_ticks):
+    t = 0.01 * tick
+    sched.append(4); ts.append(t); zs.append(rng.normal(size=3) * 0.025)
+    sched.append(10); ts.append(t); zs.append(hacc.flatten() + rng.normal(size=3) * 0.5)
+    if tick % 10 == 9:
+      sched.append(12); ts.append(t); zs.append(x_true[0:3] + rng.normal(size=3) * 5)
+  est = []
+  xs, Ps, ys, xps = [], [], [], []
+  for k, t, z in zip(sched, ts, zs):
+    f.predict(t)
+    xps.append(f.state().copy())
+    r = f.predict_and_update_batch(t, k, np.array([z]), np.array([L.obs_noise[k]]))
+    est.append(r)
+    xs.append(f.state().copy()); Ps.append(f.covs().copy()); ys.append(np.asarray(r[6][0]).flatten())
+  xs, Ps = np.array(xs), np.array(Ps)
+  keep = np.arange(0, len(sched), 7).tolist() + [len(sched) - 1]
+  np.savez_compressed(os.path.join(GOLD, "live_stream.npz"), x0=x0, P0=P0, kinds=np.array(sched), ts=np.array(ts),
+                      zs=np.array(zs), ys=np.array(ys), xs=xs, x_pred=np.array(xps), P_idx=np.array(keep), Ps=Ps[keep])
+  print("live stream:", len(sched), "steps; final pos err", xs[-1][:3] - x_true[:3], "quat", xs[-1][3:7])
+  return f, est
+
+
+def rts_goldens():
+  """rts_smooth (ekf_sym.py:651-690) on (a) the kinematic stream, (b) a live stream, reference numpy path.
+  rts_smooth aliases and mutates its input estimates (xk_n = xk_k, Pk_n = Pk_k) -- deep copies go in."""
+  import copy
+  Q = np.diag([0.1**2, 2.0**2]); x0 = np.array([0.5, 0.0]); P0 = np.diag([1.0, 1.0]); R = np.array([[[0.1**2]]])
+  np.random.seed(0)
+  f = ref_filter("kinematic", Q, x0, P0, 2, 2)
+  dt = 0.01
+  ts = np.arange(0, 1.2, step=dt)
+  est = []
+  x = 0.0
+  for t, v in zip(ts, np.sin(ts * 5)):
+    est.append(f.predict_and_update_batch(t, 1, np.array([[np.random.normal(x, 0.1)]]), R))
+    x += v * dt
+  pack = lambda es: dict(xk_km1=np.array([e[0] for e in es]), xk_k=np.array([e[1] for e in es]),  # noqa: E731
+                         Pk_km1=np.array([e[2] for e in es]), Pk_k=np.array([e[3] for e in es]),
+                         t=np.array([e[4] for e in es]))
+  inp = pack(est)
+  xs_s, Ps_s = f.rts_smooth(copy.deepcopy(est), norm_quats=False)
+  np.savez_compressed(os.path.join(GOLD, "kinematic_rts.npz"), xs_smooth=xs_s, Ps_smooth=Ps_s, **inp)
+
+  fl, est_l = live_stream(n_ticks=30)
+  inp = pack(est_l)
+  xs_s, Ps_s = fl.rts_smooth(copy.deepcopy(est_l), norm_quats=True)
+  keep = np.arange(0, len(est_l), 5)
+  np.savez_compressed(os.path.join(GOLD, "live_rts.npz"), xs_smooth=xs_s, Ps_smooth_idx=keep, Ps_smooth=Ps_s[keep],
+                      xk_km1=inp["xk_km1"], xk_k=inp["xk_k"], t=inp["t"], Pk_km1=inp["Pk_km1"].astype(np.float64),
+                      Pk_k=inp["Pk_k"])
+
+
+def maha_goldens():
+  """Gate DECISIONS of the reference's maha_test (ekf_sym.py:626-649; threshold = chi2_ppf(0.95, Z) from the
+  reference's lookup table) on live ECEF_POS observations with and without gross outliers."""
+  L = _live_setup()
+  rng = np.random.default_rng(99)
+  f = ref_filter("live", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22)
+  n = 64
+  X = np.tile(L.initial_x, (n, 1)); X[:, 0:3] += rng.normal(size=(n, 3)) * 3
+  Pdiag = np.array(L.initial_P_diag) * np.array([1e-6] * 3 + [1e-3] * 19)
+  Ps = np.stack([_random_spd(rng, Pdiag) for _ in range(n)])
+  R = L.obs_noise[12]
+  z = X[:, 0:3] + rng.normal(size=(n, 3)) * 8
+  z[::4] += rng.normal(size=(len(z[::4]), 3)) * 500
+  ok = np.array([f.maha_test(X[i].reshape(-1, 1).copy(), Ps[i].copy(), 12, z[i].copy(), R.copy(), extra_args=np.zeros(1)) for i in range(n)])
+  from rednose.helpers.chi2_lookup import chi2_ppf as ref_chi2
+  np.savez_compressed(os.path.join(GOLD, "live_maha.npz"), x=X, P=Ps, z=z, R=R, accepted=ok,
+                      thresholds=np.array([ref_chi2(0.95, d) for d in (1, 2, 3, 6)]))
+  print("maha accepted", ok.sum(), "of", n)
+
+
+if __name__ == "__main__":
+  os.makedirs(GOLD, exist_ok=True)
+  kinematic_stream()
+  compare_rewind()
+  live_single_steps()
+  live_stream()
+  rts_goldens()
+  maha_goldens()
+  for fn in sorted(os.listdir(GOLD)):
+    print(fn, os.path.getsize(os.path.join(GOLD, fn)))

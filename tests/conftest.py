@@ -1,0 +1,40 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "oracle")):
+  if p not in sys.path:
+    sys.path.insert(0, p)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+  config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+  return np.load(os.path.join(GOLDEN, name))
+
+
+def assert_close(got, want, rtol=1e-12, floor=1e-14, what=""):
+  """|got - want| <= rtol*|want| + floor*max|want| over the last axis (per-row scale), SURVEY.md section 8c."""
+  got = np.asarray(got, dtype=np.float64)
+  want = np.asarray(want, dtype=np.float64)
+  assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
+  scale = np.max(np.abs(want), axis=-1, keepdims=True) if want.ndim else np.abs(want)
+  tol = rtol * np.abs(want) + floor * scale + 1e-300
+  err = np.abs(got - want)
+  bad = err > tol
+  if np.any(bad):
+    idx = np.unravel_index(np.argmax(err / tol), err.shape)
+    raise AssertionError(f"{what}: {bad.sum()} of {bad.size} entries off; worst at {idx}: got {got[idx]!r} want {want[idx]!r} "
+                         f"err {err[idx]:.3e} tol {tol[idx]:.3e}")
+
+
+@pytest.fixture(scope="session")
+def repo_root():
+  return REPO
