@@ -1,0 +1,36 @@
+"""Model definitions written against the rednose_amd filter API, and a helper that generates + builds them.
+
+GENERATED_DIR plays the role of the reference's examples/generated/ (produced there by SCons,
+/root/reference/examples/SConscript:5-19).
+"""
+import os
+
+GENERATED_DIR = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', 'generated'))
+
+
+def model_table():
+  from examples.kinematic_kf import KinematicKalman
+  from examples.kinematic6_kf import Kinematic6Kalman
+  from examples.live_kf import LiveKalman, ObservationKind as LK
+  return {
+    "kinematic": lambda d: KinematicKalman.generate_code(d),
+    "kinematic6": lambda d: Kinematic6Kalman.generate_code(d),
+    "kinematic6_maha": lambda d: _renamed(Kinematic6Kalman, "kinematic6_maha", d, maha_test_kinds=[1]),
+    "live": lambda d: LiveKalman.generate_code(d),
+    "live_maha": lambda d: LiveKalman.generate_code(d, name="live_maha", maha_test_kinds=[LK.ECEF_POS]),
+  }
+
+
+def _renamed(cls, name, folder, **kw):
+  from rednose_amd.helpers.ekf_sym import gen_code
+  mdl = cls.model()
+  mdl["name"] = name
+  gen_code(folder, **mdl, **kw)
+
+
+def ensure_generated(names=None, folder=GENERATED_DIR):
+  """Generate + compile the named example filters (skips up-to-date ones).  Returns the folder."""
+  table = model_table()
+  for n in (names or table.keys()):
+    table[n](folder)
+  return folder

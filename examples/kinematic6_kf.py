@@ -8,7 +8,11 @@ f = x + dt*[v; 0], h = pos, x0 = [0.5,0.5,0.5,0,0,0], P0 = I, Q = diag(0.1^2 x3,
 R = 0.1^2 I3.  Each axis is an independent copy of the reference's 2-state filter, which
 tests/test_oracle.py uses as a cross-check.
 """
+import os
 import sys
+
+if __name__ == "__main__":  # allow running as a script from anywhere (generator CLI contract)
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 import numpy as np
 import sympy as sp

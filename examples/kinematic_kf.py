@@ -6,7 +6,11 @@ h = [position]); this is the DIM=2 model the reference's known-answer test pins
 (/root/reference/examples/test_kinematic_kf.py:52-55).  Usage as a generator script follows the
 reference CLI contract:  kinematic_kf.py <target> <out_dir>   (only argv[2] is read).
 """
+import os
 import sys
+
+if __name__ == "__main__":  # allow running as a script from anywhere (generator CLI contract)
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 import numpy as np
 import sympy as sp

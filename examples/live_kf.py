@@ -13,7 +13,11 @@ Differences by design:
   * the quaternion slice is renormalised inside the kernels (quaternion_idxs=[3]) after every predict
     and update, as EKFSym does when given the index (/root/reference/rednose/helpers/ekf_sym.cc:207,213).
 """
+import os
 import sys
+
+if __name__ == "__main__":  # allow running as a script from anywhere (generator CLI contract)
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 import numpy as np
 import sympy as sp

@@ -1,0 +1,292 @@
+"""Kernel family S ("lane per filter"): the whole filter state lives in one lane's VGPRs.
+
+Used when E is small (kinematic: D=E=2; kinematic6: D=E=6 -> 6 + 36 doubles = 84 VGPRs).  A
+wavefront owns 64 consecutive filters: it pulls their x / P / z records out of HBM as one
+contiguous, 16-byte-vectorised burst per array, transposes through its private LDS slice so that
+lane l ends up holding filter l, runs the fully unrolled predict / update algebra below in
+registers, and writes back the same way.  All sparsity of F and H.H_mod is resolved here, at
+generation time: structural zeros emit no instruction, unit entries no multiply.
+
+Algebra emitted (reference lines in /root/reference/rednose/templates/ekf_c.c):
+  predict :8-33   x' = f(x,dt); F = F(x,dt) at the PRE-propagation state; P' = (F P) F^T + dt Q
+                  (MEDIM < EDIM handled as F_full = blockdiag(F_main, I), identical to :23-26)
+  update  :37-121 y = z - h(x); He = H(x) H_mod(x); G = He P; Gt = He P^T; S = G He^T + R;
+                  optional gate d2 = y^T S^-1 y > thresh => R *= 1e16 (:88-94);
+                  K^T = S^-1 Gt via Cholesky (:101 uses fullPivLu; S is SPD);
+                  dx = K y; x = err_fun(x, dx);
+                  Joseph form (:115) evaluated with its rank-Z structure:
+                     B = P - K G            (= I_KH P)
+                     C = B He^T             (E x Z)
+                     P' = B + (K R - C) K^T (= B I_KH^T + K R K^T)
+                  which is the same polynomial in the same inputs -- including the property that the
+                  rounding error of B is cancelled to first order by the correction term.
+"""
+import sympy as sp
+
+from rednose_amd.codegen.lower import Block, vector_names
+from rednose_amd.codegen.emit_common import SMat, term, sum_terms
+
+
+def _ind(lines, n=2):
+  pad = " " * n
+  return [pad + s for s in lines]
+
+
+def predict_regs(spec):
+  """-> text of `predict_regs(x, P, Q, dt)` operating on registers."""
+  D, E, M = spec.dim_x, spec.dim_err, spec.dim_main_err
+  names = {**vector_names(spec.x_sym, 'x'), spec.dt_sym: 'dt'}
+  blk = Block(names, tmp_prefix="pt")
+  for i in range(D):
+    blk.add(f"xn_{i}", spec.f_sym[i])
+  fmtF = lambda i, j: f"F_{i}_{j}"  # noqa: E731
+  for i in range(M):
+    for j in range(M):
+      blk.add(fmtF(i, j), spec.F_sym[i, j])
+  stmts, st = blk.lower()
+  F = SMat.identity_padded(SMat.from_structure(M, M, st, fmtF), E)
+
+  body = list(stmts)
+  # T = F P   (rows of F that are a bare unit diagonal alias the row of P)
+  T = [[None] * E for _ in range(E)]
+  for i in range(E):
+    nz = F.row_nz(i)
+    if len(nz) == 1 and nz[0][0] == i and nz[0][1][0] == 'one':
+      for j in range(E):
+        T[i][j] = f"P[{i * E + j}]"
+      continue
+    for j in range(E):
+      body.append(f"const double T_{i}_{j} = {sum_terms(term(c, f'P[{k * E + j}]') for k, c in nz)};")
+      T[i][j] = f"T_{i}_{j}"
+  # P' = T F^T + dt Q
+  newP = []
+  for i in range(E):
+    for j in range(E):
+      s = sum_terms(term(c, T[i][k]) for k, c in F.row_nz(j))
+      newP.append(f"const double Pn_{i}_{j} = {s} + dt*Q[{i * E + j}];")
+  body += newP
+  for i in range(E):
+    for j in range(E):
+      body.append(f"P[{i * E + j}] = Pn_{i}_{j};")
+  for i in range(D):
+    kind, val = st[f"xn_{i}"]
+    body.append(f"x[{i}] = xn_{i};" if kind == 'expr' else f"x[{i}] = {float(val)!r};")
+  head = (f"__device__ __forceinline__ void predict_regs(double (&x)[{D}], double (&P)[{E * E}], "
+          "const double* __restrict__ Q, const double dt) {")
+  return "\n".join([head] + _ind(body) + ["}"]), F
+
+
+def update_regs(spec, k):
+  """-> text of `update_<kind>_regs(x, P, z, R)`; returns the gate flag."""
+  D, E, Z = spec.dim_x, spec.dim_err, k.zdim
+  names = dict(vector_names(spec.x_sym, 'x'))
+  if k.ea_sym is not None:
+    names.update(vector_names(k.ea_sym, 'ea'))
+  Herr = sp.Matrix(k.H_sym) * sp.Matrix(spec.H_mod_sym)
+  blk = Block(names, tmp_prefix="ut")
+  for i in range(Z):
+    blk.add(f"hx_{i}", k.h_sym[i])
+  fmtH = lambda i, j: f"He_{i}_{j}"  # noqa: E731
+  for i in range(Z):
+    for j in range(E):
+      blk.add(fmtH(i, j), Herr[i, j])
+  stmts, st = blk.lower()
+  He = SMat.from_structure(Z, E, st, fmtH)
+
+  b = list(stmts)
+  for i in range(Z):
+    kind, val = st[f"hx_{i}"]
+    hx = f"hx_{i}" if kind == 'expr' else repr(float(val))
+    b.append(f"const double y_{i} = z[{i}] - {hx};")
+  # G = He P ; Gt = He P^T
+  for zi in range(Z):
+    nz = He.row_nz(zi)
+    for j in range(E):
+      b.append(f"const double G_{zi}_{j} = {sum_terms(term(c, f'P[{kk * E + j}]') for kk, c in nz)};")
+      b.append(f"const double Gt_{zi}_{j} = {sum_terms(term(c, f'P[{j * E + kk}]') for kk, c in nz)};")
+  # HPHt, S, Cholesky, optional gate
+  b.append(f"double HPH[{Z * Z}], Rl[{Z * Z}], S[{Z * Z}], L[{Z * Z}], iL[{Z}];")
+  for zi in range(Z):
+    for w in range(Z):
+      b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(c, f'G_{zi}_{j}') for j, c in He.row_nz(w))};")
+  b.append("#pragma unroll")
+  b.append(f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}")
+  b.append(f"rn::chol_factor<{Z}>(S, L, iL);")
+  b.append("int gated = 0;")
+  if k.maha_test:
+    b.append("{")
+    b.append(f"  double v[{Z}] = {{{', '.join(f'y_{i}' for i in range(Z))}}};")
+    b.append(f"  rn::chol_forward<{Z}>(L, iL, v);")
+    b.append("  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]" for i in range(Z)) + ";")
+    b.append(f"  if (d2 > {k.maha_thresh!r}) {{")
+    b.append("    gated = 1;")
+    b.append("#pragma unroll")
+    b.append(f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}")
+    b.append(f"    rn::chol_factor<{Z}>(S, L, iL);")
+    b.append("  }")
+    b.append("}")
+  # K (E x Z): column j of Gt solved against S
+  for j in range(E):
+    b.append(f"double k_{j}[{Z}] = {{{', '.join(f'Gt_{zi}_{j}' for zi in range(Z))}}};")
+    b.append(f"rn::chol_solve<{Z}>(L, iL, k_{j});")
+  K = lambda i, zi: f"k_{i}[{zi}]"  # noqa: E731
+  for j in range(E):
+    b.append(f"const double dx_{j} = " + " + ".join(f"{K(j, zi)}*y_{zi}" for zi in range(Z)) + ";")
+  # error injection
+  nom, delta = spec.err_eqs[1], spec.err_eqs[2]
+  enames = dict(vector_names(nom, 'x'))
+  enames.update({(delta, i, 0): f"dx_{i}" for i in range(E)})
+  eblk = Block(enames, tmp_prefix="et")
+  for i in range(D):
+    eblk.add(f"xi_{i}", sp.Matrix(spec.err_eqs[0])[i])
+  estmts, est = eblk.lower()
+  b += estmts
+  # B = P - K G (in place)
+  for i in range(E):
+    for j in range(E):
+      b.append(f"P[{i * E + j}] -= " + " + ".join(f"{K(i, zi)}*G_{zi}_{j}" for zi in range(Z)) + ";")
+  # C = B He^T, D = K R - C
+  for i in range(E):
+    for zi in range(Z):
+      c = sum_terms(term(cf, f"P[{i * E + j}]") for j, cf in He.row_nz(zi))
+      kr = " + ".join(f"{K(i, w)}*Rl[{w * Z + zi}]" for w in range(Z))
+      b.append(f"const double Dm_{i}_{zi} = ({kr}) - ({c});")
+  for i in range(E):
+    for j in range(E):
+      b.append(f"P[{i * E + j}] += " + " + ".join(f"Dm_{i}_{zi}*{K(j, zi)}" for zi in range(Z)) + ";")
+  for i in range(D):
+    kind, val = est[f"xi_{i}"]
+    b.append(f"x[{i}] = xi_{i};" if kind == 'expr' else f"x[{i}] = {float(val)!r};")
+  for i in range(Z):
+    b.append(f"z[{i}] = y_{i};")
+  b.append("return gated;")
+  ea_arg = ", const double* __restrict__ ea" if k.ea_sym is not None else ""
+  head = (f"__device__ __forceinline__ int update_{k.kind}_regs(double (&x)[{D}], double (&P)[{E * E}], "
+          f"double (&z)[{Z}], const double (&R)[{Z * Z}]{ea_arg}) {{")
+  return "\n".join([head] + _ind(b) + ["}"]), He
+
+
+def kernels(spec):
+  """Device functions + __global__ kernels of family S for every kind."""
+  D, E = spec.dim_x, spec.dim_err
+  EE = E * E
+  out = []
+  ptxt, _ = predict_regs(spec)
+  out.append(ptxt)
+  for k in spec.kinds:
+    utxt, _ = update_regs(spec, k)
+    out.append(utxt)
+  quat = "".join(f" rn::normalize_quat<{D}>(x, {q});" for q in spec.quaternion_idxs)
+  norm = f"if (norm_quats) {{{quat} }}" if spec.quaternion_idxs else "(void)norm_quats;"
+
+  out.append(f"""
+// ---- predict only: one launch propagates n filters by dt -------------------------------------------
+__global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double* __restrict__ gP,
+    const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
+    const int norm_quats) {{
+  __shared__ __attribute__((aligned(16))) double s_x[64 * {D}];
+  __shared__ __attribute__((aligned(16))) double s_P[64 * {EE}];
+  const int lane = threadIdx.x;
+  const int64_t tiles = (n + 63) >> 6;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
+    const int64_t base = tile << 6;
+    const int cnt = (n - base) < 64 ? (int)(n - base) : 64;
+    rn::tile_g2l<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_g2l<{EE}>(gP + base * {EE}, cnt, s_P, lane);
+    const double dt = (gdt != nullptr && lane < cnt) ? gdt[base + lane] : dt_scalar;
+    rn::wave_lds_sync();
+    double x[{D}], P[{EE}];
+    rn::lds_to_regs<{D}>(s_x, lane, x);
+    rn::lds_to_regs<{EE}>(s_P, lane, P);
+    predict_regs(x, P, gQ, dt);
+    {norm}
+    rn::wave_lds_sync();
+    rn::regs_to_lds<{D}>(s_x, lane, x);
+    rn::regs_to_lds<{EE}>(s_P, lane, P);
+    rn::wave_lds_sync();
+    rn::tile_l2g<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_l2g<{EE}>(gP + base * {EE}, cnt, s_P, lane);
+    rn::wave_lds_sync();
+  }}
+}}
+""")
+  for k in spec.kinds:
+    Z = k.zdim
+    ZZ = Z * Z
+    ea = ", gea" if k.ea_sym is not None else ""
+    out.append(f"""
+// ---- kind {k.kind}: [predict +] update, state round-trips HBM once per launch --------------------------
+template <bool DO_PREDICT>
+__global__ __launch_bounds__(64) void k_step_{k.kind}(double* __restrict__ gx, double* __restrict__ gP,
+    double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const double* __restrict__ gea,
+    const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
+    const int norm_quats, uint8_t* __restrict__ flags) {{
+  __shared__ __attribute__((aligned(16))) double s_x[64 * {D}];
+  __shared__ __attribute__((aligned(16))) double s_P[64 * {EE}];
+  __shared__ __attribute__((aligned(16))) double s_z[64 * {Z}];
+  __shared__ __attribute__((aligned(16))) double s_R[64 * {ZZ}];
+  const int lane = threadIdx.x;
+  const int64_t tiles = (n + 63) >> 6;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
+    const int64_t base = tile << 6;
+    const int cnt = (n - base) < 64 ? (int)(n - base) : 64;
+    rn::tile_g2l<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_g2l<{EE}>(gP + base * {EE}, cnt, s_P, lane);
+    rn::tile_g2l<{Z}>(gz + base * {Z}, cnt, s_z, lane);
+    if (r_per_filter) rn::tile_g2l<{ZZ}>(gR + base * {ZZ}, cnt, s_R, lane);
+    double dt = dt_scalar;
+    if (DO_PREDICT && gdt != nullptr && lane < cnt) dt = gdt[base + lane];
+    rn::wave_lds_sync();
+    double x[{D}], P[{EE}], z[{Z}], R[{ZZ}];
+    rn::lds_to_regs<{D}>(s_x, lane, x);
+    rn::lds_to_regs<{EE}>(s_P, lane, P);
+    rn::lds_to_regs<{Z}>(s_z, lane, z);
+    if (r_per_filter) {{
+      rn::lds_to_regs<{ZZ}>(s_R, lane, R);
+    }} else {{
+#pragma unroll
+      for (int i = 0; i < {ZZ}; i++) R[i] = gR[i];
+    }}
+    if (DO_PREDICT) {{
+      predict_regs(x, P, gQ, dt);
+      {norm}
+    }}
+    int fl = update_{k.kind}_regs(x, P, z, R{ea});
+    {norm}
+    rn::wave_lds_sync();
+    rn::regs_to_lds<{D}>(s_x, lane, x);
+    rn::regs_to_lds<{EE}>(s_P, lane, P);
+    rn::regs_to_lds<{Z}>(s_z, lane, z);
+    rn::wave_lds_sync();
+    rn::tile_l2g<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_l2g<{EE}>(gP + base * {EE}, cnt, s_P, lane);
+    rn::tile_l2g<{Z}>(gz + base * {Z}, cnt, s_z, lane);
+    if (flags != nullptr && lane < cnt) {{
+      double acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < {D}; i++) acc += x[i];
+      if (!(acc - acc == 0.0)) fl |= 2;          // non-finite state
+      flags[base + lane] = (uint8_t)fl;
+    }}
+    rn::wave_lds_sync();
+  }}
+}}
+""")
+  return "\n".join(out)
+
+
+def launch_predict():
+  return """  const int64_t tiles = (n + 63) >> 6;
+  hipLaunchKernelGGL(k_predict, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     x, P, Q, dt_vec, dt, n, norm_quats);"""
+
+
+def launch_step(kind, do_predict):
+  tf = "true" if do_predict else "false"
+  if do_predict:
+    args = "x, P, z, R, r_per_filter, ea, Q, dt_vec, dt, n, norm_quats, flags"
+  else:
+    args = "x, P, z, R, r_per_filter, ea, nullptr, nullptr, 0.0, n, norm_quats, flags"
+  return f"""  const int64_t tiles = (n + 63) >> 6;
+  hipLaunchKernelGGL(k_step_{kind}<{tf}>, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     {args});"""

@@ -1,0 +1,140 @@
+"""Expression lowering: sympy -> straight-line HIP device code (CSE + a device-friendly printer).
+
+Replaces the reference's `sympy_into_c` (/root/reference/rednose/helpers/sympy_helpers.py:122-162),
+which prints every matrix entry as an independent fully expanded C99 expression (no CSE; `x**2`
+becomes `pow(x, 2)`; live.cpp contains 1 638 pow(), 252 sin(), 234 cos() calls -- SURVEY.md 3.5).
+On a GPU that turns a memory-bound filter step into a transcendental-bound one, so here
+
+  * all outputs of a fused block (e.g. f and F, or h and H.H_mod) go through ONE `sympy.cse` pass;
+  * small integer powers are printed as multiplications, half-integer powers through sqrt
+    (`pow(r2, -1.5)` -> `1.0/(r2*sqrt(r2))`), everything else uses the C99 names which hipcc maps
+    to the ocml double-precision device functions;
+  * entries that are structurally 0 / 1 / numeric constants are reported as such so the kernel
+    emitters can skip or fold them (sparsity is resolved at generation time, never at run time).
+
+Rounding differs from the reference's expression order by a few ulp; tests bound it (tests/test_codegen.py).
+"""
+import sympy as sp
+from sympy.printing.c import C99CodePrinter
+
+
+class HipPrinter(C99CodePrinter):
+  """C99 printer with power strength-reduction suitable for fp64 device code."""
+
+  def __init__(self, symbol_names=None):
+    super().__init__(dict(precision=17, contract=False))
+    self._names = symbol_names or {}
+
+  def _print_Symbol(self, expr):
+    return self._names.get(expr, super()._print_Symbol(expr))
+
+  def _print_MatrixElement(self, expr):
+    key = (expr.parent, int(expr.i), int(expr.j))
+    if key in self._names:
+      return self._names[key]
+    rows, cols = expr.parent.shape
+    return f"{self._print(expr.parent)}[{int(expr.i) * int(cols) + int(expr.j)}]"
+
+  def _mul_chain(self, base, n):
+    b = self.parenthesize(base, 1000)
+    if n == 1:
+      return b
+    return "(" + "*".join([b] * n) + ")"
+
+  def _print_Pow(self, expr):
+    base, exp = expr.base, expr.exp
+    if exp.is_Integer:
+      n = int(exp)
+      if 1 <= n <= 4:
+        return self._mul_chain(base, n)
+      if -4 <= n <= -1:
+        return f"(1.0/{self._mul_chain(base, -n)})"
+    if exp.is_Rational or exp.is_Float:
+      two = sp.nsimplify(2 * exp)
+      if two.is_Integer and abs(int(two)) <= 9 and int(two) % 2:
+        k = (abs(int(two)) - 1) // 2          # |exp| = k + 1/2
+        root = f"sqrt({self._print(base)})"
+        body = root if k == 0 else f"({self._mul_chain(base, k)}*{root})"
+        return body if two > 0 else f"(1.0/{body})"
+    return super()._print_Pow(expr)
+
+  def _print_Rational(self, expr):
+    return f"({int(expr.p)}.0/{int(expr.q)}.0)"
+
+  def _print_Integer(self, expr):
+    # keep arithmetic in double (sympy would print bare ints, e.g. `1` for F's unit diagonal)
+    return f"{int(expr)}.0" if int(expr) >= 0 else f"(-{-int(expr)}.0)"
+
+
+def classify(expr):
+  """-> ('zero'|'one'|'const'|'expr', value)."""
+  e = sp.sympify(expr)
+  if e.is_zero:
+    return 'zero', 0.0
+  if e.is_number:
+    v = float(e)
+    if v == 0.0:
+      return 'zero', 0.0
+    if v == 1.0:
+      return 'one', 1.0
+    return 'const', v
+  return 'expr', e
+
+
+class Block:
+  """A fused group of symbolic outputs lowered together.
+
+  outputs: list of (c_lvalue, sympy expr).  After `lower()`, `.statements` holds C statements
+  (temporaries first) and `.structure[c_lvalue]` the ('zero'|'one'|'const'|'expr') classification.
+  Structural zeros/ones/constants are NOT assigned by the statements unless `materialize_all`.
+  """
+
+  def __init__(self, names=None, tmp_prefix="t"):
+    self.outputs = []
+    self.names = dict(names or {})
+    self.tmp_prefix = tmp_prefix
+
+  def add(self, lvalue, expr):
+    self.outputs.append((lvalue, sp.sympify(expr)))
+
+  def lower(self, materialize_all=False, decl="const double "):
+    structure = {}
+    live = []
+    for lv, e in self.outputs:
+      kind, val = classify(e)
+      structure[lv] = (kind, val)
+      if kind == 'expr' or materialize_all:
+        live.append((lv, e))
+    exprs = [e for _, e in live]
+    stmts = []
+    if exprs:
+      repl, reduced = sp.cse(exprs, symbols=sp.numbered_symbols(self.tmp_prefix), optimizations='basic', order='none')
+      pr = HipPrinter(self.names)
+      for sym, sub in repl:
+        stmts.append(f"const double {sym} = {pr.doprint(sub)};")
+      for (lv, _), red in zip(live, reduced):
+        stmts.append(f"{decl}{lv} = {pr.doprint(red)};")
+    self.statements = stmts
+    self.structure = structure
+    return stmts, structure
+
+
+def matrix_entries(mat, fmt):
+  """[(fmt(i,j), mat[i,j])] row-major."""
+  m = sp.Matrix(mat)
+  return [(fmt(i, j), m[i, j]) for i in range(m.shape[0]) for j in range(m.shape[1])]
+
+
+def vector_names(sym, cname):
+  """Map MatrixSymbol elements of a column vector `sym` to `cname[i]`."""
+  if sym is None:
+    return {}
+  if isinstance(sym, sp.MatrixSymbol):
+    return {(sym, i, 0): f"{cname}[{i}]" for i in range(sym.shape[0])}
+  if isinstance(sym, sp.Symbol):
+    return {sym: cname}
+  out = {}
+  for i, s in enumerate(sp.Matrix(sym)):
+    if isinstance(s, sp.Symbol):
+      out[s] = f"{cname}[{i}]"
+  return out

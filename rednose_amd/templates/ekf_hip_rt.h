@@ -1,0 +1,225 @@
+// ekf_hip_rt.h -- hand-written HIP runtime shared by every generated rednose_amd filter library.
+//
+// Plays the role rednose/templates/ekf_c.c plays in the reference (the fixed text spliced into every
+// generated filter, /root/reference/rednose/helpers/ekf_sym.py:207-208), but for gfx950:
+//   * wave-private LDS transposition between the AoS batch layout in HBM (x:(N,D), P:(N,E,E),
+//     z:(N,Z) row-major, the natural numpy/torch batch of the reference's per-filter buffers) and a
+//     lane-per-filter register layout, with fully coalesced 16-byte global accesses;
+//   * in-register Cholesky factor / solve for the Z x Z innovation covariance (S is SPD; the
+//     reference uses fullPivLu, ekf_c.c:89,101 -- same solution up to rounding);
+//   * host-side plumbing for the C ABI: error reporting, scratch buffers for the single-filter
+//     host-pointer entry points, launch geometry.
+// Written for CDNA4 only: 64-lane wavefronts, one wavefront per workgroup, no portability layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace rn {
+
+constexpr int WAVE = 64;
+
+// ------------------------------------------------------------------------------------------------
+// status / error reporting (the reference's entry points are void and assert; ours never abort)
+// ------------------------------------------------------------------------------------------------
+enum Status : int {
+  OK = 0,
+  ERR_HIP = 1,         // a HIP runtime call failed (no device, launch failure, ...)
+  ERR_ARG = 2,         // null / negative / unknown-kind argument
+  ERR_ALIGN = 3,       // device pointer not 16-byte aligned
+};
+
+struct ErrorState {
+  int code = 0;
+  int hip_code = 0;
+  char msg[256] = {0};
+};
+
+inline ErrorState& err() {
+  static thread_local ErrorState e;
+  return e;
+}
+
+inline int fail(int code, int hip_code, const char* what, int line) {
+  ErrorState& e = err();
+  e.code = code;
+  e.hip_code = hip_code;
+  snprintf(e.msg, sizeof(e.msg), "rednose_amd: %s failed at line %d (status %d, hip %d: %s)", what, line, code, hip_code,
+           hip_code ? hipGetErrorString((hipError_t)hip_code) : "-");
+  fprintf(stderr, "%s\n", e.msg);
+  return code;
+}
+
+#define RN_HIP(expr)                                                             \
+  do {                                                                           \
+    hipError_t rn_e_ = (expr);                                                   \
+    if (rn_e_ != hipSuccess) return rn::fail(rn::ERR_HIP, (int)rn_e_, #expr, __LINE__); \
+  } while (0)
+
+#define RN_REQUIRE(cond, code)                                                   \
+  do {                                                                           \
+    if (!(cond)) return rn::fail((code), 0, #cond, __LINE__);                    \
+  } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Launch geometry: one wavefront (64 filters, lane-per-filter) per workgroup.  The dispatcher places
+// workgroup b on XCD b % 8, so the tile -> workgroup map is kept identical for every kernel of a
+// library (tile = blockIdx.x + k * gridDim.x with gridDim.x a multiple of 8): a filter's x/P written by
+// one step are still in the SAME XCD's L2 when the next launch reads them.
+constexpr int MAX_GRID = 256 * 16;   // 16 single-wave workgroups per CU, then grid-stride
+
+inline int grid_for_tiles(int64_t tiles) {
+  int64_t g = tiles < MAX_GRID ? tiles : MAX_GRID;
+  if (g >= 8) g -= g % 8;
+  return (int)(g < 1 ? 1 : g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// device side
+// ------------------------------------------------------------------------------------------------
+
+// Orders this wavefront's LDS traffic.  The LDS services one wave's instructions in issue order, so
+// no s_waitcnt / s_barrier is needed -- only the compiler must not move accesses across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Copy one tile (cnt <= 64 filters x EPF doubles, contiguous in HBM) into this wave's LDS region.
+// Full tiles move as 16-byte vectors, lane l taking vectors l, l+64, ... (1 KiB per wave-instruction).
+template <int EPF>
+__device__ __forceinline__ void tile_g2l(const double* __restrict__ g, int cnt, double* lds, int lane) {
+  constexpr int NV = 32 * EPF;                      // double2 vectors in a full tile
+  if (cnt == WAVE) {
+    const double2* __restrict__ g2 = reinterpret_cast<const double2*>(g);
+    double2* l2 = reinterpret_cast<double2*>(lds);
+    double2 v[(NV + WAVE - 1) / WAVE];
+#pragma unroll
+    for (int i = 0; i < (NV + WAVE - 1) / WAVE; i++) {
+      const int idx = lane + i * WAVE;
+      if ((NV % WAVE == 0) || idx < NV) v[i] = g2[idx];
+    }
+#pragma unroll
+    for (int i = 0; i < (NV + WAVE - 1) / WAVE; i++) {
+      const int idx = lane + i * WAVE;
+      if ((NV % WAVE == 0) || idx < NV) l2[idx] = v[i];
+    }
+  } else {
+    const int total = cnt * EPF;
+    for (int idx = lane; idx < total; idx += WAVE) lds[idx] = g[idx];
+  }
+}
+
+template <int EPF>
+__device__ __forceinline__ void tile_l2g(double* __restrict__ g, int cnt, const double* lds, int lane) {
+  constexpr int NV = 32 * EPF;
+  if (cnt == WAVE) {
+    double2* __restrict__ g2 = reinterpret_cast<double2*>(g);
+    const double2* l2 = reinterpret_cast<const double2*>(lds);
+#pragma unroll
+    for (int i = 0; i < (NV + WAVE - 1) / WAVE; i++) {
+      const int idx = lane + i * WAVE;
+      if ((NV % WAVE == 0) || idx < NV) g2[idx] = l2[idx];
+    }
+  } else {
+    const int total = cnt * EPF;
+    for (int idx = lane; idx < total; idx += WAVE) g[idx] = lds[idx];
+  }
+}
+
+// lane-per-filter register <-> LDS (filter `lane` owns lds[lane*EPF .. lane*EPF+EPF))
+template <int EPF>
+__device__ __forceinline__ void lds_to_regs(const double* lds, int lane, double (&r)[EPF]) {
+#pragma unroll
+  for (int k = 0; k < EPF; k++) r[k] = lds[lane * EPF + k];
+}
+
+template <int EPF>
+__device__ __forceinline__ void regs_to_lds(double* lds, int lane, const double (&r)[EPF]) {
+#pragma unroll
+  for (int k = 0; k < EPF; k++) lds[lane * EPF + k] = r[k];
+}
+
+// S = L L^T, lower triangle of S is read; iL[i] = 1 / L[i][i].  Fully unrolled, lives in VGPRs.
+template <int Z>
+__device__ __forceinline__ void chol_factor(const double (&S)[Z * Z], double (&L)[Z * Z], double (&iL)[Z]) {
+#pragma unroll
+  for (int j = 0; j < Z; j++) {
+    double d = S[j * Z + j];
+#pragma unroll
+    for (int k = 0; k < j; k++) d -= L[j * Z + k] * L[j * Z + k];
+    const double ljj = sqrt(d);
+    L[j * Z + j] = ljj;
+    iL[j] = 1.0 / ljj;
+#pragma unroll
+    for (int i = j + 1; i < Z; i++) {
+      double s = S[i * Z + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= L[i * Z + k] * L[j * Z + k];
+      L[i * Z + j] = s * iL[j];
+    }
+  }
+}
+
+// forward substitution only: b <- L^{-1} b
+template <int Z>
+__device__ __forceinline__ void chol_forward(const double (&L)[Z * Z], const double (&iL)[Z], double (&b)[Z]) {
+#pragma unroll
+  for (int i = 0; i < Z; i++) {
+    double s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= L[i * Z + k] * b[k];
+    b[i] = s * iL[i];
+  }
+}
+
+// b <- (L L^T)^{-1} b
+template <int Z>
+__device__ __forceinline__ void chol_solve(const double (&L)[Z * Z], const double (&iL)[Z], double (&b)[Z]) {
+  chol_forward<Z>(L, iL, b);
+#pragma unroll
+  for (int i = Z - 1; i >= 0; i--) {
+    double s = b[i];
+#pragma unroll
+    for (int k = i + 1; k < Z; k++) s -= L[k * Z + i] * b[k];
+    b[i] = s * iL[i];
+  }
+}
+
+// EKFSym::normalize_slice (/root/reference/rednose/helpers/ekf_sym.cc:75-77): x[idx:idx+4] /= ||.||
+template <int DIM>
+__device__ __forceinline__ void normalize_quat(double (&x)[DIM], int idx) {
+  const double n = sqrt(x[idx] * x[idx] + x[idx + 1] * x[idx + 1] + x[idx + 2] * x[idx + 2] + x[idx + 3] * x[idx + 3]);
+  x[idx] /= n;
+  x[idx + 1] /= n;
+  x[idx + 2] /= n;
+  x[idx + 3] /= n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: scratch for the single-filter host-pointer entry points (the reference's scalar ABI)
+// ------------------------------------------------------------------------------------------------
+struct Scratch {
+  double* dev = nullptr;
+  size_t cap = 0;   // doubles
+  int ensure(size_t doubles) {
+    if (doubles <= cap) return OK;
+    if (dev) (void)hipFree(dev);
+    dev = nullptr;
+    cap = 0;
+    RN_HIP(hipMalloc(reinterpret_cast<void**>(&dev), doubles * sizeof(double)));
+    cap = doubles;
+    return OK;
+  }
+};
+
+inline Scratch& scratch() {
+  static Scratch s;
+  return s;
+}
+
+}  // namespace rn

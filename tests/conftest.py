@@ -20,13 +20,14 @@ def golden(name):
   return np.load(os.path.join(GOLDEN, name))
 
 
-def assert_close(got, want, rtol=1e-12, floor=1e-14, what=""):
-  """|got - want| <= rtol*|want| + floor*max|want| over the last axis (per-row scale), SURVEY.md section 8c."""
+def assert_close(got, want, rtol=1e-12, floor=1e-14, what="", atol=0.0):
+  """|got - want| <= rtol*|want| + floor*max|want| over the last axis (per-row scale), SURVEY.md section 8c.
+  `atol` is for residuals y = z - h(x), whose rounding error scales with |z|, not |y|."""
   got = np.asarray(got, dtype=np.float64)
   want = np.asarray(want, dtype=np.float64)
   assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
   scale = np.max(np.abs(want), axis=-1, keepdims=True) if want.ndim else np.abs(want)
-  tol = rtol * np.abs(want) + floor * scale + 1e-300
+  tol = rtol * np.abs(want) + floor * scale + atol + 1e-300
   err = np.abs(got - want)
   bad = err > tol
   if np.any(bad):

@@ -1,0 +1,236 @@
+"""GPU parity tests: the generated HIP library (through its C ABI) against the CPU oracle and the golden fixtures.
+
+Tolerances (fp64): single predict/update call rtol 1e-12 with an absolute floor of
+1e-14 x row max; 500-step kinematic stream 1e-10 (the reference's own test asserts 7 decimal places).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import assert_close, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+  import torch
+  assert torch.cuda.is_available(), "these tests need the MI355X"
+  return torch
+
+
+@pytest.fixture(scope="module")
+def gen_dir():
+  from examples import ensure_generated
+  return ensure_generated(["kinematic", "kinematic6", "kinematic6_maha"])
+
+
+def _rand_spd(rng, n, E, scale=1.0):
+  A = rng.normal(size=(n, E, E)) * 0.3
+  return (np.eye(E)[None] + A @ A.transpose(0, 2, 1)) * scale
+
+
+# ------------------------------------------------------------------ reference scalar ABI on the GPU
+def test_known_answer_scalar_abi_on_gpu(gen_dir, torch_cuda):
+  """/root/reference/examples/test_kinematic_kf.py:11-55 through the drop-in host-pointer ABI (batch of one)."""
+  from examples.kinematic_kf import KinematicKalman, ObservationKind
+  g = golden("kinematic_stream.npz")
+  kf = KinematicKalman(gen_dir)
+  for t, meas in zip(g["ts"], g["zs"]):
+    kf.predict_and_observe(t, ObservationKind.POSITION, [meas])
+  lit = g["literals"]
+  std = np.sqrt(np.diag(kf.P))
+  for got, want in zip((kf.x[0], std[0], kf.x[1], std[1]), lit):
+    assert round(abs(got - want), 7) == 0
+  assert_close(kf.x, g["xs"][-1], rtol=1e-10, floor=1e-12)
+  assert_close(kf.P.reshape(-1), g["Ps"][-1].reshape(-1), rtol=1e-10, floor=1e-12)
+
+
+def test_scalar_sympy_routines_on_gpu(gen_dir, torch_cuda):
+  from oracle_lib import OracleLib
+  from rednose_amd.helpers.ekf_sym import EKF_sym
+  from examples.kinematic6_kf import Kinematic6Kalman as K6
+  f = EKF_sym(gen_dir, "kinematic6", K6.Q, K6.initial_x, np.diag(K6.initial_P_diag), 6, 6)
+  o = OracleLib("kinematic6")
+  rng = np.random.default_rng(0)
+  x = rng.normal(size=6)
+  dx = rng.normal(size=6)
+  table = {"f_fun": f.f, "F_fun": f.F, "err_fun": f.err_function, "inv_err_fun": f.inv_err_function, "H_mod_fun": f.H_mod,
+           "h_1": f.hs[1], "H_1": f.Hs[1]}
+  for sym, args, n in (("f_fun", (x, 0.03), 6), ("F_fun", (x, 0.03), 36), ("err_fun", (x, dx), 6), ("inv_err_fun", (x, dx), 6),
+                       ("H_mod_fun", (x,), 36), ("h_1", (x, np.zeros(1)), 3), ("H_1", (x, np.zeros(1)), 18)):
+    got, want = np.zeros(n), np.zeros(n)
+    table[sym](*args, got)
+    o.call(sym, *args, want)
+    assert_close(got, want, what=sym)
+
+
+# ------------------------------------------------------------------ batched kernels vs oracle
+@pytest.mark.parametrize("name,n", [("kinematic", 1), ("kinematic", 65), ("kinematic", 1000), ("kinematic6", 64), ("kinematic6", 777),
+                                    ("kinematic6", 4096)])
+def test_batched_stream_vs_oracle(gen_dir, torch_cuda, name, n):
+  """Random streams; every filter is compared with the oracle after EVERY step (ragged tiles included)."""
+  torch = torch_cuda
+  from oracle_lib import OracleLib
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  o = OracleLib(name)
+  D, E, Z = o.D, o.E, o.zdim(1)
+  rng = np.random.default_rng(1234 + n)
+  Q = np.diag([0.1**2] * (D // 2) + [2.0**2] * (D // 2))
+  R = np.eye(Z) * 0.1**2
+  x0 = rng.normal(size=(n, D))
+  P0 = _rand_spd(rng, n, E)
+  f = BatchedEKF(gen_dir, name, Q, x0[0], P0[0], D, E, batch=n)
+  f.init_state(x0, P0, None)
+  xr, Pr = x0.copy(), P0.copy()
+  t = 0.0
+  for step in range(25):
+    dt = 0.0 if step == 0 else float(rng.uniform(0.005, 0.02))
+    t += dt
+    z = rng.normal(size=(n, Z))
+    zr = z.copy()
+    o.batch_step(1, xr, Pr, zr, R, Q, dt)
+    y = f.predict_and_update_batch(t, 1, z, R)
+    torch.cuda.synchronize()
+    assert_close(f.state(), xr, what=f"{name} n={n} x step {step}")
+    assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1), what=f"{name} n={n} P step {step}")
+    assert_close(y.cpu().numpy(), zr, atol=1e-14 * np.abs(z).max(), what=f"{name} n={n} y step {step}")
+    # re-synchronise: every step is a single-call comparison from bit-identical inputs (strict tolerance);
+    # free-running trajectories are compared in test_full_size_config2_properties with a looser bound
+    xr, Pr = f.state().copy(), f.covs().copy()
+
+
+def test_split_predict_then_update_equals_fused(gen_dir, torch_cuda):
+  torch = torch_cuda
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  from examples.kinematic6_kf import Kinematic6Kalman as K6
+  n = 300
+  rng = np.random.default_rng(5)
+  x0 = rng.normal(size=(n, 6))
+  P0 = _rand_spd(rng, n, 6)
+  R = K6.obs_noise[1]
+  a = BatchedEKF(gen_dir, "kinematic6", K6.Q, x0[0], P0[0], 6, 6, batch=n)
+  a.init_state(x0, P0, 0.0)
+  b = BatchedEKF(gen_dir, "kinematic6", K6.Q, x0[0], P0[0], 6, 6, batch=n)
+  b.init_state(x0, P0, 0.0)
+  z = rng.normal(size=(n, 3))
+  ya = a.predict_and_update_batch(0.01, 1, z.copy(), R)
+  est = b.predict_and_update_batch(0.01, 1, z.copy(), R, keep_estimate=True)
+  torch.cuda.synchronize()
+  assert torch.equal(a.x, b.x) and torch.equal(a.P, b.P) and torch.equal(ya, est[6])
+  assert len(est) == 9 and torch.equal(est[1], b.x) and not torch.equal(est[0], est[1])
+
+
+def test_per_filter_R_and_dt(gen_dir, torch_cuda):
+  torch = torch_cuda
+  from oracle_lib import OracleLib
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  from examples.kinematic6_kf import Kinematic6Kalman as K6
+  o = OracleLib("kinematic6")
+  n = 193
+  rng = np.random.default_rng(6)
+  x0 = rng.normal(size=(n, 6))
+  P0 = _rand_spd(rng, n, 6)
+  Rn = _rand_spd(rng, n, 3, 0.01)
+  dts = rng.uniform(0.0, 0.05, size=n)
+  z = rng.normal(size=(n, 3))
+  f = BatchedEKF(gen_dir, "kinematic6", K6.Q, x0[0], P0[0], 6, 6, batch=n)
+  f.init_state(x0, P0, 0.0)
+  f.predict_dt(dts)
+  y = f.update(1, z.copy(), Rn)
+  torch.cuda.synchronize()
+  xr, Pr, zr = x0.copy(), P0.copy(), z.copy()
+  o.batch_step(1, xr, Pr, zr, Rn, K6.Q, dts)
+  assert_close(f.state(), xr)
+  assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1))
+  assert_close(y.cpu().numpy(), zr, atol=1e-14 * np.abs(z).max())
+
+
+def test_maha_gate_flags(gen_dir, torch_cuda):
+  torch = torch_cuda
+  from oracle_lib import OracleLib
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  from examples.kinematic6_kf import Kinematic6Kalman as K6
+  o = OracleLib("kinematic6_maha")
+  n = 2048
+  rng = np.random.default_rng(8)
+  x0 = rng.normal(size=(n, 6))
+  P0 = _rand_spd(rng, n, 6, 0.01)
+  z = x0[:, :3] + rng.normal(size=(n, 3)) * 0.1
+  z[::5] += 50.0                                   # gross outliers, far from the chi2 threshold
+  f = BatchedEKF(gen_dir, "kinematic6_maha", K6.Q, x0[0], P0[0], 6, 6, batch=n, maha_test_kinds=[1])
+  f.init_state(x0, P0, 0.0)
+  f.update(1, z.copy(), K6.obs_noise[1])
+  torch.cuda.synchronize()
+  xr, Pr, zr = x0.copy(), P0.copy(), z.copy()
+  fl = np.zeros(n, dtype=np.uint8)
+  o.batch_step(1, xr, Pr, zr, K6.obs_noise[1], K6.Q, 0.0, flags=fl, do_predict=False)
+  got = f.flags.cpu().numpy()
+  assert np.array_equal(got & 1, fl) and fl[::5].all() and (got & 2).sum() == 0
+  assert_close(f.state(), xr)
+  assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-11, floor=1e-13)
+  with pytest.raises(Exception):
+    BatchedEKF(gen_dir, "kinematic6_maha", K6.Q, x0[0], P0[0], 6, 6, batch=4)      # library/ctor gate lists differ
+
+
+def test_full_size_config2_properties(gen_dir, torch_cuda):
+  """BASELINE.json config 2 at full size (N = 65 536): final state vs oracle for ALL filters, plus properties
+  that do not need the oracle -- covariance symmetric positive-definite, identical filters stay identical."""
+  torch = torch_cuda
+  from oracle_lib import OracleLib
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  from examples.kinematic6_kf import Kinematic6Kalman as K6
+  o = OracleLib("kinematic6")
+  n, T = 65536, 40
+  rng = np.random.default_rng(1234)
+  phase = rng.uniform(0, 2 * np.pi, size=(n, 3))
+  x0 = np.tile(K6.initial_x, (n, 1)) + rng.normal(size=(n, 6)) * 0.1
+  x0[-64:] = x0[-65]                                # 65 identical filters fed identical data
+  phase[-64:] = phase[-65]
+  f = BatchedEKF(gen_dir, "kinematic6", K6.Q, K6.initial_x, np.diag(K6.initial_P_diag), 6, 6, batch=n)
+  f.init_state(x0, np.diag(K6.initial_P_diag), None)
+  xr = x0.copy()
+  Pr = np.tile(np.diag(K6.initial_P_diag), (n, 1, 1))
+  pos = np.zeros((n, 3))
+  R = K6.obs_noise[1]
+  for step in range(T):
+    t = 0.01 * step
+    noise = rng.normal(size=(n, 3)) * 0.1
+    noise[-64:] = noise[-65]
+    z = pos + noise
+    zr = z.copy()
+    o.batch_step(1, xr, Pr, zr, R, K6.Q, 0.0 if step == 0 else 0.01)
+    f.predict_and_update_batch(t, 1, z, R)
+    pos += np.sin(5 * t + phase) * 0.01
+  torch.cuda.synchronize()
+  X, P = f.state(), f.covs()
+  assert_close(X, xr, rtol=1e-11, floor=1e-13)
+  assert_close(P.reshape(n, -1), Pr.reshape(n, -1), rtol=1e-11, floor=1e-13)
+  assert np.abs(P - P.transpose(0, 2, 1)).max() < 1e-12
+  assert np.linalg.eigvalsh(0.5 * (P + P.transpose(0, 2, 1))).min() > 0
+  assert np.array_equal(X[-64:], np.tile(X[-65], (64, 1))) and np.array_equal(P[-64:], np.tile(P[-65], (64, 1, 1)))
+
+
+# ------------------------------------------------------------------ error behaviour of the C ABI
+def test_error_conventions(gen_dir, torch_cuda):
+  torch = torch_cuda
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  from examples.kinematic6_kf import Kinematic6Kalman as K6
+  f = BatchedEKF(gen_dir, "kinematic6", K6.Q, K6.initial_x, np.diag(K6.initial_P_diag), 6, 6, batch=128)
+  with pytest.raises(KeyError):
+    f.predict_and_update_batch(0.0, 99, np.zeros((128, 3)), np.eye(3))      # unknown kind, like ekf_sym.py:343
+  lib = f._lib
+  buf = torch.zeros(128 * 6 + 1, dtype=torch.float64, device=f.device)
+  rc = lib.kinematic6_batch_predict(ctypes.c_void_p(buf.data_ptr() + 8), ctypes.c_void_p(f.P.data_ptr()), ctypes.c_void_p(f.Q.data_ptr()),
+                                    None, 0.01, 128, 0, None)
+  assert rc == 3 and b"aligned16" in lib.kinematic6_last_error_string()     # ERR_ALIGN, nothing launched
+  lib.kinematic6_clear_error()
+  assert lib.kinematic6_batch_predict(None, None, None, None, 0.0, 5, 0, None) == 2   # ERR_ARG
+  lib.kinematic6_clear_error()
+  assert lib.kinematic6_batch_predict(ctypes.c_void_p(f.x.data_ptr()), ctypes.c_void_p(f.P.data_ptr()), ctypes.c_void_p(f.Q.data_ptr()),
+                                      None, 0.0, 0, 0, None) == 0                      # empty batch is a no-op
+  f.predict(0.0)
+  f.predict(0.5)
+  with pytest.raises(AssertionError):
+    f.predict(0.25)                                                                   # dt < 0 (ekf_sym.py:459)

@@ -1,0 +1,106 @@
+"""CPU tests of the host-side orchestrator (rednose_amd.helpers.ekf_sym.EKF_sym): time bookkeeping, rewind /
+fast-forward ring, Estimate tuples, rts_smooth, maha_test.
+
+The class binds whatever library exports the reference's scalar C ABI.  Here -- and only here, as the
+checker -- it is pointed at the ORACLE build of that ABI (oracle/_ref or oracle/_port) so the host logic can
+be exercised without a GPU and compared with trajectories produced by the reference's own Python class
+(tests/golden/, oracle/make_golden.py).  The product path (generated HIP library) is covered by -m gpu tests.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_close, golden
+from oracle_lib import OracleLib
+from rednose_amd.helpers.ekf_sym import EKF_sym
+
+
+def oracle_folder(name):
+  lib = OracleLib(name)
+  return os.path.dirname(lib.path)
+
+
+def test_known_answer_through_orchestrator():
+  """/root/reference/examples/test_kinematic_kf.py:11-55 driven through EKF_sym.predict_and_update_batch."""
+  g = golden("kinematic_stream.npz")
+  f = EKF_sym(oracle_folder("kinematic"), "kinematic", np.diag([0.1**2, 2.0**2]), np.array([0.5, 0.0]), np.diag([1.0, 1.0]), 2, 2)
+  R = np.array([[[0.1**2]]])
+  for t, meas in zip(g["ts"], g["zs"]):
+    est = f.predict_and_update_batch(t, 1, np.array([[meas]]), R)
+    assert len(est) == 9 and est[4] == t and est[5] == 1
+  lit = g["literals"]
+  x, std = f.state(), np.sqrt(np.diag(f.covs()))
+  for got, want in zip((x[0], std[0], x[1], std[1]), lit):
+    assert round(abs(got - want), 7) == 0          # the reference's assertAlmostEqual
+  assert_close(x, g["xs"][-1], rtol=1e-11, floor=1e-13)
+
+
+def test_rewind_and_fast_forward_matches_reference_class():
+  """/root/reference/examples/test_compare.py:103-120: samples 20 and 40 arrive swapped."""
+  g = golden("compare_rewind.npz")
+  f = EKF_sym(oracle_folder("compare"), "compare", np.diag([0.1**2, 2.0**2]), np.array([0.5, 0.0]), np.diag([1.0, 1.0]), 2, 2)
+  R = np.array([[[0.1**2]]])
+  for i, (t, meas) in enumerate(zip(g["ts"], g["zs"])):
+    f.predict_and_update_batch(t, 1, np.array([[meas]]), R)
+    assert abs(f.get_filter_time() - g["filter_times"][i]) < 1e-12
+    assert_close(f.state(), g["xs"][i], rtol=1e-10, floor=1e-12, what=f"state step {i}")
+    assert_close(f.covs().reshape(-1), g["Ps"][i].reshape(-1), rtol=1e-10, floor=1e-12, what=f"cov step {i}")
+
+
+def test_too_old_observation_is_dropped():
+  f = EKF_sym(oracle_folder("kinematic"), "kinematic", np.diag([0.1**2, 2.0**2]), np.array([0.5, 0.0]), np.diag([1.0, 1.0]), 2, 2)
+  R = np.array([[[0.01]]])
+  for i in range(300):
+    assert f.predict_and_update_batch(0.01 * i, 1, np.array([[0.1]]), R) is not None
+  x_before = f.state().copy()
+  assert f.predict_and_update_batch(0.5, 1, np.array([[0.1]]), R) is None     # > max_rewind_age (1 s) behind
+  assert np.array_equal(x_before, f.state())
+  with pytest.raises(KeyError):
+    f.predict_and_update_batch(3.1, 7, np.array([[0.1]]), R)                   # unknown kind (ekf_sym.py:343)
+  with pytest.raises(AssertionError):
+    f.predict(1.0)                                                            # dt < 0 (ekf_sym.py:459)
+
+
+def test_rewind_ring_is_bounded():
+  f = EKF_sym(oracle_folder("kinematic"), "kinematic", np.diag([0.1**2, 2.0**2]), np.array([0.5, 0.0]), np.diag([1.0, 1.0]), 2, 2)
+  R = np.array([[[0.01]]])
+  for i in range(600):
+    f.predict_and_update_batch(0.001 * i, 1, np.array([[0.1]]), R)
+  assert len(f.rewind_t) == len(f.rewind_states) == len(f.rewind_obscache) == 512
+  f.init_state(np.array([0.5, 0.0]), np.eye(2), None)
+  assert len(f.rewind_t) == 0 and f.get_filter_time() is None
+
+
+def _estimates(g, with_pk=True):
+  n = len(g["t"])
+  return [(g["xk_km1"][i], g["xk_k"][i], g["Pk_km1"][i], g["Pk_k"][i], g["t"][i], 0, None, None, None) for i in range(n)]
+
+
+def test_rts_smooth_kinematic_matches_reference():
+  g = golden("kinematic_rts.npz")
+  f = EKF_sym(oracle_folder("kinematic"), "kinematic", np.diag([0.1**2, 2.0**2]), np.array([0.5, 0.0]), np.diag([1.0, 1.0]), 2, 2)
+  xs, Ps = f.rts_smooth(_estimates(g), norm_quats=False)
+  assert_close(xs, g["xs_smooth"], rtol=1e-10, floor=1e-12, what="smoothed states")
+  assert_close(Ps.reshape(len(Ps), -1), g["Ps_smooth"].reshape(len(Ps), -1), rtol=1e-9, floor=1e-11, what="smoothed covs")
+
+
+def test_rts_smooth_live_matches_reference():
+  from examples.live_kf import LiveKalman as L
+  g = golden("live_rts.npz")
+  f = EKF_sym(oracle_folder("live"), "live", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22, quaternion_idxs=[3])
+  est_in = _estimates(g)
+  keep_copy = [e[1].copy() for e in est_in]
+  xs, Ps = f.rts_smooth(est_in, norm_quats=True)
+  assert all(np.array_equal(a, e[1]) for a, e in zip(keep_copy, est_in)), "rts_smooth must not modify its input"
+  assert_close(xs, g["xs_smooth"], rtol=1e-7, floor=1e-9, what="smoothed states")
+  idx = g["Ps_smooth_idx"]
+  assert_close(Ps[idx].reshape(len(idx), -1), g["Ps_smooth"].reshape(len(idx), -1), rtol=1e-6, floor=1e-8, what="smoothed covs")
+
+
+def test_maha_test_matches_reference_decisions():
+  from examples.live_kf import LiveKalman as L
+  g = golden("live_maha.npz")
+  f = EKF_sym(oracle_folder("live"), "live", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22)
+  got = np.array([f.maha_test(g["x"][i], g["P"][i], 12, g["z"][i], g["R"]) for i in range(len(g["x"]))])
+  assert np.array_equal(got, g["accepted"])
