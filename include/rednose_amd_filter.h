@@ -1,0 +1,91 @@
+/*
+ * rednose_amd_filter.h -- the C ABI of a generated rednose_amd filter library (lib{name}.so).
+ *
+ * Every symbol is prefixed with the filter name chosen at gen_code() time, exactly like the reference
+ * (/root/reference/rednose/helpers/ekf_sym.py:149-171).  This header documents the ABI with the macro
+ * RN_FN(name, sym) == name##_##sym; the concrete per-model prototype lists that gen_code writes next to
+ * each library are committed for the shipped models as include/kinematic.h, include/kinematic6.h and
+ * include/live.h, and tests/test_abi.py checks that each library exports every symbol they declare.
+ *
+ * Conventions
+ *   - fp64 everywhere, dense row-major: x is D doubles, P is E x E, z is Z, R is Z x Z
+ *     (/root/reference/rednose/templates/ekf_c.c:4-6,39-44).
+ *   - in-place semantics of the reference are kept: x and P are updated in place, z is overwritten with the
+ *     residual y = z - h(x) (ekf_c.c:118-120); Q, R, ea are read-only; no allocation crosses the boundary.
+ *   - section 1 takes HOST pointers and one filter (the reference's existing ABI, run as a batch of one on
+ *     the GPU); section 2 takes DEVICE pointers and n filters laid out as the natural batch of the same
+ *     buffers: x (n, D), P (n, E, E), z (n, Z), R (Z, Z) shared or (n, Z, Z), contiguous, 16-byte aligned.
+ *   - section 2 functions are asynchronous on `stream` (a hipStream_t passed as void*, NULL = default
+ *     stream) and return 0 on success or a status (1 HIP error, 2 bad argument, 3 misaligned pointer); the
+ *     reference returns void and asserts (/root/reference/rednose/helpers/ekf_sym.cc:13,25-27,204).
+ *     {name}_last_error() / {name}_last_error_string() report the last failure of the calling thread,
+ *     including failures inside the void section-1 functions.
+ *   - there is no CPU implementation behind any of these symbols.
+ */
+#ifndef REDNOSE_AMD_FILTER_H
+#define REDNOSE_AMD_FILTER_H
+
+#include <stdint.h>
+
+#define RN_FN(name, sym) name##_##sym
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------------
+ * Section 1 -- the reference's scalar ABI, unchanged signatures (HOST pointers, one filter)
+ * --------------------------------------------------------------------------------------------------- */
+#define RN_DECLARE_SCALAR_ABI(name)                                                                              \
+  /* replaces {name}_predict, ekf_sym.py:162-165 -> predict(), ekf_c.c:8-33 */                                     \
+  void RN_FN(name, predict)(double *in_x, double *in_P, double *in_Q, double dt);                                  \
+  /* sympy routine wrappers, ekf_sym.py:155-161 (typedefs in rednose/helpers/ekf.h:21-25) */                      \
+  void RN_FN(name, f_fun)(double *state, double dt, double *out);        /* next nominal state, D            */   \
+  void RN_FN(name, F_fun)(double *state, double dt, double *out);        /* error-state transition, E x E    */   \
+  void RN_FN(name, err_fun)(double *nom_x, double *delta_x, double *out);    /* inject error, D              */   \
+  void RN_FN(name, inv_err_fun)(double *nom_x, double *true_x, double *out); /* extract error, E             */   \
+  void RN_FN(name, H_mod_fun)(double *state, double *out);               /* d nominal / d error, D x E       */
+
+/* per observation kind k (the integer is part of the symbol):
+ *   replaces {name}_update_{k}, ekf_sym.py:149-152 -> update<Z,3,MAHA>(), ekf_c.c:37-121 */
+#define RN_DECLARE_SCALAR_KIND(name, k)                                                                          \
+  void RN_FN(name, update_##k)(double *in_x, double *in_P, double *in_z, double *in_R, double *in_ea);             \
+  void RN_FN(name, h_##k)(double *state, double *ea, double *out);       /* predicted observation, Z         */   \
+  void RN_FN(name, H_##k)(double *state, double *ea, double *out);       /* observation Jacobian, Z x D      */
+
+/* ---------------------------------------------------------------------------------------------------
+ * Section 2 -- batched entry points (DEVICE pointers, n independent filters) -- new with this engine.
+ * They replace n sequential calls of the section-1 functions made by the reference's orchestrators
+ * (EKFSym::predict / ::update, /root/reference/rednose/helpers/ekf_sym.cc:196-219).
+ * --------------------------------------------------------------------------------------------------- */
+#define RN_DECLARE_BATCH_ABI(name)                                                                               \
+  void RN_FN(name, dims)(int *dims);                  /* dims[0..2] = DIM, EDIM, MEDIM (ekf_sym.py:122-124) */     \
+  int RN_FN(name, num_kinds)(void);                                                                              \
+  void RN_FN(name, kinds)(int *out);                  /* observation kinds, EKF::kinds (ekf.h:18)            */   \
+  int RN_FN(name, kind_zdim)(int kind);               /* Z of a kind, -1 if unknown                          */   \
+  int RN_FN(name, kind_maha)(int kind);               /* 1 if generated with the Mahalanobis gate            */   \
+  int RN_FN(name, last_error)(void);                                                                             \
+  const char *RN_FN(name, last_error_string)(void);                                                              \
+  void RN_FN(name, clear_error)(void);                                                                           \
+  /* P <- F P F^T + dt Q, x <- f(x, dt) for n filters; dt_vec (n) may be NULL => scalar dt for all;            \
+   * norm_quats != 0 renormalises the quaternion slices given to gen_code (EKFSym::normalize_quaternions,      \
+   * ekf_sym.cc:69-77,207) */                                                                                  \
+  int RN_FN(name, batch_predict)(double *x, double *P, const double *Q, const double *dt_vec, double dt,         \
+                                 int64_t n, int norm_quats, void *stream);
+
+#define RN_DECLARE_BATCH_KIND(name, k)                                                                           \
+  /* update only.  flags (n bytes, may be NULL): bit0 = Mahalanobis gate fired (R inflated, ekf_c.c:88-94),    \
+   * bit1 = non-finite state after the update */                                                               \
+  int RN_FN(name, batch_update_##k)(double *x, double *P, double *z, const double *R, int r_per_filter,          \
+                                    const double *ea, int64_t n, int norm_quats, uint8_t *flags, void *stream);  \
+  /* fused predict + update: ONE launch, state crosses HBM once (EKFSym::predict_and_update_batch with a       \
+   * single observation, ekf_sym.cc:158-194) */                                                                \
+  int RN_FN(name, batch_predict_update_##k)(double *x, double *P, const double *Q, const double *dt_vec,         \
+                                            double dt, double *z, const double *R, int r_per_filter,             \
+                                            const double *ea, int64_t n, int norm_quats, uint8_t *flags,         \
+                                            void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REDNOSE_AMD_FILTER_H */

@@ -1,0 +1,310 @@
+"""Kernel family W ("lane group per filter"): one 32-lane half-wavefront per filter, lane c owns row c of P.
+
+Used when the covariance does not fit one lane's registers (live: D=23, E=22 -> P is 484 doubles).
+A wavefront owns 2 consecutive filters.  Their P records (2 x E*E doubles, contiguous in HBM) are pulled
+with 16-byte coalesced loads into the wave's private LDS image; lane c of a group then holds row c (and,
+when needed, column c) of its filter's P in VGPRs, and the nominal state x replicated in every lane.
+
+  predict (ekf_c.c:8-33)    A = P F^T   row-local sparse mat-vec (F has ~33 non-trivial entries of 484)
+                            --LDS transpose-->  column c of A;  P' = F A + dt Q  column-local
+                            --LDS transpose-->  row c of P'
+  update  (ekf_c.c:37-121)  G[:,c] = He P[:,c] (column-local), Gt[:,c] = He P[c,:]^T (row-local);
+                            G is broadcast through LDS so every lane forms S = G He^T + R redundantly and
+                            factors the Z x Z matrix in registers (no cross-lane reduction);
+                            K[c,:] = S^-1 Gt[:,c];  B[c,:] = P[c,:] - K[c,:] G;  C[c,:] = B[c,:] He^T;
+                            D[c,:] = K[c,:] R - C[c,:];  K broadcast;  P'[c,:] = B[c,:] + D[c,:] K^T
+                            (the Joseph form of :115 with its rank-Z structure, see emit_small.py);
+                            dx broadcast; x' = err_fun(x, dx) redundantly per lane.
+The x-dependent scalars (f, F, h, H.H_mod, err_fun) are CSE'd straight-line code evaluated by every lane of
+the group (SIMD makes the redundancy free in issue slots; distributing it is a later optimisation).
+"""
+import sympy as sp
+
+from rednose_amd.codegen.lower import Block, vector_names
+from rednose_amd.codegen.emit_common import SMat, term, sum_terms
+
+G_LANES = 32
+FPW = 2          # filters per wavefront
+
+
+def _ind(lines, n=2):
+  pad = " " * n
+  return [pad + s for s in lines]
+
+
+def _even(n):
+  return n + (n & 1)
+
+
+def predict_fn(spec):
+  D, E, M = spec.dim_x, spec.dim_err, spec.dim_main_err
+  names = {**vector_names(spec.x_sym, 'x'), spec.dt_sym: 'dt'}
+  blk = Block(names, tmp_prefix="pt")
+  for i in range(D):
+    blk.add(f"xn_{i}", spec.f_sym[i])
+  fmtF = lambda i, j: f"F_{i}_{j}"  # noqa: E731
+  for i in range(M):
+    for j in range(M):
+      blk.add(fmtF(i, j), spec.F_sym[i, j])
+  stmts, st = blk.lower()
+  F = SMat.identity_padded(SMat.from_structure(M, M, st, fmtF), E)
+  b = list(stmts)
+  # a = F row  (row c of P F^T)
+  b.append(f"double a[{E}];")
+  for i in range(E):
+    b.append(f"a[{i}] = {sum_terms(term(cf, f'row[{k}]') for k, cf in F.row_nz(i))};")
+  b.append("if (act) {")
+  b.append("#pragma unroll")
+  b.append(f"  for (int i = 0; i < {E}; i++) sP[cc * {E} + i] = a[i];")
+  b.append("}")
+  b.append("rn::wave_lds_sync();")
+  b.append("#pragma unroll")
+  b.append(f"for (int k = 0; k < {E}; k++) a[k] = sP[k * {E} + cc];        // column c of P F^T")
+  for i in range(E):
+    b.append(f"col[{i}] = {sum_terms(term(cf, f'a[{k}]') for k, cf in F.row_nz(i))} + dt*sQ[{i} * {E} + cc];")
+  b.append("rn::wave_lds_sync();")
+  b.append("if (act) {")
+  b.append("#pragma unroll")
+  b.append(f"  for (int k = 0; k < {E}; k++) sP[k * {E} + cc] = col[k];")
+  b.append("}")
+  b.append("rn::wave_lds_sync();")
+  b.append("if (WANT_ROW) {")
+  b.append("#pragma unroll")
+  b.append(f"  for (int j = 0; j < {E}; j++) row[j] = sP[cc * {E} + j];")
+  b.append("}")
+  for i in range(D):
+    kind, val = st[f"xn_{i}"]
+    b.append(f"x[{i}] = xn_{i};" if kind == 'expr' else f"x[{i}] = {float(val)!r};")
+  head = (f"template <bool WANT_ROW>\n__device__ __forceinline__ void predict_wide(double (&x)[{D}], double (&row)[{E}], double (&col)[{E}], "
+          "double* sP, const double* sQ, const double dt, const int cc, const bool act) {")
+  return "\n".join([head] + _ind(b) + ["}"])
+
+
+def update_fn(spec, k):
+  D, E, Z = spec.dim_x, spec.dim_err, k.zdim
+  names = dict(vector_names(spec.x_sym, 'x'))
+  Herr = sp.Matrix(k.H_sym) * sp.Matrix(spec.H_mod_sym)
+  blk = Block(names, tmp_prefix="ut")
+  for i in range(Z):
+    blk.add(f"hx_{i}", k.h_sym[i])
+  fmtH = lambda i, j: f"He_{i}_{j}"  # noqa: E731
+  for i in range(Z):
+    for j in range(E):
+      blk.add(fmtH(i, j), Herr[i, j])
+  stmts, st = blk.lower()
+  He = SMat.from_structure(Z, E, st, fmtH)
+  b = list(stmts)
+  for i in range(Z):
+    kind, val = st[f"hx_{i}"]
+    hx = f"hx_{i}" if kind == 'expr' else repr(float(val))
+    b.append(f"const double y_{i} = z[{i}] - {hx};")
+  for zi in range(Z):
+    nz = He.row_nz(zi)
+    b.append(f"const double G_{zi} = {sum_terms(term(cf, f'col[{kk}]') for kk, cf in nz)};")
+    b.append(f"const double Gt_{zi} = {sum_terms(term(cf, f'row[{kk}]') for kk, cf in nz)};")
+  b.append("if (act) { " + " ".join(f"sG[{zi} * {E} + cc] = G_{zi};" for zi in range(Z)) + " }")
+  b.append("rn::wave_lds_sync();")
+  b.append(f"double HPH[{Z * Z}], Rl[{Z * Z}], S[{Z * Z}], L[{Z * Z}], iL[{Z}];")
+  for zi in range(Z):
+    for w in range(Z):
+      b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in He.row_nz(w))};")
+  b.append("#pragma unroll")
+  b.append(f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}")
+  b.append(f"rn::chol_factor<{Z}>(S, L, iL);")
+  b.append("int gated = 0;")
+  if k.maha_test:
+    b.append("{")
+    b.append(f"  double v[{Z}] = {{{', '.join(f'y_{i}' for i in range(Z))}}};")
+    b.append(f"  rn::chol_forward<{Z}>(L, iL, v);")
+    b.append("  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]" for i in range(Z)) + ";")
+    b.append(f"  if (d2 > {k.maha_thresh!r}) {{")
+    b.append("    gated = 1;")
+    b.append("#pragma unroll")
+    b.append(f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}")
+    b.append(f"    rn::chol_factor<{Z}>(S, L, iL);")
+    b.append("  }")
+    b.append("}")
+  b.append(f"double kk[{Z}] = {{{', '.join(f'Gt_{zi}' for zi in range(Z))}}};")
+  b.append(f"rn::chol_solve<{Z}>(L, iL, kk);                       // K[c][:]")
+  b.append("const double dxc = " + " + ".join(f"kk[{zi}]*y_{zi}" for zi in range(Z)) + ";")
+  # B row
+  b.append("#pragma unroll")
+  b.append(f"for (int j = 0; j < {E}; j++) row[j] -= " + " + ".join(f"kk[{zi}]*sG[{zi} * {E} + j]" for zi in range(Z)) + ";")
+  for zi in range(Z):
+    c = sum_terms(term(cf, f"row[{j}]") for j, cf in He.row_nz(zi))
+    kr = " + ".join(f"kk[{w}]*Rl[{w * Z + zi}]" for w in range(Z))
+    b.append(f"const double Dm_{zi} = ({kr}) - ({c});")
+  b.append("if (act) { " + " ".join(f"sK[{zi} * {E} + cc] = kk[{zi}];" for zi in range(Z)) + " sdx[cc] = dxc; }")
+  b.append("rn::wave_lds_sync();")
+  b.append("#pragma unroll")
+  b.append(f"for (int j = 0; j < {E}; j++) row[j] += " + " + ".join(f"Dm_{zi}*sK[{zi} * {E} + j]" for zi in range(Z)) + ";")
+  # error injection, replicated
+  b.append(f"double dxa[{E}];")
+  b.append("#pragma unroll")
+  b.append(f"for (int j = 0; j < {E}; j++) dxa[j] = sdx[j];")
+  nom, delta = spec.err_eqs[1], spec.err_eqs[2]
+  enames = dict(vector_names(nom, 'x'))
+  enames.update({(delta, i, 0): f"dxa[{i}]" for i in range(E)})
+  eblk = Block(enames, tmp_prefix="et")
+  for i in range(D):
+    eblk.add(f"xi_{i}", sp.Matrix(spec.err_eqs[0])[i])
+  estmts, est = eblk.lower()
+  b += estmts
+  for i in range(D):
+    kind, val = est[f"xi_{i}"]
+    b.append(f"x[{i}] = xi_{i};" if kind == 'expr' else f"x[{i}] = {float(val)!r};")
+  for i in range(Z):
+    b.append(f"z[{i}] = y_{i};")
+  b.append("rn::wave_lds_sync();      // broadcast buffers are free again")
+  b.append("return gated;")
+  head = (f"__device__ __forceinline__ int update_{k.kind}_wide(double (&x)[{D}], double (&row)[{E}], const double (&col)[{E}], "
+          f"double (&z)[{Z}], const double (&R)[{Z * Z}], double* sG, double* sK, double* sdx, const int cc, const bool act) {{")
+  return "\n".join([head] + _ind(b) + ["}"]), He
+
+
+def kernels(spec):
+  D, E = spec.dim_x, spec.dim_err
+  EE = E * E
+  DP = _even(D)
+  zmax = max(k.zdim for k in spec.kinds)
+  out = [f"constexpr int GL = {G_LANES};    // lanes per filter", f"constexpr int FPW = {FPW};   // filters per wavefront", ""]
+  out.append(predict_fn(spec))
+  for k in spec.kinds:
+    utxt, _ = update_fn(spec, k)
+    out.append(utxt)
+  quat = "".join(f" rn::normalize_quat<{D}>(x, {q});" for q in spec.quaternion_idxs)
+  norm = f"if (norm_quats) {{{quat} }}" if spec.quaternion_idxs else "(void)norm_quats;"
+
+  common_decl = f"""  __shared__ __attribute__((aligned(16))) double s_P[FPW * {EE}];
+  __shared__ __attribute__((aligned(16))) double s_Q[{EE}];
+  __shared__ __attribute__((aligned(16))) double s_x[FPW * {DP}];
+  const int lane = threadIdx.x;
+  const int g = lane / GL;
+  const int c = lane % GL;
+  const bool act = c < {E};
+  const int cc = act ? c : 0;
+  if (gQ != nullptr) rn::copy_g2l<{EE}>(gQ, {EE}, s_Q, lane);
+  const int64_t tiles = (n + FPW - 1) / FPW;"""
+
+  out.append(f"""
+// ---- predict only ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double* __restrict__ gP,
+    const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
+    const int norm_quats) {{
+{common_decl}
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
+    const int64_t base = tile * FPW;
+    const int cnt = (n - base) < FPW ? (int)(n - base) : FPW;
+    const int gg = g < cnt ? g : 0;
+    rn::copy_g2l<FPW * {EE}>(gP + base * {EE}, cnt * {EE}, s_P, lane);
+    rn::copy_g2l<FPW * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);
+    const double dt = gdt != nullptr ? gdt[base + gg] : dt_scalar;
+    rn::wave_lds_sync();
+    double x[{D}], row[{E}], col[{E}];
+#pragma unroll
+    for (int i = 0; i < {D}; i++) x[i] = s_x[gg * {D} + i];
+#pragma unroll
+    for (int j = 0; j < {E}; j++) row[j] = s_P[gg * {EE} + cc * {E} + j];
+    predict_wide<false>(x, row, col, s_P + gg * {EE}, s_Q, dt, cc, act && g < cnt);
+    {norm}
+    if (c == 0 && g < cnt) {{
+#pragma unroll
+      for (int i = 0; i < {D}; i++) s_x[g * {D} + i] = x[i];
+    }}
+    rn::wave_lds_sync();
+    rn::copy_l2g<FPW * {EE}>(gP + base * {EE}, cnt * {EE}, s_P, lane);
+    rn::copy_l2g<FPW * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);
+    rn::wave_lds_sync();
+  }}
+}}
+""")
+  for k in spec.kinds:
+    Z = k.zdim
+    ZZ = Z * Z
+    out.append(f"""
+// ---- kind {k.kind}: [predict +] update ---------------------------------------------------------------------
+template <bool DO_PREDICT>
+__global__ __launch_bounds__(64) void k_step_{k.kind}(double* __restrict__ gx, double* __restrict__ gP,
+    double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const double* __restrict__ gea,
+    const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
+    const int norm_quats, uint8_t* __restrict__ flags) {{
+  __shared__ __attribute__((aligned(16))) double s_z[FPW * {Z} + 2];
+  __shared__ __attribute__((aligned(16))) double s_G[FPW * {Z * E}];
+  __shared__ __attribute__((aligned(16))) double s_K[FPW * {Z * E}];
+  __shared__ __attribute__((aligned(16))) double s_dx[FPW * {E}];
+{common_decl}
+  (void)gea;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
+    const int64_t base = tile * FPW;
+    const int cnt = (n - base) < FPW ? (int)(n - base) : FPW;
+    const int gg = g < cnt ? g : 0;
+    const bool on = act && g < cnt;
+    rn::copy_g2l<FPW * {EE}>(gP + base * {EE}, cnt * {EE}, s_P, lane);
+    rn::copy_g2l<FPW * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);
+    rn::copy_g2l<FPW * {Z}>(gz + base * {Z}, cnt * {Z}, s_z, lane);
+    double dt = dt_scalar;
+    if (DO_PREDICT && gdt != nullptr) dt = gdt[base + gg];
+    double R[{ZZ}];
+#pragma unroll
+    for (int i = 0; i < {ZZ}; i++) R[i] = r_per_filter ? gR[(base + gg) * {ZZ} + i] : gR[i];
+    rn::wave_lds_sync();
+    double x[{D}], row[{E}], col[{E}], z[{Z}];
+#pragma unroll
+    for (int i = 0; i < {D}; i++) x[i] = s_x[gg * {D} + i];
+#pragma unroll
+    for (int i = 0; i < {Z}; i++) z[i] = s_z[gg * {Z} + i];
+#pragma unroll
+    for (int j = 0; j < {E}; j++) row[j] = s_P[gg * {EE} + cc * {E} + j];
+    if (DO_PREDICT) {{
+      predict_wide<true>(x, row, col, s_P + gg * {EE}, s_Q, dt, cc, on);
+      {norm}
+    }} else {{
+#pragma unroll
+      for (int k = 0; k < {E}; k++) col[k] = s_P[gg * {EE} + k * {E} + cc];
+    }}
+    int fl = update_{k.kind}_wide(x, row, col, z, R, s_G + gg * {Z * E}, s_K + gg * {Z * E}, s_dx + gg * {E}, cc, on);
+    {norm}
+    if (on) {{
+#pragma unroll
+      for (int j = 0; j < {E}; j++) s_P[g * {EE} + c * {E} + j] = row[j];
+    }}
+    if (c == 0 && g < cnt) {{
+#pragma unroll
+      for (int i = 0; i < {D}; i++) s_x[g * {D} + i] = x[i];
+#pragma unroll
+      for (int i = 0; i < {Z}; i++) s_z[g * {Z} + i] = z[i];
+      if (flags != nullptr) {{
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < {D}; i++) acc += x[i];
+        if (!(acc - acc == 0.0)) fl |= 2;
+        flags[base + g] = (uint8_t)fl;
+      }}
+    }}
+    rn::wave_lds_sync();
+    rn::copy_l2g<FPW * {EE}>(gP + base * {EE}, cnt * {EE}, s_P, lane);
+    rn::copy_l2g<FPW * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);
+    rn::copy_l2g<FPW * {Z}>(gz + base * {Z}, cnt * {Z}, s_z, lane);
+    rn::wave_lds_sync();
+  }}
+}}
+""")
+  return "\n".join(out)
+
+
+def launch_predict():
+  return """  const int64_t tiles = (n + 1) / 2;
+  hipLaunchKernelGGL(k_predict, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     x, P, Q, dt_vec, dt, n, norm_quats);"""
+
+
+def launch_step(kind, do_predict):
+  tf = "true" if do_predict else "false"
+  # Q is staged into LDS by every kernel of this family, so update-only launches need a valid pointer too
+  if do_predict:
+    args = "x, P, z, R, r_per_filter, ea, Q, dt_vec, dt, n, norm_quats, flags"
+  else:
+    args = "x, P, z, R, r_per_filter, ea, nullptr, nullptr, 0.0, n, norm_quats, flags"
+  return f"""  const int64_t tiles = (n + 1) / 2;
+  hipLaunchKernelGGL(k_step_{kind}<{tf}>, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     {args});"""

@@ -131,6 +131,42 @@ __device__ __forceinline__ void tile_l2g(double* __restrict__ g, int cnt, const 
   }
 }
 
+// Copy `nd` contiguous doubles (nd <= MAXD, source 16-byte aligned) between HBM and this wave's LDS as
+// 16-byte vectors, all loads issued before the first LDS store so they overlap.
+template <int MAXD>
+__device__ __forceinline__ void copy_g2l(const double* __restrict__ g, int nd, double* lds, int lane) {
+  constexpr int IT = (MAXD / 2 + WAVE - 1) / WAVE;
+  const int nv = nd >> 1;
+  const double2* __restrict__ g2 = reinterpret_cast<const double2*>(g);
+  double2* l2 = reinterpret_cast<double2*>(lds);
+  double2 v[IT];
+#pragma unroll
+  for (int i = 0; i < IT; i++) {
+    const int idx = lane + i * WAVE;
+    if (idx < nv) v[i] = g2[idx];
+  }
+#pragma unroll
+  for (int i = 0; i < IT; i++) {
+    const int idx = lane + i * WAVE;
+    if (idx < nv) l2[idx] = v[i];
+  }
+  if ((nd & 1) && lane == 0) lds[nd - 1] = g[nd - 1];
+}
+
+template <int MAXD>
+__device__ __forceinline__ void copy_l2g(double* __restrict__ g, int nd, const double* lds, int lane) {
+  constexpr int IT = (MAXD / 2 + WAVE - 1) / WAVE;
+  const int nv = nd >> 1;
+  double2* __restrict__ g2 = reinterpret_cast<double2*>(g);
+  const double2* l2 = reinterpret_cast<const double2*>(lds);
+#pragma unroll
+  for (int i = 0; i < IT; i++) {
+    const int idx = lane + i * WAVE;
+    if (idx < nv) g2[idx] = l2[idx];
+  }
+  if ((nd & 1) && lane == 0) g[nd - 1] = lds[nd - 1];
+}
+
 // lane-per-filter register <-> LDS (filter `lane` owns lds[lane*EPF .. lane*EPF+EPF))
 template <int EPF>
 __device__ __forceinline__ void lds_to_regs(const double* lds, int lane, double (&r)[EPF]) {
