@@ -45,7 +45,8 @@ def cpu_baseline(name, kind, K6, batch, budget_s=6.0):
     gomp = None
   rng = np.random.default_rng(1)
   n = min(batch, 65536)
-  x = np.tile(K6.initial_x, (n, 1)) + rng.normal(size=(n, lib.D)) * 0.1
+  quat = list(getattr(K6, 'quaternion_idxs', []))
+  x = np.tile(K6.initial_x, (n, 1)) + (0.0 if quat else 0.1) * rng.normal(size=(n, lib.D))
   P = np.tile(np.diag(K6.initial_P_diag), (n, 1, 1))
   Z = lib.zdim(kind)
   R = np.atleast_2d(K6.obs_noise[kind])
@@ -60,7 +61,7 @@ def cpu_baseline(name, kind, K6, batch, budget_s=6.0):
     while el < budget_s and steps < 4000:
       z = zpool[steps % 8].copy()
       t0 = time.perf_counter()
-      lib.batch_step(kind, x, P, z, R, K6.Q, 0.01)
+      lib.batch_step(kind, x, P, z, R, K6.Q, 0.01, quat_idx=quat[0] if quat else -1)
       el += time.perf_counter() - t0
       steps += 1
     out[label] = dict(value=n * steps / el, cores=int(threads), steps=steps, seconds=el)
@@ -68,65 +69,77 @@ def cpu_baseline(name, kind, K6, batch, budget_s=6.0):
   return out, n, flav
 
 
-def main():
-  ap = argparse.ArgumentParser()
-  ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=2000)
-  ap.add_argument("--warmup", type=int, default=100)
-  ap.add_argument("--batch", type=int, default=65536, help="filters per GPU")
-  ap.add_argument("--model", default="kinematic6", choices=["kinematic6", "kinematic"])
-  ap.add_argument("--no-cpu-baseline", action="store_true")
-  args = ap.parse_args()
-
-  import torch
-  import torch.distributed as dist
-
-  world = int(os.environ.get("WORLD_SIZE", "1"))
-  rank = int(os.environ.get("RANK", "0"))
-  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-  if not torch.cuda.is_available():
-    raise SystemExit("bench.py needs a HIP device: rednose_amd has no CPU path")
-  torch.cuda.set_device(local_rank)
-  dev = torch.device(f"cuda:{local_rank}")
-  if world > 1:
-    dist.init_process_group(backend="nccl", device_id=dev)
-
-  from examples import ensure_generated
-  from rednose_amd.helpers.ekf_sym import BatchedEKF
-  if args.model == "kinematic6":
-    from examples.kinematic6_kf import Kinematic6Kalman as M
-  else:
-    from examples.kinematic_kf import KinematicKalman as M
-  kind = 1
-  if rank == 0:
-    gen = ensure_generated([args.model])
-  if world > 1:
-    dist.barrier()
-  gen = ensure_generated([args.model])
-
-  n, K, W = args.batch, args.steps, args.warmup
+def kinematic_stream(torch, M, n, total, dev, rank):
+  """truth v_i(t) = sin(5t + phi_i) per axis, z = pos + N(0, 0.1^2); one kind, dt = 0.01."""
   D = M.initial_x.shape[0]
-  E = M.initial_P_diag.shape[0]
-  R = np.atleast_2d(M.obs_noise[kind])
-  Z = R.shape[0]
-  f = BatchedEKF(gen, M.name, M.Q, M.initial_x, np.diag(M.initial_P_diag), D, E, batch=n, device=dev)
-
-  # synthetic stream: truth v_i(t) = sin(5t + phi_i) per axis, z = pos + N(0, 0.1^2)
+  Z = np.atleast_2d(M.obs_noise[1]).shape[0]
   gcpu = torch.Generator().manual_seed(1234 + rank)
   gdev = torch.Generator(device=dev).manual_seed(1234 + rank)
   phi = torch.rand((n, Z), generator=gcpu, dtype=torch.float64).to(dev) * (2 * np.pi)
   x0 = torch.as_tensor(M.initial_x, dtype=torch.float64).repeat(n, 1) + 0.1 * torch.randn((n, D), generator=gcpu, dtype=torch.float64)
-  f.init_state(x0, np.diag(M.initial_P_diag), None)
-  dt = 0.01
-  total = W + K
-  ts = torch.arange(total, dtype=torch.float64, device=dev) * dt
-  # pos(t) = integral of sin(5 s + phi) ds, closed form; one (total, n, Z) block resident in HBM
-  pos = (torch.cos(phi)[None] - torch.cos(5.0 * ts[:, None, None] + phi[None])) / 5.0
+  ts = torch.arange(total, dtype=torch.float64, device=dev) * 0.01
+  pos = (torch.cos(phi)[None] - torch.cos(5.0 * ts[:, None, None] + phi[None])) / 5.0   # closed-form integral of v
   zs = pos + 0.1 * torch.randn(pos.shape, generator=gdev, dtype=torch.float64, device=dev)
-  del pos
+  sched = [(1, 0.01 * i, zs[i]) for i in range(total)]
+  return x0, np.diag(M.initial_P_diag), sched
+
+
+def live_stream(torch, M, f, n, total, dev, rank):
+  """stationary device, per 10 ms tick a PHONE_GYRO(4) then a PHONE_ACCEL(10) observation at the same
+  time (second has dt = 0), every 10th tick an ECEF_POS(12); per-filter initial attitude error <= 0.05 rad."""
+  from rednose_amd.helpers.ekf_sym import EKF_sym
+  gdev = torch.Generator(device=dev).manual_seed(2025 + rank)
+  x_true = M.initial_x.copy()
+  # expected specific force at the true state through the library's own h_10 (GPU, batch of one)
+  s = EKF_sym(f._folder, f.name, M.Q, M.initial_x, np.diag(M.initial_P_diag), 23, 22)
+  hacc = np.zeros(3)
+  s.hs[10](np.ascontiguousarray(x_true), np.zeros(1), hacc)
+  e = (torch.rand((n, 3), generator=gdev, dtype=torch.float64, device=dev) - 0.5) * 0.1
+  x0 = torch.as_tensor(x_true, dtype=torch.float64, device=dev).repeat(n, 1)
+  q = torch.cat([torch.ones((n, 1), dtype=torch.float64, device=dev), 0.5 * e], dim=1)
+  x0[:, 3:7] = q / q.norm(dim=1, keepdim=True)
+  sched = []
+  tick = 0
+  while len(sched) < total:
+    t = 0.01 * tick
+    sched.append((4, t, 0.025 * torch.randn((n, 3), generator=gdev, dtype=torch.float64, device=dev)))
+    sched.append((10, t, torch.as_tensor(hacc, device=dev)[None] + 0.5 * torch.randn((n, 3), generator=gdev, dtype=torch.float64, device=dev)))
+    if tick % 10 == 9:
+      sched.append((12, t, torch.as_tensor(x_true[:3], device=dev)[None] + 5.0 * torch.randn((n, 3), generator=gdev, dtype=torch.float64, device=dev)))
+    tick += 1
+  return x0, np.diag(M.initial_P_diag), sched[:total]
+
+
+def run_model(torch, dist, args, model, n, K, W, dev, rank, world):
+  """Warm up W steps, time exactly K steps (barrier + synchronize on both sides).  Returns timing dict (max over ranks)."""
+  from examples import ensure_generated
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  if model == "kinematic6":
+    from examples.kinematic6_kf import Kinematic6Kalman as M
+  elif model == "kinematic":
+    from examples.kinematic_kf import KinematicKalman as M
+  else:
+    from examples.live_kf import LiveKalman as M
+  if rank == 0:
+    ensure_generated([model])
+  if world > 1:
+    dist.barrier()
+  gen = ensure_generated([model])
+  D, E = M.initial_x.shape[0], M.initial_P_diag.shape[0]
+  quat = list(getattr(M, "quaternion_idxs", []))
+  f = BatchedEKF(gen, M.name, M.Q, M.initial_x, np.diag(M.initial_P_diag), D, E, batch=n, device=dev, quaternion_idxs=quat)
+  f._folder = gen
+  total = W + K
+  if model == "live":
+    x0, P0, sched = live_stream(torch, M, f, n, total, dev, rank)
+  else:
+    x0, P0, sched = kinematic_stream(torch, M, n, total, dev, rank)
+  f.init_state(x0, P0, None)
+  Rs = {k: np.atleast_2d(v) for k, v in M.obs_noise.items()}
 
   def step(i):
-    f.predict_and_update_batch(float(i) * dt, kind, zs[i], R)
+    kind, t, z = sched[i]
+    f.predict_and_update_batch(t, kind, z, Rs[kind])
 
   for i in range(W):
     step(i)
@@ -146,20 +159,59 @@ def main():
   torch.cuda.synchronize()
   wall = time.perf_counter() - t0
   dev_ms = ev0.elapsed_time(ev1)
-
-  # sanity: the filter must have tracked the truth (guards against timing a broken kernel)
-  X = f.x
-  assert torch.isfinite(X).all() and torch.isfinite(f.P).all()
-
+  assert torch.isfinite(f.x).all() and torch.isfinite(f.P).all(), "filter diverged: refusing to report a timing"
   stats = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
   if world > 1:
     dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-  wall_max, dev_ms_max = float(stats[0]), float(stats[1])
+  zdims = [f.zdims[sched[i][0]] for i in range(W, W + K)]
+  bytes_per_step = 8.0 * (2 * (D + E * E) + 2 * float(np.mean(zdims)))
+  return dict(M=M, D=D, E=E, Z=float(np.mean(zdims)), wall=float(stats[0]), dev_ms=float(stats[1]), bytes_per_step=bytes_per_step,
+              kinds=sorted(set(s[0] for s in sched[W:W + K])))
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=2000)
+  ap.add_argument("--warmup", type=int, default=100)
+  ap.add_argument("--batch", type=int, default=None, help="filters per GPU (default 65536; 16384 for --model live)")
+  ap.add_argument("--model", default="kinematic6", choices=["kinematic6", "kinematic", "live"])
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-extras", action="store_true", help="skip the additional configs reported under 'extra'")
+  args = ap.parse_args()
+
+  import torch
+  import torch.distributed as dist
+
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if not torch.cuda.is_available():
+    raise SystemExit("bench.py needs a HIP device: rednose_amd has no CPU path")
+  torch.cuda.set_device(local_rank)
+  dev = torch.device(f"cuda:{local_rank}")
+  if world > 1:
+    dist.init_process_group(backend="nccl", device_id=dev)
+
+  K, W = args.steps, args.warmup
+  n = args.batch or (16384 if args.model == "live" else 65536)
+  r = run_model(torch, dist, args, args.model, n, K, W, dev, rank, world)
+  M, D, E = r["M"], r["D"], r["E"]
+
+  extra = {}
+  if not args.no_extras and world == 1:
+    others = {"kinematic6": [("live", 16384, 420, 42), ("kinematic", 65536, 500, 50)],
+              "live": [], "kinematic": []}[args.model]
+    for om, on, oK, oW in others:
+      o = run_model(torch, dist, args, om, on, oK, oW, dev, rank, world)
+      ls = o["dev_ms"] * 1e-3 / oK
+      extra[om] = {"batch": on, "steps": oK, "value": on * oK / o["wall"], "unit": "steps/s", "launch_us": ls * 1e6,
+                   "algorithmic_bytes_per_filter_step": o["bytes_per_step"], "achieved_GBs": o["bytes_per_step"] * on / ls / 1e9,
+                   "frac_of_8TBs": o["bytes_per_step"] * on / ls / 1e9 / HBM_PEAK_GBS, "kinds": o["kinds"]}
 
   if rank == 0:
-    bytes_per_step = 8 * (2 * (D + E * E) + 2 * Z)
-    launch_s = dev_ms_max * 1e-3 / K
-    achieved = bytes_per_step * n / launch_s / 1e9
+    launch_s = r["dev_ms"] * 1e-3 / K
+    achieved = r["bytes_per_step"] * n / launch_s / 1e9
     traffic = None
     tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(tf):
@@ -168,32 +220,36 @@ def main():
       key = f"{M.name}_b{n}"
       if key in rec:
         traffic = rec[key]["hbm_bytes_per_launch"]
+    kern = "k_step_1<true>" if args.model != "live" else "k_step_{4,10,12}<true> (stream mix)"
     out = {
       "metric": "EKF predict+update steps/sec at batch N",
-      "value": n * world * K / wall_max,
+      "value": n * world * K / r["wall"],
       "unit": "steps/s",
       "n_gpus": world,
       "steps": K,
       "warmup": W,
-      "ms_per_step": wall_max * 1e3 / K,
+      "ms_per_step": r["wall"] * 1e3 / K,
       "higher_is_better": True,
       "scaling": "weak",
       "vs_baseline": None,
       "dtype": "f64",
       "data": "synthetic",
-      "config": {"workload": f"{M.name} (D={D}, E={E}, Z={Z}) fused predict+update, step-granular (state round-trips HBM each step), "
+      "config": {"workload": f"{M.name} (D={D}, E={E}, Z={r['Z']:g}) fused predict+update, step-granular (state round-trips HBM each step), "
                              f"batch {n} per GPU, shared R, scalar dt", "batch_per_gpu": n, "global_batch": n * world,
                  "parallelism": f"batch-sharded x{world}, no data-path collective"},
       "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                   "traffic": traffic, "kernel": f"k_step_{kind}<true>", "algorithmic_bytes_per_launch": bytes_per_step * n,
+                   "traffic": traffic, "kernel": kern, "algorithmic_bytes_per_launch": r["bytes_per_step"] * n,
                    "launch_us": launch_s * 1e6},
     }
     if not args.no_cpu_baseline and world == 1:
+      kind = 1 if args.model != "live" else 10
       cb, ncpu, flav = cpu_baseline(M.name, kind, M, n)
       one = cb["1core"]
       out["cpu_baseline"] = {"value": one["value"], "unit": "steps/s", "cores": 1, "kind": "port",
                              "sample": f"{ncpu} filters x {one['steps']} steps ({one['seconds']:.1f} s), {flav}, gcc -O2",
                              "all_cores": cb.get("allcores")}
+    if extra:
+      out["extra"] = extra
     print(json.dumps(out))
   if world > 1:
     dist.destroy_process_group()

@@ -1,0 +1,28 @@
+#pragma once
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+void kinematic_err_fun(double *nom_x, double *delta_x, double *out);
+void kinematic_inv_err_fun(double *nom_x, double *true_x, double *out);
+void kinematic_H_mod_fun(double *state, double *out);
+void kinematic_f_fun(double *state, double dt, double *out);
+void kinematic_F_fun(double *state, double dt, double *out);
+void kinematic_h_1(double *state, double *unused1, double *out);
+void kinematic_H_1(double *state, double *unused1, double *out);
+void kinematic_dims(int *dims);
+int kinematic_kind_zdim(int kind);
+int kinematic_kind_maha(int kind);
+int kinematic_num_kinds(void);
+void kinematic_kinds(int *out);
+int kinematic_last_error(void);
+const char *kinematic_last_error_string(void);
+void kinematic_clear_error(void);
+int kinematic_batch_predict(double *x, double *P, const double *Q, const double *dt_vec, double dt, int64_t n, int norm_quats, void *stream);
+int kinematic_batch_update_1(double *x, double *P, double *z, const double *R, int r_per_filter, const double *ea, int64_t n, int norm_quats, uint8_t *flags, void *stream);
+int kinematic_batch_predict_update_1(double *x, double *P, const double *Q, const double *dt_vec, double dt, double *z, const double *R, int r_per_filter, const double *ea, int64_t n, int norm_quats, uint8_t *flags, void *stream);
+void kinematic_predict(double *in_x, double *in_P, double *in_Q, double dt);
+void kinematic_update_1(double *in_x, double *in_P, double *in_z, double *in_R, double *in_ea);
+#ifdef __cplusplus
+}
+#endif
