@@ -272,7 +272,95 @@ __global__ __launch_bounds__(64) void k_step_{k.kind}(double* __restrict__ gx, d
   }}
 }}
 """)
+  out.append(run_kernel(spec, norm))
   return "\n".join(out)
+
+
+def run_kernel(spec, norm):
+  """T steps per launch: x and P stay in VGPRs, only z (in) / y (out) and the optional trace touch HBM."""
+  D, E = spec.dim_x, spec.dim_err
+  EE = E * E
+  zmax = max(k.zdim for k in spec.kinds)
+  cases = []
+  for k in spec.kinds:
+    Z = k.zdim
+    ea = ", nullptr" if k.ea_sym is not None else ""
+    cases.append(f"""        case {k.kind}: {{
+          double zk[{Z}], Rk[{Z * Z}];
+#pragma unroll
+          for (int i = 0; i < {Z}; i++) zk[i] = z[i];
+#pragma unroll
+          for (int i = 0; i < {Z * Z}; i++) Rk[i] = gR[t * {zmax * zmax} + i];
+          fl = update_{k.kind}_regs(x, P, zk, Rk{ea});
+#pragma unroll
+          for (int i = 0; i < {Z}; i++) z[i] = zk[i];
+          break;
+        }}""")
+  return f"""
+// ---- fused multi-step run: kinds[t], dts[t] shared by all filters; z is (T, n, {zmax}) in: z, out: y -----------
+__global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __restrict__ gP, const double* __restrict__ gQ,
+    const int32_t* __restrict__ kinds, const double* __restrict__ dts, const int64_t T, double* __restrict__ gz,
+    const double* __restrict__ gR, const int64_t n, const int norm_quats, uint8_t* __restrict__ flags,
+    double* __restrict__ tx, double* __restrict__ tP) {{
+  __shared__ __attribute__((aligned(16))) double s_x[64 * {D}];
+  __shared__ __attribute__((aligned(16))) double s_P[64 * {EE}];
+  __shared__ __attribute__((aligned(16))) double s_z[64 * {zmax}];
+  const int lane = threadIdx.x;
+  const int64_t tiles = (n + 63) >> 6;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
+    const int64_t base = tile << 6;
+    const int cnt = (n - base) < 64 ? (int)(n - base) : 64;
+    rn::tile_g2l<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_g2l<{EE}>(gP + base * {EE}, cnt, s_P, lane);
+    rn::tile_g2l<{zmax}>(gz + base * {zmax}, cnt, s_z, lane);
+    rn::wave_lds_sync();
+    double x[{D}], P[{EE}], z[{zmax}];
+    rn::lds_to_regs<{D}>(s_x, lane, x);
+    rn::lds_to_regs<{EE}>(s_P, lane, P);
+    for (int64_t t = 0; t < T; t++) {{
+      rn::lds_to_regs<{zmax}>(s_z, lane, z);
+      rn::wave_lds_sync();
+      // software prefetch: next step's observations travel while this step computes
+      rn::TilePrefetch<{zmax}> nxt;
+      if (t + 1 < T) nxt.issue(gz + ((t + 1) * n + base) * {zmax}, cnt, lane);
+      const int kind = kinds[t];
+      const double dt = dts[t];
+      predict_regs(x, P, gQ, dt);
+      {norm}
+      int fl = 0;
+      switch (kind) {{
+{chr(10).join(cases)}
+        default: break;
+      }}
+      {norm}
+      // y(t) and the optional trace go out through LDS as coalesced 16-byte stores
+      rn::regs_to_lds<{zmax}>(s_z, lane, z);
+      if (tx != nullptr) rn::regs_to_lds<{D}>(s_x, lane, x);
+      if (tP != nullptr) rn::regs_to_lds<{EE}>(s_P, lane, P);
+      rn::wave_lds_sync();
+      rn::tile_l2g<{zmax}>(gz + (t * n + base) * {zmax}, cnt, s_z, lane);
+      if (tx != nullptr) rn::tile_l2g<{D}>(tx + (t * n + base) * {D}, cnt, s_x, lane);
+      if (tP != nullptr) rn::tile_l2g<{EE}>(tP + (t * n + base) * {EE}, cnt, s_P, lane);
+      if (flags != nullptr && lane < cnt) flags[t * n + base + lane] = (uint8_t)fl;
+      rn::wave_lds_sync();
+      if (t + 1 < T) nxt.commit(s_z, cnt, lane);
+      rn::wave_lds_sync();
+    }}
+    rn::regs_to_lds<{D}>(s_x, lane, x);
+    rn::regs_to_lds<{EE}>(s_P, lane, P);
+    rn::wave_lds_sync();
+    rn::tile_l2g<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_l2g<{EE}>(gP + base * {EE}, cnt, s_P, lane);
+    rn::wave_lds_sync();
+  }}
+}}
+"""
+
+
+def launch_run():
+  return """  const int64_t tiles = (n + 63) >> 6;
+  hipLaunchKernelGGL(k_run, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P);"""
 
 
 def launch_predict():

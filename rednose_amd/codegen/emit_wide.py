@@ -289,7 +289,122 @@ __global__ __launch_bounds__(64) void k_step_{k.kind}(double* __restrict__ gx, d
   }}
 }}
 """)
+  out.append(run_kernel(spec, norm))
   return "\n".join(out)
+
+
+def run_kernel(spec, norm):
+  """T steps per launch: rows of P stay in VGPRs (x replicated), only z/y and the optional trace touch HBM."""
+  D, E = spec.dim_x, spec.dim_err
+  EE = E * E
+  DP = _even(D)
+  zmax = max(k.zdim for k in spec.kinds)
+  cases = []
+  for k in spec.kinds:
+    Z = k.zdim
+    cases.append(f"""        case {k.kind}: {{
+          double zk[{Z}], Rk[{Z * Z}];
+#pragma unroll
+          for (int i = 0; i < {Z}; i++) zk[i] = z[i];
+#pragma unroll
+          for (int i = 0; i < {Z * Z}; i++) Rk[i] = gR[t * {zmax * zmax} + i];
+          fl = update_{k.kind}_wide(x, row, col, zk, Rk, s_G + gg * {zmax * E}, s_K + gg * {zmax * E}, s_dx + gg * {E}, cc, on);
+#pragma unroll
+          for (int i = 0; i < {Z}; i++) z[i] = zk[i];
+          break;
+        }}""")
+  return f"""
+// ---- fused multi-step run: kinds[t], dts[t] shared by all filters; z is (T, n, {zmax}) in: z, out: y -----------
+__global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __restrict__ gP, const double* __restrict__ gQ,
+    const int32_t* __restrict__ kinds, const double* __restrict__ dts, const int64_t T, double* __restrict__ gz,
+    const double* __restrict__ gR, const int64_t n, const int norm_quats, uint8_t* __restrict__ flags,
+    double* __restrict__ tx, double* __restrict__ tP) {{
+  __shared__ __attribute__((aligned(16))) double s_P[FPW * {EE}];
+  __shared__ __attribute__((aligned(16))) double s_Q[{EE}];
+  __shared__ __attribute__((aligned(16))) double s_x[FPW * {DP}];
+  __shared__ __attribute__((aligned(16))) double s_z[FPW * {zmax} + 2];
+  __shared__ __attribute__((aligned(16))) double s_G[FPW * {zmax * E}];
+  __shared__ __attribute__((aligned(16))) double s_K[FPW * {zmax * E}];
+  __shared__ __attribute__((aligned(16))) double s_dx[FPW * {E}];
+  const int lane = threadIdx.x;
+  const int g = lane / GL;
+  const int c = lane % GL;
+  const bool act = c < {E};
+  const int cc = act ? c : 0;
+  rn::copy_g2l<{EE}>(gQ, {EE}, s_Q, lane);
+  const int64_t tiles = (n + FPW - 1) / FPW;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
+    const int64_t base = tile * FPW;
+    const int cnt = (n - base) < FPW ? (int)(n - base) : FPW;
+    const int gg = g < cnt ? g : 0;
+    const bool on = act && g < cnt;
+    rn::copy_g2l<FPW * {EE}>(gP + base * {EE}, cnt * {EE}, s_P, lane);
+    rn::copy_g2l<FPW * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);
+    if (lane < cnt * {zmax}) s_z[lane] = gz[base * {zmax} + lane];
+    rn::wave_lds_sync();
+    double x[{D}], row[{E}], col[{E}], z[{zmax}];
+#pragma unroll
+    for (int i = 0; i < {D}; i++) x[i] = s_x[gg * {D} + i];
+#pragma unroll
+    for (int j = 0; j < {E}; j++) row[j] = s_P[gg * {EE} + cc * {E} + j];
+    for (int64_t t = 0; t < T; t++) {{
+#pragma unroll
+      for (int i = 0; i < {zmax}; i++) z[i] = s_z[gg * {zmax} + i];
+      rn::wave_lds_sync();
+      double zn = 0.0;                                 // next step's observation, in flight during this step
+      if (t + 1 < T && lane < cnt * {zmax}) zn = gz[((t + 1) * n + base) * {zmax} + lane];
+      const int kind = kinds[t];
+      const double dt = dts[t];
+      predict_wide<true>(x, row, col, s_P + gg * {EE}, s_Q, dt, cc, on);
+      {norm}
+      int fl = 0;
+      switch (kind) {{
+{chr(10).join(cases)}
+        default: break;
+      }}
+      {norm}
+      if (c == 0 && g < cnt) {{
+#pragma unroll
+        for (int i = 0; i < {zmax}; i++) s_z[g * {zmax} + i] = z[i];
+        if (tx != nullptr) {{
+#pragma unroll
+          for (int i = 0; i < {D}; i++) s_x[g * {D} + i] = x[i];
+        }}
+        if (flags != nullptr) flags[t * n + base + g] = (uint8_t)fl;
+      }}
+      if (tP != nullptr && on) {{
+#pragma unroll
+        for (int j = 0; j < {E}; j++) s_P[g * {EE} + c * {E} + j] = row[j];
+      }}
+      rn::wave_lds_sync();
+      if (lane < cnt * {zmax}) gz[(t * n + base) * {zmax} + lane] = s_z[lane];
+      if (tx != nullptr) rn::copy_l2g<FPW * {D}>(tx + (t * n + base) * {D}, cnt * {D}, s_x, lane);
+      if (tP != nullptr) rn::copy_l2g<FPW * {EE}>(tP + (t * n + base) * {EE}, cnt * {EE}, s_P, lane);
+      rn::wave_lds_sync();
+      if (lane < cnt * {zmax}) s_z[lane] = zn;
+      rn::wave_lds_sync();
+    }}
+    if (on) {{
+#pragma unroll
+      for (int j = 0; j < {E}; j++) s_P[g * {EE} + c * {E} + j] = row[j];
+    }}
+    if (c == 0 && g < cnt) {{
+#pragma unroll
+      for (int i = 0; i < {D}; i++) s_x[g * {D} + i] = x[i];
+    }}
+    rn::wave_lds_sync();
+    rn::copy_l2g<FPW * {EE}>(gP + base * {EE}, cnt * {EE}, s_P, lane);
+    rn::copy_l2g<FPW * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);
+    rn::wave_lds_sync();
+  }}
+}}
+"""
+
+
+def launch_run():
+  return """  const int64_t tiles = (n + 1) / 2;
+  hipLaunchKernelGGL(k_run, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P);"""
 
 
 def launch_predict():

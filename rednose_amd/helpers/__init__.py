@@ -21,6 +21,7 @@ _CTYPES = {
   "double": ctypes.c_double,
   "int": ctypes.c_int,
   "int64_t": ctypes.c_int64,
+  "int32_t": ctypes.c_int32,
   "long": ctypes.c_long,
 }
 

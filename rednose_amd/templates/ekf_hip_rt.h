@@ -167,6 +167,48 @@ __device__ __forceinline__ void copy_l2g(double* __restrict__ g, int nd, const d
   if ((nd & 1) && lane == 0) g[nd - 1] = lds[nd - 1];
 }
 
+// Register-staged prefetch of one tile (cnt <= 64 filters x EPF doubles): issue() starts the coalesced global
+// loads, commit() later drops them into the wave's LDS image -- the loads fly while the caller computes.
+template <int EPF>
+struct TilePrefetch {
+  static constexpr int NV = 32 * EPF;
+  static constexpr int IT = (NV + WAVE - 1) / WAVE;
+  double2 v[IT];
+  double s[(EPF + 0)];
+  __device__ __forceinline__ void issue(const double* __restrict__ g, int cnt, int lane) {
+    if (cnt == WAVE) {
+      const double2* __restrict__ g2 = reinterpret_cast<const double2*>(g);
+#pragma unroll
+      for (int i = 0; i < IT; i++) {
+        const int idx = lane + i * WAVE;
+        if ((NV % WAVE == 0) || idx < NV) v[i] = g2[idx];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < EPF; i++) {
+        const int idx = lane + i * WAVE;
+        if (idx < cnt * EPF) s[i] = g[idx];
+      }
+    }
+  }
+  __device__ __forceinline__ void commit(double* lds, int cnt, int lane) const {
+    if (cnt == WAVE) {
+      double2* l2 = reinterpret_cast<double2*>(lds);
+#pragma unroll
+      for (int i = 0; i < IT; i++) {
+        const int idx = lane + i * WAVE;
+        if ((NV % WAVE == 0) || idx < NV) l2[idx] = v[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < EPF; i++) {
+        const int idx = lane + i * WAVE;
+        if (idx < cnt * EPF) lds[idx] = s[i];
+      }
+    }
+  }
+};
+
 // lane-per-filter register <-> LDS (filter `lane` owns lds[lane*EPF .. lane*EPF+EPF))
 template <int EPF>
 __device__ __forceinline__ void lds_to_regs(const double* lds, int lane, double (&r)[EPF]) {

@@ -1,0 +1,105 @@
+"""GPU parity of the fused multi-step entry point {name}_batch_run against the oracle's batch_run (same schedule
+conventions) and against the step-granular path (must agree bit for bit: same device code, same order)."""
+import numpy as np
+import pytest
+
+from conftest import assert_close, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+  import torch
+  assert torch.cuda.is_available()
+  from examples import ensure_generated
+  return torch, ensure_generated(["kinematic6", "live", "live_maha"])
+
+
+@pytest.mark.parametrize("n", [64, 301])
+def test_kinematic6_run_vs_oracle_and_step_path(env, n):
+  torch, gen = env
+  from oracle_lib import OracleLib
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  from examples.kinematic6_kf import Kinematic6Kalman as K6
+  o = OracleLib("kinematic6")
+  rng = np.random.default_rng(n)
+  T = 40
+  x0 = rng.normal(size=(n, 6)); A = rng.normal(size=(n, 6, 6)) * 0.3; P0 = np.eye(6)[None] + A @ A.transpose(0, 2, 1)
+  ts = np.cumsum(rng.uniform(0.005, 0.02, size=T))
+  zs = rng.normal(size=(T, n, 3))
+  R = K6.obs_noise[1]
+  f = BatchedEKF(gen, "kinematic6", K6.Q, x0[0], P0[0], 6, 6, batch=n); f.init_state(x0, P0, 0.0)
+  ys, tx, tP, _ = f.run(ts, np.ones(T, dtype=np.int32), zs.copy(), {1: R}, trace=True)
+  torch.cuda.synchronize()
+  s = BatchedEKF(gen, "kinematic6", K6.Q, x0[0], P0[0], 6, 6, batch=n); s.init_state(x0, P0, 0.0)
+  for t in range(T):
+    y = s.predict_and_update_batch(ts[t], 1, zs[t].copy(), R)
+    assert torch.equal(y, ys[t]) and torch.equal(s.x, tx[t]) and torch.equal(s.P, tP[t]), f"fused != step-granular at t={t}"
+  assert torch.equal(s.x, f.x) and torch.equal(s.P, f.P)
+  xr, Pr, zr = x0.copy(), P0.copy(), zs.copy()
+  xf = np.zeros((T, n, 6)); Pf = np.zeros((T, n, 6, 6))
+  o.batch_run(np.ones(T, dtype=np.int32), np.diff(np.concatenate([[0.0], ts])), xr, Pr, zr, np.tile(R.reshape(1, 9), (T, 1)), K6.Q, xf=xf, Pf=Pf)
+  assert_close(f.state(), xr, rtol=1e-10, floor=1e-12); assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-10, floor=1e-12)
+  assert_close(tx.cpu().numpy().reshape(T * n, -1), xf.reshape(T * n, -1), rtol=1e-10, floor=1e-12)
+  assert_close(ys.cpu().numpy().reshape(T * n, -1), zr.reshape(T * n, -1), rtol=1e-9, atol=1e-12)
+
+
+def test_live_run_vs_reference_stream_and_step_path(env):
+  torch, gen = env
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  from examples.live_kf import LiveKalman as L
+  g = golden("live_stream.npz")
+  n = 5
+  kinds, ts = g["kinds"].astype(np.int32), g["ts"]
+  T = len(kinds)
+  zs = np.tile(g["zs"][:, None, :], (1, n, 1))
+  Rs = {int(k): L.obs_noise[int(k)] for k in set(kinds.tolist())}
+  mk = lambda: BatchedEKF(gen, "live", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22, batch=n, quaternion_idxs=[3])  # noqa: E731
+  f = mk(); f.init_state(g["x0"], g["P0"], None)
+  ys, tx, tP, _ = f.run(ts, kinds, zs.copy(), Rs, trace=True)
+  torch.cuda.synchronize()
+  s = mk(); s.init_state(g["x0"], g["P0"], None)
+  for t in range(T):
+    y = s.predict_and_update_batch(float(ts[t]), int(kinds[t]), zs[t].copy(), Rs[int(kinds[t])])
+    assert torch.equal(s.x, tx[t]) and torch.equal(s.P, tP[t]) and torch.equal(y, ys[t]), f"fused != step-granular at t={t}"
+  X = tx.cpu().numpy()
+  for j in range(n):
+    assert_close(X[:, j], g["xs"], rtol=1e-8, floor=1e-10, what="fused live stream vs reference numpy path")
+  assert_close(tP.cpu().numpy()[g["P_idx"], 0].reshape(len(g["P_idx"]), -1), g["Ps"].reshape(len(g["P_idx"]), -1), rtol=1e-7, floor=1e-9)
+
+
+def test_live_maha_run_flags(env):
+  """Config 4 forward pass in miniature: gated GNSS kind inside a fused run, 2 % gross outliers, decisions vs oracle."""
+  torch, gen = env
+  from oracle_lib import OracleLib
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  from examples.live_kf import LiveKalman as L
+  g = golden("live_stream.npz")
+  o = OracleLib("live_maha")
+  n = 37
+  rng = np.random.default_rng(4)
+  kinds, ts = g["kinds"].astype(np.int32), g["ts"]
+  T = len(kinds)
+  zs = np.tile(g["zs"][:, None, :], (1, n, 1)) + rng.normal(size=(T, n, 3)) * 1e-3
+  pos_steps = np.where(kinds == 12)[0]
+  out_t = pos_steps[2:]
+  bad = rng.random(size=(len(out_t), n)) < 0.3
+  for a, t in enumerate(out_t):
+    zs[t, bad[a]] += rng.normal(size=(bad[a].sum(), 3)) * 5000.0
+  Rs = {int(k): L.obs_noise[int(k)] for k in set(kinds.tolist())}
+  f = BatchedEKF(gen, "live_maha", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22, batch=n, quaternion_idxs=[3], maha_test_kinds=[12])
+  f.init_state(g["x0"], g["P0"], None)
+  ys, _, _, fl = f.run(ts, kinds, zs.copy(), Rs, flags=True)
+  torch.cuda.synchronize()
+  xr = np.tile(g["x0"], (n, 1)); Pr = np.tile(g["P0"], (n, 1, 1)); zr = zs.copy()
+  Rt = np.zeros((T, 9))
+  for t, k in enumerate(kinds):
+    Rt[t] = L.obs_noise[int(k)].reshape(-1)
+  flr = np.zeros((T, n), dtype=np.uint8)
+  o.batch_run(kinds, np.diff(np.concatenate([[ts[0]], ts])), xr, Pr, zr, Rt, L.Q, quat_idx=3, flags=flr)
+  got = fl.cpu().numpy()
+  assert np.array_equal(got & 1, flr)
+  assert flr[out_t][bad].all() and flr.sum() >= bad.sum()
+  assert_close(f.state(), xr, rtol=1e-7, floor=1e-9)
+  assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-6, floor=1e-8)
