@@ -73,6 +73,22 @@ extern "C" {
   int RN_FN(name, batch_predict)(double *x, double *P, const double *Q, const double *dt_vec, double dt,         \
                                  int64_t n, int norm_quats, void *stream);
 
+/* fused multi-step run and offline smoothing (SURVEY.md 8b "proposed new batched exports") */
+#define RN_DECLARE_BATCH_RUN(name)                                                                               \
+  int RN_FN(name, zmax)(void);                        /* largest Z over the kinds: row stride of z in batch_run  */  \
+  /* T predict+update steps in ONE launch, x and P resident on chip between steps.  kinds (T) int32, dts (T),   \
+   * R (T, zmax*zmax; the leading Z*Z entries of row t are that step's row-major R) and z (T, n, zmax; in: z,   \
+   * out: y) are DEVICE arrays; the schedule is shared by all filters.  flags (T, n), trace_x (T, n, D) and      \
+   * trace_P (T, n, E, E) -- the FILTERED pair after each step, i.e. Estimate.xk/Pk of ekf_sym.h:32-42 -- may be  \
+   * NULL.  Replaces T calls of EKFSym::predict_and_update_batch (ekf_sym.cc:158-194). */                         \
+  int RN_FN(name, batch_run)(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts,       \
+                             int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags,    \
+                             double *trace_x, double *trace_P, void *stream);                                     \
+  /* Rauch-Tung-Striebel backward pass over a filtered trace; replaces the Python-only EKF_sym.rts_smooth        \
+   * (/root/reference/rednose/helpers/ekf_sym.py:651-690).  xs/Ps may alias xf/Pf. */                             \
+  int RN_FN(name, batch_rts)(const double *xf, const double *Pf, const double *ts, int64_t T, const double *Q,     \
+                             int64_t n, int norm_quats, double *xs, double *Ps, void *stream);
+
 #define RN_DECLARE_BATCH_KIND(name, k)                                                                           \
   /* update only.  flags (n bytes, may be NULL): bit0 = Mahalanobis gate fired (R inflated, ekf_c.c:88-94),    \
    * bit1 = non-finite state after the update */                                                               \

@@ -26,8 +26,9 @@ def source_digest(*texts):
   h = hashlib.sha256()
   for t in texts:
     h.update(t.encode("utf-8"))
-  with open(os.path.join(TEMPLATE_DIR, "ekf_hip_rt.h"), "rb") as f:
-    h.update(f.read())
+  for hdr in ("ekf_hip_rt.h", "ekf_hip_rts.h"):
+    with open(os.path.join(TEMPLATE_DIR, hdr), "rb") as f:
+      h.update(f.read())
   h.update(" ".join(HIPCC_FLAGS).encode())
   return h.hexdigest()
 

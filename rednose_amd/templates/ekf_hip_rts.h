@@ -1,0 +1,259 @@
+// ekf_hip_rts.h -- batched Rauch-Tung-Striebel backward pass (hand-written HIP, gfx950).
+//
+// Restates the reference's Python-only smoother (/root/reference/rednose/helpers/ekf_sym.py:651-690) for N
+// independent filters on the GPU.  Per backward step k (T-2 ... 0), with estimates[k] = (xk_km1, xk_k, Pk_km1, Pk_k, t):
+//     Fk      = F(xk_k, t[k+1] - t[k])                                              (:673)
+//     Ck      = solve(Pk1_k, Fk Pk_k^T)^T                                           (:677)
+//     delta   = Ck inv_err(xk1_k, xk1_n);  xk_n = err(xk_k, delta)                  (:680-684)
+//     Pk_n    = Pk_k + Ck (Pk1_n - Pk1_k) Ck^T                                      (:686)
+// including its quirks: the recursion starts from the PREDICTED state/covariance of the last step
+// (estimates[-1][0], [2], :658-659), and with norm_quats every xk1_n is renormalised in place, so all returned
+// states except the oldest are normalised (:665-667).
+// Memory plan (SURVEY.md section 7 "smoother trace capacity"): only the FILTERED trace (xk_k, Pk_k, t) is stored by
+// the forward pass; the predicted pair (xk1_k, Pk1_k) is recomputed here from the filtered pair of step k with the
+// same f/F code -- half the trace (140 GB instead of 279 GB at 2100 x 16384 live steps).  Outputs may alias inputs.
+//
+// Mapping: 32-lane group per filter (2 filters per wavefront), all E x E work matrices in the wave's private LDS,
+// lane c owns row/column c.  Pk1_k is SPD: Cholesky (unrolled, row-owner) + one forward/back substitution per lane
+// (lane c solves for column c of Ck^T).  No MFMA: 22 x 22 fp64 blocks, and the pass is bound by LDS/VALU latency.
+#pragma once
+
+#include "ekf_hip_rt.h"
+
+namespace rn {
+
+// Model must provide: D, E; f(x, dt, out[D]); F(x, dt, out[E*E]); err(nom, delta, out[D]);
+// inv_err(nom, tru, out[E]); normalize(x) (quaternion slices, no-op if none).
+template <class Model>
+__global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const double* __restrict__ Pf,
+                                            const double* __restrict__ ts, const int64_t T,
+                                            const double* __restrict__ gQ, const int64_t n, const int norm_quats,
+                                            double* __restrict__ xs, double* __restrict__ Ps) {
+  constexpr int D = Model::D, E = Model::E, EE = E * E, GL = 32, FPW = 2;
+  constexpr int DP = D + (D & 1);
+  __shared__ __attribute__((aligned(16))) double s_A[FPW * EE];   // Pk_k in, Pk_n out (HBM staging)
+  __shared__ __attribute__((aligned(16))) double s_F[FPW * EE];   // Fk
+  __shared__ __attribute__((aligned(16))) double s_M[FPW * EE];   // M = Fk Pk_k^T
+  __shared__ __attribute__((aligned(16))) double s_L[FPW * EE];   // Pk1_k -> its Cholesky factor
+  __shared__ __attribute__((aligned(16))) double s_C[FPW * EE];   // Ck
+  __shared__ __attribute__((aligned(16))) double s_D[FPW * EE];   // Pk1_n - Pk1_k
+  __shared__ __attribute__((aligned(16))) double s_N[FPW * EE];   // Pk1_n (smoothed covariance of step k+1)
+  __shared__ __attribute__((aligned(16))) double s_Q[EE];
+  __shared__ __attribute__((aligned(16))) double s_x[FPW * DP];
+  __shared__ __attribute__((aligned(16))) double s_d[FPW * E];
+  __shared__ __attribute__((aligned(16))) double s_il[FPW * E];
+
+  const int lane = threadIdx.x;
+  const int g = lane / GL;
+  const int c = lane % GL;
+  const bool act = c < E;
+  const int cc = act ? c : 0;
+  copy_g2l<EE>(gQ, EE, s_Q, lane);
+  const int64_t tiles = (n + FPW - 1) / FPW;
+
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t base = tile * FPW;
+    const int cnt = (n - base) < FPW ? (int)(n - base) : FPW;
+    const int gg = g < cnt ? g : 0;
+    const bool on = act && g < cnt;
+    double* A = s_A + gg * EE;
+    double* Fm = s_F + gg * EE;
+    double* M = s_M + gg * EE;
+    double* L = s_L + gg * EE;
+    double* C = s_C + gg * EE;
+    double* Dm = s_D + gg * EE;
+    double* Nn = s_N + gg * EE;
+    double* sd = s_d + gg * E;
+    double* sil = s_il + gg * E;
+
+    double xn1[D];          // xk1_n: smoothed state of step k+1 (replicated per lane)
+#pragma unroll
+    for (int i = 0; i < D; i++) xn1[i] = 0.0;
+
+    for (int64_t k = T - 2; k >= -1; k--) {
+      if (k < 0) {
+        // the oldest smoothed state goes out un-normalised (ekf_sym.py:665-667 never reaches it)
+        if (T >= 1) {
+          if (c == 0 && g < cnt) {
+#pragma unroll
+            for (int i = 0; i < D; i++) s_x[g * D + i] = xn1[i];
+          }
+          wave_lds_sync();
+          if (T >= 2) {
+            copy_l2g<FPW * D>(xs + base * D, cnt * D, s_x, lane);
+            copy_l2g<FPW * EE>(Ps + base * EE, cnt * EE, s_N, lane);
+          }
+          wave_lds_sync();
+        }
+        break;
+      }
+      // ---- load the filtered pair of step k ---------------------------------------------------------
+      copy_g2l<FPW * EE>(Pf + (k * n + base) * EE, cnt * EE, s_A, lane);
+      copy_g2l<FPW * D>(xf + (k * n + base) * D, cnt * D, s_x, lane);
+      const double dt = ts[k + 1] - ts[k];
+      wave_lds_sync();
+      double xk[D], x1k[D];
+#pragma unroll
+      for (int i = 0; i < D; i++) xk[i] = s_x[gg * D + i];
+      double prow[E];       // row c of Pk_k
+#pragma unroll
+      for (int j = 0; j < E; j++) prow[j] = A[cc * E + j];
+
+      // ---- recompute the predicted pair of step k+1 exactly as the forward pass did ----------------------
+      Model::f(xk, dt, x1k);
+      if (norm_quats) Model::normalize(x1k);
+      if (c == 0 && g < cnt) Model::F(xk, dt, Fm);
+      wave_lds_sync();
+      // M = Fk Pk_k^T : lane c forms column c, M[i][c] = sum_m F[i][m] Pk[c][m]
+      double mcol[E];
+#pragma unroll
+      for (int i = 0; i < E; i++) {
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < E; m++) s += Fm[i * E + m] * prow[m];
+        mcol[i] = s;
+      }
+      if (on) {
+#pragma unroll
+        for (int i = 0; i < E; i++) M[i * E + c] = mcol[i];
+      }
+      wave_lds_sync();
+      // Pk1_k = Fk (Pk_k Fk^T) + dt Q : column c, using row c of M (= column c of Pk_k Fk^T)
+      double p1col[E];
+      {
+        double mrow[E];
+#pragma unroll
+        for (int m = 0; m < E; m++) mrow[m] = M[cc * E + m];
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+          double s = 0.0;
+#pragma unroll
+          for (int m = 0; m < E; m++) s += Fm[i * E + m] * mrow[m];
+          p1col[i] = s + dt * s_Q[i * E + cc];
+        }
+      }
+      if (on) {
+#pragma unroll
+        for (int i = 0; i < E; i++) L[i * E + c] = p1col[i];
+      }
+      wave_lds_sync();
+
+      if (k == T - 2) {
+        // recursion start: smoothed(T-1) := predicted(T-1)   (estimates[-1][0], [2])
+#pragma unroll
+        for (int i = 0; i < D; i++) xn1[i] = x1k[i];
+        if (on) {
+#pragma unroll
+          for (int i = 0; i < E; i++) Nn[i * E + c] = p1col[i];
+        }
+        wave_lds_sync();
+      }
+      if (norm_quats) Model::normalize(xn1);
+      // smoothed step k+1 is final now: write it out (state after the in-place renormalisation)
+      if (c == 0 && g < cnt) {
+#pragma unroll
+        for (int i = 0; i < D; i++) s_x[g * D + i] = xn1[i];
+      }
+      wave_lds_sync();
+      copy_l2g<FPW * D>(xs + ((k + 1) * n + base) * D, cnt * D, s_x, lane);
+      copy_l2g<FPW * EE>(Ps + ((k + 1) * n + base) * EE, cnt * EE, s_N, lane);
+
+      // Dm = Pk1_n - Pk1_k (column c)
+      if (on) {
+#pragma unroll
+        for (int i = 0; i < E; i++) Dm[i * E + c] = Nn[i * E + c] - p1col[i];
+      }
+
+      // ---- Cholesky of Pk1_k in LDS, lane c owns row c -------------------------------------------------
+      {
+        double lrow[E];
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+          double s = L[cc * E + j];
+#pragma unroll
+          for (int m = 0; m < j; m++) s -= lrow[m] * L[j * E + m];
+          if (c == j) {
+            const double ljj = sqrt(s);
+            lrow[j] = ljj;
+            if (g < cnt) { L[j * E + j] = ljj; sil[j] = 1.0 / ljj; }
+          }
+          wave_lds_sync();
+          if (c > j) {
+            lrow[j] = s * sil[j];
+            if (on) L[c * E + j] = lrow[j];
+          }
+          wave_lds_sync();
+        }
+      }
+      // ---- Ck^T = Pk1_k^-1 M : lane c solves for column c ------------------------------------------------
+      double ck[E];
+#pragma unroll
+      for (int i = 0; i < E; i++) {
+        double s = mcol[i];
+#pragma unroll
+        for (int m = 0; m < i; m++) s -= L[i * E + m] * ck[m];
+        ck[i] = s * sil[i];
+      }
+#pragma unroll
+      for (int i = E - 1; i >= 0; i--) {
+        double s = ck[i];
+#pragma unroll
+        for (int m = i + 1; m < E; m++) s -= L[m * E + i] * ck[m];
+        ck[i] = s * sil[i];
+      }
+      // ck[j] = X[j][c] = Ck[c][j]: row c of Ck
+      if (on) {
+#pragma unroll
+        for (int j = 0; j < E; j++) C[c * E + j] = ck[j];
+      }
+      // ---- state: delta = Ck inv_err(xk1_k, xk1_n); xk_n = err(xk_k, delta) -------------------------------
+      {
+        double delta[E];
+        Model::inv_err(x1k, xn1, delta);
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < E; j++) s += ck[j] * delta[j];
+        if (on) sd[c] = s;
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < E; j++) delta[j] = sd[j];
+        Model::err(xk, delta, xn1);          // xk_n, becomes xk1_n of the next (older) step
+      }
+      // ---- covariance: Pk_n = Pk_k + (Ck Dm) Ck^T, row c -----------------------------------------------
+      {
+        double trow[E];
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+          double s = 0.0;
+#pragma unroll
+          for (int j = 0; j < E; j++) s += ck[j] * Dm[j * E + m];
+          trow[m] = s;
+        }
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+          double s = prow[m];
+#pragma unroll
+          for (int j = 0; j < E; j++) s += trow[j] * C[m * E + j];
+          prow[m] = s;
+        }
+      }
+      wave_lds_sync();           // everyone is done reading Nn / Dm / C
+      if (on) {
+#pragma unroll
+        for (int m = 0; m < E; m++) Nn[c * E + m] = prow[m];
+      }
+      wave_lds_sync();
+    }
+    // T == 1: nothing to smooth, the single estimate's predicted pair is not available -> copy filtered through
+    if (T == 1) {
+      copy_g2l<FPW * EE>(Pf + base * EE, cnt * EE, s_A, lane);
+      copy_g2l<FPW * D>(xf + base * D, cnt * D, s_x, lane);
+      wave_lds_sync();
+      copy_l2g<FPW * EE>(Ps + base * EE, cnt * EE, s_A, lane);
+      copy_l2g<FPW * D>(xs + base * D, cnt * D, s_x, lane);
+      wave_lds_sync();
+    }
+  }
+}
+
+}  // namespace rn

@@ -1,0 +1,83 @@
+"""GPU parity of the batched RTS smoother ({name}_batch_rts) against smoothed trajectories produced by the
+reference's own rts_smooth (tests/golden/*_rts.npz, oracle/make_golden.py)."""
+import numpy as np
+import pytest
+
+from conftest import assert_close, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+  import torch
+  assert torch.cuda.is_available()
+  from examples import ensure_generated
+  return torch, ensure_generated(["kinematic", "live"])
+
+
+def test_rts_kinematic_vs_reference(env):
+  torch, gen = env
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  g = golden("kinematic_rts.npz")
+  n = 5
+  T = len(g["t"])
+  f = BatchedEKF(gen, "kinematic", np.diag([0.1**2, 2.0**2]), np.array([0.5, 0.0]), np.eye(2), 2, 2, batch=n)
+  xf = np.tile(g["xk_k"][:, None, :], (1, n, 1)); Pf = np.tile(g["Pk_k"][:, None], (1, n, 1, 1))
+  xs, Ps = f.rts_smooth(xf, Pf, g["t"], norm_quats=False)
+  torch.cuda.synchronize()
+  xs, Ps = xs.cpu().numpy(), Ps.cpu().numpy()
+  for j in range(n):
+    assert_close(xs[:, j], g["xs_smooth"], rtol=1e-9, floor=1e-11, what="smoothed states")
+    assert_close(Ps[:, j].reshape(T, -1), g["Ps_smooth"].reshape(T, -1), rtol=1e-8, floor=1e-10, what="smoothed covs")
+
+
+def test_rts_live_vs_reference_and_inplace(env):
+  torch, gen = env
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  from examples.live_kf import LiveKalman as L
+  g = golden("live_rts.npz")
+  n = 3
+  T = len(g["t"])
+  f = BatchedEKF(gen, "live", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22, batch=n, quaternion_idxs=[3])
+  xf = np.tile(g["xk_k"][:, None, :], (1, n, 1)); Pf = np.tile(g["Pk_k"][:, None], (1, n, 1, 1))
+  xs, Ps = f.rts_smooth(xf, Pf, g["t"], norm_quats=True)
+  torch.cuda.synchronize()
+  X, P = xs.cpu().numpy(), Ps.cpu().numpy()
+  idx = g["Ps_smooth_idx"]
+  for j in range(n):
+    assert_close(X[:, j], g["xs_smooth"], rtol=1e-6, floor=1e-8, what="smoothed live states")
+    assert_close(P[idx, j].reshape(len(idx), -1), g["Ps_smooth"].reshape(len(idx), -1), rtol=1e-5, floor=1e-7, what="smoothed live covs")
+  # every smoothed quaternion but the oldest is unit-norm (the reference's in-place renormalisation quirk)
+  qn = np.linalg.norm(X[1:, 0, 3:7], axis=1)
+  assert np.abs(qn - 1).max() < 1e-14
+  # aliasing outputs onto inputs gives the same result
+  xd = torch.as_tensor(xf, device=f.device); Pd = torch.as_tensor(Pf, device=f.device)
+  xi, Pi = f.rts_smooth(xd, Pd, g["t"], norm_quats=True, inplace=True)
+  torch.cuda.synchronize()
+  assert xi.data_ptr() == xd.data_ptr() and torch.equal(xi, xs) and torch.equal(Pi, Ps)
+
+
+def test_forward_trace_then_smooth_reduces_uncertainty(env):
+  """End-to-end config-4 shape: fused forward run with trace, then the backward pass; property checks that need no
+  oracle -- smoothed covariance <= filtered covariance (trace), last smoothed == last predicted, finite everywhere."""
+  torch, gen = env
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  from examples.live_kf import LiveKalman as L
+  g = golden("live_stream.npz")
+  n = 64
+  rng = np.random.default_rng(11)
+  kinds, ts = g["kinds"].astype(np.int32), g["ts"]
+  T = len(kinds)
+  zs = np.tile(g["zs"][:, None, :], (1, n, 1)) + rng.normal(size=(T, n, 3)) * 1e-3
+  Rs = {int(k): L.obs_noise[int(k)] for k in set(kinds.tolist())}
+  f = BatchedEKF(gen, "live", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22, batch=n, quaternion_idxs=[3])
+  f.init_state(g["x0"], g["P0"], None)
+  _, tx, tP, _ = f.run(ts, kinds, zs, Rs, trace=True)
+  xs, Ps = f.rts_smooth(tx, tP, ts)
+  torch.cuda.synchronize()
+  assert torch.isfinite(xs).all() and torch.isfinite(Ps).all()
+  tr_f = torch.diagonal(tP, dim1=-2, dim2=-1).sum(-1).cpu().numpy()
+  tr_s = torch.diagonal(Ps, dim1=-2, dim2=-1).sum(-1).cpu().numpy()
+  # strictly distinct timestamps only: same-time pairs (dt = 0) smooth nothing
+  assert (tr_s[:-1] <= tr_f[:-1] * (1 + 1e-9)).all()
