@@ -121,10 +121,10 @@ def run_model(torch, dist, args, model, n, K, W, dev, rank, world):
   else:
     from examples.live_kf import LiveKalman as M
   if rank == 0:
-    ensure_generated([model])
+    ensure_generated([model], **({'folder': os.environ['RN_GEN_DIR']} if 'RN_GEN_DIR' in os.environ else {}))
   if world > 1:
     dist.barrier()
-  gen = ensure_generated([model])
+  gen = ensure_generated([model], **({'folder': os.environ['RN_GEN_DIR']} if 'RN_GEN_DIR' in os.environ else {}))
   D, E = M.initial_x.shape[0], M.initial_P_diag.shape[0]
   quat = list(getattr(M, "quaternion_idxs", []))
   f = BatchedEKF(gen, M.name, M.Q, M.initial_x, np.diag(M.initial_P_diag), D, E, batch=n, device=dev, quaternion_idxs=quat)

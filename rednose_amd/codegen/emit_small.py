@@ -21,6 +21,8 @@ Algebra emitted (reference lines in /root/reference/rednose/templates/ekf_c.c):
                   which is the same polynomial in the same inputs -- including the property that the
                   rounding error of B is cancelled to first order by the correction term.
 """
+import os
+
 import sympy as sp
 
 from rednose_amd.codegen.lower import Block, vector_names
@@ -166,8 +168,20 @@ def update_regs(spec, k):
   return "\n".join([head] + _ind(b) + ["}"]), He
 
 
+def _tune():
+  """Generation-time tuning knobs (A/B experiments): RN_TUNE="waves=1" -> amdgpu_waves_per_eu(1,1) on the step kernels."""
+  out = {}
+  for kv in os.environ.get("RN_TUNE", "").split(","):
+    if "=" in kv:
+      k, v = kv.split("=")
+      out[k.strip()] = v.strip()
+  return out
+
+
 def kernels(spec):
   """Device functions + __global__ kernels of family S for every kind."""
+  tune = _tune()
+  kattr = f" __attribute__((amdgpu_waves_per_eu({tune['waves']}, {tune['waves']})))" if "waves" in tune else ""
   D, E = spec.dim_x, spec.dim_err
   EE = E * E
   out = []
@@ -217,7 +231,7 @@ __global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double*
     out.append(f"""
 // ---- kind {k.kind}: [predict +] update, state round-trips HBM once per launch --------------------------
 template <bool DO_PREDICT>
-__global__ __launch_bounds__(64) void k_step_{k.kind}(double* __restrict__ gx, double* __restrict__ gP,
+__global__ __launch_bounds__(64){kattr} void k_step_{k.kind}(double* __restrict__ gx, double* __restrict__ gP,
     double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const double* __restrict__ gea,
     const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
     const int norm_quats, uint8_t* __restrict__ flags) {{

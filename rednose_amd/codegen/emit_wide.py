@@ -162,7 +162,7 @@ def update_fn(spec, k):
   return "\n".join([head] + _ind(b) + ["}"]), He
 
 
-def kernels(spec):
+def kernels(spec, step_kernels=True):
   D, E = spec.dim_x, spec.dim_err
   EE = E * E
   DP = _even(D)
@@ -186,7 +186,8 @@ def kernels(spec):
   if (gQ != nullptr) rn::copy_g2l<{EE}>(gQ, {EE}, s_Q, lane);
   const int64_t tiles = (n + FPW - 1) / FPW;"""
 
-  out.append(f"""
+  if step_kernels:
+   out.append(f"""
 // ---- predict only ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double* __restrict__ gP,
     const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double*
   }}
 }}
 """)
-  for k in spec.kinds:
+  for k in (spec.kinds if step_kernels else []):
     Z = k.zdim
     ZZ = Z * Z
     out.append(f"""

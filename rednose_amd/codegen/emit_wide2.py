@@ -1,0 +1,370 @@
+"""Kernel family W, step-granular kernels, second structure: scalar phase lane-per-filter, matrix phase lane-group.
+
+emit_wide.py evaluates the x-dependent scalars (f, F, h, H.H_mod, err_fun: ~2 000 instructions with the
+accelerometer kind's gravity/rotation terms) redundantly in all 32 lanes of a filter's lane group, twice per
+wavefront, and keeps them in VGPRs next to the covariance rows: 256 VGPRs + AGPR spills, 1 wave per SIMD, 13.7 % of
+the HBM roofline on live (round-1 profile).  Here a wavefront owns a tile of FT filters and works in three phases:
+
+  phase 1  lane l = filter l of the tile (FT lanes active): x, z -> f, F non-zeros, normalise, h, He = H.H_mod
+           non-zeros, y = z - h; results go to the filter's scalar SLOT in LDS.  One evaluation per filter.
+  phase 2  for each pair of filters: the 32-lane-group-per-filter covariance algebra of emit_wide.py, but every
+           x-dependent coefficient is an LDS broadcast read from the slot; the next pair's P record is prefetched
+           into registers while the current pair computes.  dx goes back to the slot.
+  phase 3  lane l = filter l again: x' = err_fun(x, dx), renormalise, x / y / flags leave through LDS, coalesced.
+
+The algebra and its order are unchanged (see emit_wide.py / emit_small.py docstrings); only who evaluates the
+scalars changed, so the results are bit-identical to the first structure.
+"""
+import os
+
+import sympy as sp
+
+from rednose_amd.codegen.lower import Block, vector_names
+from rednose_amd.codegen.emit_common import SMat, term, sum_terms
+
+G_LANES = 32
+
+
+def _ind(lines, n=2):
+  pad = " " * n
+  return [pad + s for s in lines]
+
+
+SCHED_FENCE = "rn::reg_fence();"
+
+
+def _fenced(lines, every):
+  """Insert a scheduling fence every `every` statements: keeps hipcc from hoisting dozens of LDS reads / CSE
+  temporaries at once (460 registers without it -> one wave per SIMD)."""
+  if every <= 0:
+    return list(lines)
+  out = []
+  for i, ln in enumerate(lines):
+    out.append(ln)
+    if (i + 1) % every == 0:
+      out.append(SCHED_FENCE)
+  return out
+
+
+def _knob(name, default):
+  return int(os.environ.get(name, str(default)))
+
+
+def _odd(n):
+  return n if n & 1 else n + 1
+
+
+def tile_filters():
+  return int(os.environ.get("RN_WIDE_FT", "16"))
+
+
+class Layout:
+  """Per-filter scalar slot in LDS (doubles)."""
+
+  def __init__(self, spec, f_vars, he_vars_by_kind):
+    D, E = spec.dim_x, spec.dim_err
+    self.zmax = max(k.zdim for k in spec.kinds)
+    self.nf = len(f_vars)
+    self.nh = max([len(v) for v in he_vars_by_kind.values()] + [0])
+    self.OFF_X = 0
+    self.OFF_F = self.OFF_X + D
+    self.OFF_Y = self.OFF_F + self.nf
+    self.OFF_HE = self.OFF_Y + self.zmax
+    self.OFF_DX = self.OFF_HE + self.nh
+    self.OFF_DT = self.OFF_DX + E
+    self.OFF_FL = self.OFF_DT + 1
+    self.SLOT = _odd(self.OFF_FL + 1)     # odd stride: lane-per-filter ds_*_b64 accesses hit 32 distinct bank pairs
+
+
+def _lowered_predict(spec):
+  D, M = spec.dim_x, spec.dim_main_err
+  names = {**vector_names(spec.x_sym, 'x'), spec.dt_sym: 'dt'}
+  blk = Block(names, tmp_prefix="pt")
+  for i in range(D):
+    blk.add(f"xn_{i}", spec.f_sym[i])
+  fmtF = lambda i, j: f"F_{i}_{j}"  # noqa: E731
+  for i in range(M):
+    for j in range(M):
+      blk.add(fmtF(i, j), spec.F_sym[i, j])
+  stmts, st = blk.lower()
+  F = SMat.identity_padded(SMat.from_structure(M, M, st, fmtF), spec.dim_err)
+  f_vars = [c[1] for row in F.e for c in row if c is not None and c[0] == 'var']
+  return stmts, st, F, f_vars
+
+
+def _lowered_obs(spec, k):
+  E, Z = spec.dim_err, k.zdim
+  names = dict(vector_names(spec.x_sym, 'x'))
+  Herr = sp.Matrix(k.H_sym) * sp.Matrix(spec.H_mod_sym)
+  blk = Block(names, tmp_prefix="ut")
+  for i in range(Z):
+    blk.add(f"hx_{i}", k.h_sym[i])
+  fmtH = lambda i, j: f"He_{i}_{j}"  # noqa: E731
+  for i in range(Z):
+    for j in range(E):
+      blk.add(fmtH(i, j), Herr[i, j])
+  stmts, st = blk.lower()
+  He = SMat.from_structure(Z, E, st, fmtH)
+  he_vars = [c[1] for row in He.e for c in row if c is not None and c[0] == 'var']
+  return stmts, st, He, he_vars
+
+
+def _slotted(smat, var_list, off):
+  """Copy of `smat` whose named entries read the filter's LDS slot instead of a register."""
+  m = SMat(smat.rows, smat.cols)
+  index = {v: i for i, v in enumerate(var_list)}
+  for i in range(smat.rows):
+    for j in range(smat.cols):
+      e = smat.e[i][j]
+      if e is not None and e[0] == 'var':
+        m.e[i][j] = ('var', f"sl[{off + index[e[1]]}]")
+      else:
+        m.e[i][j] = e
+  return m
+
+
+def device_functions(spec):
+  D, E = spec.dim_x, spec.dim_err
+  INL = "__noinline__" if os.environ.get("RN_WIDE_INLINE", "1") == "0" else "__forceinline__"
+  pst, pstruct, F, f_vars = _lowered_predict(spec)
+  obs = {k.kind: _lowered_obs(spec, k) for k in spec.kinds}
+  lay = Layout(spec, f_vars, {kk: v[3] for kk, v in obs.items()})
+  out = []
+
+  # ---- phase 1: scalars of predict ---------------------------------------------------------------
+  # All phase functions are __noinline__ with pointer-only interfaces (state lives in LDS between them): inlined into
+  # the pair loop hipcc keeps ~460 registers live (1 wave/SIMD); as separate functions each stays under 256.
+  quat = "".join(f" rn::normalize_quat<{D}>(x, {q});" for q in spec.quaternion_idxs)
+  normq = f"if (norm_quats) {{{quat} }}" if spec.quaternion_idxs else "(void)norm_quats;"
+  b = [f"double x[{D}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = xin[i];"]
+  b += _fenced(pst, _knob("RN_WIDE_FENCE1", 0))
+  for i, v in enumerate(f_vars):
+    b.append(f"sl[{lay.OFF_F + i}] = {v};")
+  for i in range(D):
+    kind, val = pstruct[f"xn_{i}"]
+    b.append(f"x[{i}] = xn_{i};" if kind == 'expr' else f"x[{i}] = {float(val)!r};")
+  b.append(normq)
+  b.append(f"sl[{lay.OFF_DT}] = dt;")
+  b += ["#pragma unroll", f"for (int i = 0; i < {D}; i++) sl[{lay.OFF_X} + i] = x[i];"]
+  out.append("\n".join(["__device__ {INL} void scal_predict(const double* xin, const double dt, double* sl, const int norm_quats) {"] + _ind(b) + ["}"]))
+
+  # ---- phase 1: scalars of each observation kind ---------------------------------------------------
+  for k in spec.kinds:
+    stmts, st, He, he_vars = obs[k.kind]
+    Z = k.zdim
+    b = [f"double x[{D}], z[{Z}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = sl[{lay.OFF_X} + i];",
+         "#pragma unroll", f"for (int i = 0; i < {Z}; i++) z[i] = zin[i];"]
+    b += _fenced(stmts, _knob("RN_WIDE_FENCE1", 0))
+    for i in range(Z):
+      kind, val = st[f"hx_{i}"]
+      hx = f"hx_{i}" if kind == 'expr' else repr(float(val))
+      b.append(f"sl[{lay.OFF_Y + i}] = z[{i}] - {hx};")
+    for i, v in enumerate(he_vars):
+      b.append(f"sl[{lay.OFF_HE + i}] = {v};")
+    out.append("\n".join([f"__device__ {INL} void scal_obs_{k.kind}(double* sl, const double* zin) {{"] + _ind(b) + ["}"]))
+
+  # ---- phase 3: error injection ----------------------------------------------------------------------
+  nom, delta = spec.err_eqs[1], spec.err_eqs[2]
+  enames = dict(vector_names(nom, 'x'))
+  enames.update({(delta, i, 0): f"sl[{lay.OFF_DX + i}]" for i in range(E)})
+  eblk = Block(enames, tmp_prefix="et")
+  for i in range(D):
+    eblk.add(f"xi_{i}", sp.Matrix(spec.err_eqs[0])[i])
+  estmts, est = eblk.lower()
+  b = [f"double x[{D}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = sl[{lay.OFF_X} + i];"]
+  b += list(estmts)
+  for i in range(D):
+    kind, val = est[f"xi_{i}"]
+    b.append(f"x[{i}] = xi_{i};" if kind == 'expr' else f"x[{i}] = {float(val)!r};")
+  b.append(normq)
+  b += ["#pragma unroll", f"for (int i = 0; i < {D}; i++) xout[i] = x[i];", "double acc = 0.0;", "#pragma unroll",
+        f"for (int i = 0; i < {D}; i++) acc += x[i];", "return (acc - acc == 0.0) ? 0 : 2;"]
+  out.append("\n".join(["__device__ {INL} int scal_inject(const double* sl, double* xout, const int norm_quats) {"] + _ind(b) + ["}"]))
+
+  # ---- phase 2: predict, matrix part (P in sP -> P' in sP) ------------------------------------------------
+  Fs = _slotted(F, f_vars, lay.OFF_F)
+  ch = max(1, _knob("RN_WIDE_CHUNK", 6))
+  b = [f"const double dt = sl[{lay.OFF_DT}];", f"double row[{E}], a[{E}], col[{E}];", "#pragma unroll",
+       f"for (int j = 0; j < {E}; j++) row[j] = sP[cc * {E} + j];"]
+  for i in range(E):
+    b.append(f"a[{i}] = {sum_terms(term(cf, f'row[{kk}]') for kk, cf in Fs.row_nz(i))};")
+  b += ["if (act) {", "#pragma unroll", f"  for (int i = 0; i < {E}; i++) sP[cc * {E} + i] = a[i];", "}", "rn::wave_lds_sync();",
+        "#pragma unroll", f"for (int k = 0; k < {E}; k++) a[k] = sP[k * {E} + cc];"]
+  for i in range(E):
+    b.append(f"col[{i}] = {sum_terms(term(cf, f'a[{kk}]') for kk, cf in Fs.row_nz(i))} + dt*gQ[{i} * {E} + cc];")
+  b += ["rn::wave_lds_sync();", "if (act) {", "#pragma unroll", f"  for (int k = 0; k < {E}; k++) sP[k * {E} + cc] = col[k];", "}",
+        "rn::wave_lds_sync();"]
+  out.append("\n".join(["__device__ {INL} void mat_predict(double* sP, const double* __restrict__ gQ, const double* sl, const int cc, const bool act) {"]
+                        + _ind(b) + ["}"]))
+
+  # ---- phase 2: update, matrix part ----------------------------------------------------------------------
+  for k in spec.kinds:
+    _, _, He, he_vars = obs[k.kind]
+    Hs = _slotted(He, he_vars, lay.OFF_HE)
+    Z = k.zdim
+    b = [f"double row[{E}], col[{E}], R[{Z * Z}];", "#pragma unroll", f"for (int j = 0; j < {E}; j++) row[j] = sP[cc * {E} + j];",
+         "#pragma unroll", f"for (int kq = 0; kq < {E}; kq++) col[kq] = sP[kq * {E} + cc];",
+         "#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) R[i] = gR[i];", "rn::wave_lds_sync();"]
+    for zi in range(Z):
+      nz = Hs.row_nz(zi)
+      b.append(f"const double G_{zi} = {sum_terms(term(cf, f'col[{kk}]') for kk, cf in nz)};")
+      b.append(f"const double Gt_{zi} = {sum_terms(term(cf, f'row[{kk}]') for kk, cf in nz)};")
+    b.append("if (act) { " + " ".join(f"sG[{zi} * {E} + cc] = G_{zi};" for zi in range(Z)) + " }")
+    b.append("rn::wave_lds_sync();")
+    b.append(SCHED_FENCE)
+    b.append(f"double HPH[{Z * Z}], Rl[{Z * Z}], S[{Z * Z}], L[{Z * Z}], iL[{Z}];")
+    for zi in range(Z):
+      for w in range(Z):
+        b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))};")
+      b.append(SCHED_FENCE)
+    b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}", f"rn::chol_factor<{Z}>(S, L, iL);",
+          "int gated = 0;"]
+    if k.maha_test:
+      b += ["{", f"  double v[{Z}] = {{{', '.join(f'sl[{lay.OFF_Y + i}]' for i in range(Z))}}};", f"  rn::chol_forward<{Z}>(L, iL, v);",
+            "  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]" for i in range(Z)) + ";", f"  if (d2 > {k.maha_thresh!r}) {{", "    gated = 1;",
+            "#pragma unroll", f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}",
+            f"    rn::chol_factor<{Z}>(S, L, iL);", "  }", "}"]
+    b.append(f"double kk[{Z}] = {{{', '.join(f'Gt_{zi}' for zi in range(Z))}}};")
+    b.append(f"rn::chol_solve<{Z}>(L, iL, kk);")
+    b.append("const double dxc = " + " + ".join(f"kk[{zi}]*sl[{lay.OFF_Y + zi}]" for zi in range(Z)) + ";")
+    ch = _knob("RN_WIDE_CHUNK", 6)
+    for j in range(E):
+      b.append(f"row[{j}] -= " + " + ".join(f"kk[{zi}]*sG[{zi * E + j}]" for zi in range(Z)) + ";")
+      if (j + 1) % ch == 0:
+        b.append(SCHED_FENCE)
+    b.append(SCHED_FENCE)
+    for zi in range(Z):
+      c = sum_terms(term(cf, f"row[{j}]") for j, cf in Hs.row_nz(zi))
+      kr = " + ".join(f"kk[{w}]*Rl[{w * Z + zi}]" for w in range(Z))
+      b.append(f"const double Dm_{zi} = ({kr}) - ({c});")
+      b.append(SCHED_FENCE)
+    b.append("if (act) { " + " ".join(f"sK[{zi} * {E} + cc] = kk[{zi}];" for zi in range(Z)) + f" sw[{lay.OFF_DX} + cc] = dxc; if (cc == 0) sw[{lay.OFF_FL}] = (double)gated; }}")
+    b.append("rn::wave_lds_sync();")
+    for j in range(E):
+      b.append(f"row[{j}] += " + " + ".join(f"Dm_{zi}*sK[{zi * E + j}]" for zi in range(Z)) + ";")
+      if (j + 1) % ch == 0:
+        b.append(SCHED_FENCE)
+    b += ["if (act) {", "#pragma unroll", f"  for (int j = 0; j < {E}; j++) sP[cc * {E} + j] = row[j];", "}", "rn::wave_lds_sync();"]
+    out.append("\n".join([f"__device__ {INL} void mat_update_{k.kind}(double* sP, const double* __restrict__ gR, const double* sl, double* sw, "
+                          "double* sG, double* sK, const int cc, const bool act) {"] + _ind(b) + ["}"]))
+  return "\n".join(out).replace("{INL}", INL), lay
+
+
+def kernels(spec):
+  D, E = spec.dim_x, spec.dim_err
+  EE = E * E
+  FT = tile_filters()
+  fn_text, lay = device_functions(spec)
+  out = [f"// ---- family W, three-phase step kernels (tile of {FT} filters per wavefront, slot = {lay.SLOT} doubles) ----",
+         f"constexpr int FT2 = {FT};", f"constexpr int SLOT = {lay.SLOT};", fn_text]
+  lb = os.environ.get("RN_WIDE_LB", "")
+  lbs = f"__launch_bounds__(64, {lb})" if lb and lb != "0" else "__launch_bounds__(64)"
+
+  def kernel(kname, k=None):
+    upd = k is not None
+    Z = k.zdim if upd else 1
+    ZZ = Z * Z
+    tmpl = "template <bool DO_PREDICT>\n" if upd else ""
+    dop = "DO_PREDICT" if upd else "true"
+    sig_obs = ("double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const double* __restrict__ gea,\n    "
+               if upd else "")
+    flags_arg = ", uint8_t* __restrict__ flags" if upd else ""
+    L = []
+    A = L.append
+    A(f"{tmpl}__global__ {lbs} void {kname}(double* __restrict__ gx, double* __restrict__ gP,")
+    A(f"    {sig_obs}const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,")
+    A(f"    const int norm_quats{flags_arg}) {{")
+    A(f"  __shared__ __attribute__((aligned(16))) double s_P[2 * {EE}];")
+    A(f"  __shared__ __attribute__((aligned(16))) double s_x[FT2 * {D} + 2];")
+    if upd:
+      A(f"  __shared__ __attribute__((aligned(16))) double s_z[FT2 * {Z} + 2];")
+      A(f"  __shared__ __attribute__((aligned(16))) double s_G[2 * {Z * E}];")
+      A(f"  __shared__ __attribute__((aligned(16))) double s_K[2 * {Z * E}];")
+    A("  __shared__ __attribute__((aligned(16))) double s_sl[FT2 * SLOT];")
+    A("  const int lane = threadIdx.x;")
+    A(f"  const int g = lane / {G_LANES};")
+    A(f"  const int c = lane % {G_LANES};")
+    A(f"  const bool act = c < {E};")
+    A("  const int cc = act ? c : 0;")
+    A("  const int64_t tiles = (n + FT2 - 1) / FT2;")
+    A("  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {")
+    A("    const int64_t base = tile * FT2;")
+    A("    const int cnt = (n - base) < FT2 ? (int)(n - base) : FT2;")
+    A("    // ---------------- phase 1: lane l = filter l, x-dependent scalars -> LDS slot ----------------")
+    A(f"    rn::copy_g2l<FT2 * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);")
+    if upd:
+      A(f"    rn::copy_g2l<FT2 * {Z}>(gz + base * {Z}, cnt * {Z}, s_z, lane);")
+    A(f"    rn::PairPrefetch<{EE}> pf;")
+    A(f"    pf.issue(gP + base * {EE}, (cnt < 2 ? cnt : 2) * {EE}, lane);")
+    A("    rn::wave_lds_sync();")
+    A("    if (lane < cnt) {")
+    A("      double* sl = s_sl + lane * SLOT;")
+    A(f"      if ({dop}) {{")
+    A("        const double dt = gdt != nullptr ? gdt[base + lane] : dt_scalar;")
+    A(f"        scal_predict(s_x + lane * {D}, dt, sl, norm_quats);")
+    A("      } else {")
+    A("#pragma unroll")
+    A(f"        for (int i = 0; i < {D}; i++) sl[{lay.OFF_X} + i] = s_x[lane * {D} + i];")
+    A("      }")
+    if upd:
+      A(f"      scal_obs_{k.kind}(sl, s_z + lane * {Z});")
+    A("    }")
+    A("    rn::wave_lds_sync();")
+    A("    // ---------------- phase 2: 32-lane group per filter, covariance algebra ------------------------")
+    A("    const int npairs = (cnt + 1) >> 1;")
+    A("    for (int p = 0; p < npairs; p++) {")
+    A("      const int pcnt = (cnt - 2 * p) < 2 ? (cnt - 2 * p) : 2;")
+    A(f"      pf.commit(s_P, pcnt * {EE}, lane);")
+    A("      rn::wave_lds_sync();")
+    A(f"      if (p + 1 < npairs) pf.issue(gP + (base + 2 * (p + 1)) * {EE}, ((cnt - 2 * (p + 1)) < 2 ? (cnt - 2 * (p + 1)) : 2) * {EE}, lane);")
+    A("      const int gg = g < pcnt ? g : 0;")
+    A("      const bool on = act && g < pcnt;")
+    A("      double* sl = s_sl + (2 * p + gg) * SLOT;")
+    A(f"      if ({dop}) mat_predict(s_P + gg * {EE}, gQ, sl, cc, on);")
+    if upd:
+      A(f"      mat_update_{k.kind}(s_P + gg * {EE}, r_per_filter ? gR + (base + 2 * p + gg) * {ZZ} : gR, sl, sl, s_G + gg * {Z * E}, s_K + gg * {Z * E}, cc, on);")
+    A(f"      rn::copy_l2g<2 * {EE}>(gP + (base + 2 * p) * {EE}, pcnt * {EE}, s_P, lane);")
+    A("      rn::wave_lds_sync();")
+    A("    }")
+    A("    // ---------------- phase 3: lane l = filter l, inject the error state, write x / y / flags ---------")
+    A("    if (lane < cnt) {")
+    A("      const double* sl = s_sl + lane * SLOT;")
+    if upd:
+      A(f"      int fl = scal_inject(sl, s_x + lane * {D}, norm_quats);")
+      A("#pragma unroll")
+      A(f"      for (int i = 0; i < {Z}; i++) s_z[lane * {Z} + i] = sl[{lay.OFF_Y} + i];")
+      A(f"      if (flags != nullptr) flags[base + lane] = (uint8_t)(fl | (sl[{lay.OFF_FL}] != 0.0 ? 1 : 0));")
+    else:
+      A("#pragma unroll")
+      A(f"      for (int i = 0; i < {D}; i++) s_x[lane * {D} + i] = sl[{lay.OFF_X} + i];")
+    A("    }")
+    A("    rn::wave_lds_sync();")
+    A(f"    rn::copy_l2g<FT2 * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);")
+    if upd:
+      A(f"    rn::copy_l2g<FT2 * {Z}>(gz + base * {Z}, cnt * {Z}, s_z, lane);")
+    A("    rn::wave_lds_sync();")
+    A("  }")
+    A("}")
+    return "\n".join(L) + "\n"
+
+  out.append(kernel("k_predict"))
+  for k in spec.kinds:
+    out.append(kernel(f"k_step_{k.kind}", k))
+  return "\n".join(out)
+
+
+def launch_predict():
+  return """  const int64_t tiles = (n + FT2 - 1) / FT2;
+  hipLaunchKernelGGL(k_predict, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     x, P, Q, dt_vec, dt, n, norm_quats);"""
+
+
+def launch_step(kind, do_predict):
+  tf = "true" if do_predict else "false"
+  if do_predict:
+    args = "x, P, z, R, r_per_filter, ea, Q, dt_vec, dt, n, norm_quats, flags"
+  else:
+    args = "x, P, z, R, r_per_filter, ea, nullptr, nullptr, 0.0, n, norm_quats, flags"
+  return f"""  const int64_t tiles = (n + FT2 - 1) / FT2;
+  hipLaunchKernelGGL(k_step_{kind}<{tf}>, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     {args});"""

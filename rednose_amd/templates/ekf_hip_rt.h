@@ -89,6 +89,14 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Compiler-only fence: no instruction is emitted, but values loaded from LDS before it are not kept in registers
+// across it and the scheduler does not move code over it.  Used by the generated covariance algebra to bound live
+// ranges (without it hipcc keeps ~460 registers live in the wide-family update and occupancy drops to 1 wave/SIMD).
+__device__ __forceinline__ void reg_fence() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // Copy one tile (cnt <= 64 filters x EPF doubles, contiguous in HBM) into this wave's LDS region.
 // Full tiles move as 16-byte vectors, lane l taking vectors l, l+64, ... (1 KiB per wave-instruction).
 template <int EPF>
@@ -206,6 +214,35 @@ struct TilePrefetch {
         if (idx < cnt * EPF) lds[idx] = s[i];
       }
     }
+  }
+};
+
+// Register-staged prefetch of up to MAXD contiguous doubles (one or two filters' P records): issue() starts the
+// coalesced loads, commit() drops them into LDS later, so they fly while the previous pair is being processed.
+template <int MAXD>
+struct PairPrefetch {
+  static constexpr int IT = (MAXD + WAVE - 1) / WAVE;          // MAXD doubles per filter, two filters -> MAXD double2
+  double2 v[IT];
+  double tail;
+  __device__ __forceinline__ void issue(const double* __restrict__ g, int nd, int lane) {
+    const int nv = nd >> 1;
+    const double2* __restrict__ g2 = reinterpret_cast<const double2*>(g);
+#pragma unroll
+    for (int i = 0; i < IT; i++) {
+      const int idx = lane + i * WAVE;
+      if (idx < nv) v[i] = g2[idx];
+    }
+    if ((nd & 1) && lane == 0) tail = g[nd - 1];
+  }
+  __device__ __forceinline__ void commit(double* lds, int nd, int lane) const {
+    const int nv = nd >> 1;
+    double2* l2 = reinterpret_cast<double2*>(lds);
+#pragma unroll
+    for (int i = 0; i < IT; i++) {
+      const int idx = lane + i * WAVE;
+      if (idx < nv) l2[idx] = v[i];
+    }
+    if ((nd & 1) && lane == 0) lds[nd - 1] = tail;
   }
 };
 
