@@ -209,6 +209,31 @@ def main():
                    "algorithmic_bytes_per_filter_step": o["bytes_per_step"], "achieved_GBs": o["bytes_per_step"] * on / ls / 1e9,
                    "frac_of_8TBs": o["bytes_per_step"] * on / ls / 1e9 / HBM_PEAK_GBS, "kinds": o["kinds"]}
 
+  if not args.no_extras and world == 1 and args.model != "live":
+    # fused multi-step mode ({name}_batch_run): x and P stay on chip for T steps, only z / y cross HBM
+    from examples import ensure_generated
+    from rednose_amd.helpers.ekf_sym import BatchedEKF
+    gen = ensure_generated([args.model])
+    f = BatchedEKF(gen, M.name, M.Q, M.initial_x, np.diag(M.initial_P_diag), D, E, batch=n, device=dev)
+    T = 500
+    Z = int(np.atleast_2d(M.obs_noise[1]).shape[0])
+    zs = torch.randn((T, n, Z), dtype=torch.float64, device=dev) * 0.1
+    ts = np.arange(1, T + 1) * 0.01
+    f.init_state(M.initial_x, np.diag(M.initial_P_diag), 0.0)
+    f.run(ts, np.ones(T, dtype=np.int32), zs.clone(), {1: M.obs_noise[1]})      # warm-up
+    torch.cuda.synchronize()
+    f.init_state(M.initial_x, np.diag(M.initial_P_diag), 0.0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    f.run(ts, np.ones(T, dtype=np.int32), zs, {1: M.obs_noise[1]})
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    moved = 8.0 * (2 * Z) * n * T + 8.0 * 2 * (D + E * E) * n
+    extra["fused_run"] = {"model": M.name, "batch": n, "T": T, "value": n * T / (ms * 1e-3), "unit": "steps/s", "ms": ms,
+                          "hbm_bytes_moved": moved, "achieved_GBs": moved / (ms * 1e-3) / 1e9,
+                          "note": "state resident in VGPRs for T steps; bound by fp64 VALU issue, not HBM"}
+
   if rank == 0:
     launch_s = r["dev_ms"] * 1e-3 / K
     achieved = r["bytes_per_step"] * n / launch_s / 1e9

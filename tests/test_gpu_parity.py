@@ -234,3 +234,33 @@ def test_error_conventions(gen_dir, torch_cuda):
   f.predict(0.5)
   with pytest.raises(AssertionError):
     f.predict(0.25)                                                                   # dt < 0 (ekf_sym.py:459)
+
+
+# ------------------------------------------------------------------ late observations: batched rewind ring
+def test_batched_rewind_matches_reference_class(gen_dir, torch_cuda):
+  """/root/reference/examples/test_compare.py:103-120 (samples 20 and 40 arrive swapped) for a whole batch: every filter
+  must follow the trajectory the reference's own EKF_sym produced (tests/golden/compare_rewind.npz)."""
+  torch = torch_cuda
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  g = golden("compare_rewind.npz")
+  n = 130
+  f = BatchedEKF(gen_dir, "kinematic", np.diag([0.1**2, 2.0**2]), np.array([0.5, 0.0]), np.eye(2), 2, 2, batch=n, rewind_to_keep=512)
+  R = np.array([[0.1**2]])
+  for i, (t, meas) in enumerate(zip(g["ts"], g["zs"])):
+    r = f.predict_and_update_batch(float(t), 1, np.full((n, 1), meas), R)
+    assert r is not None
+    assert abs(f.get_filter_time() - g["filter_times"][i]) < 1e-12
+    if i in (19, 20, 21, 39, 40, 41, 60, 499):
+      X, P = f.state(), f.covs()
+      assert_close(X, np.tile(g["xs"][i], (n, 1)), rtol=1e-10, floor=1e-12, what=f"state step {i}")
+      assert_close(P.reshape(n, -1), np.tile(g["Ps"][i].reshape(1, -1), (n, 1)), rtol=1e-10, floor=1e-12, what=f"cov step {i}")
+  assert len(f.rewind_t) == len(f.rewind_states) == len(f.rewind_obscache) == 500 - 0 if 500 < 512 else 512
+  # an observation more than max_rewind_age behind the newest checkpoint is dropped, state untouched
+  x_before = f.state().copy()
+  assert f.predict_and_update_batch(1.0, 1, np.zeros((n, 1)), R) is None
+  assert np.array_equal(f.state(), x_before)
+  # without the ring a late observation is an error, like dt < 0 in the reference (ekf_sym.py:459)
+  h = BatchedEKF(gen_dir, "kinematic", np.diag([0.1**2, 2.0**2]), np.array([0.5, 0.0]), np.eye(2), 2, 2, batch=4)
+  h.predict_and_update_batch(1.0, 1, np.zeros((4, 1)), R)
+  with pytest.raises(AssertionError):
+    h.predict_and_update_batch(0.5, 1, np.zeros((4, 1)), R)
