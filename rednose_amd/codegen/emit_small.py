@@ -74,7 +74,7 @@ def predict_regs(spec):
     kind, val = st[f"xn_{i}"]
     body.append(f"x[{i}] = xn_{i};" if kind == 'expr' else f"x[{i}] = {float(val)!r};")
   head = (f"__device__ __forceinline__ void predict_regs(double (&x)[{D}], double (&P)[{E * E}], "
-          "const double* __restrict__ Q, const double dt) {")
+          "const double* Q, const double dt) {")
   return "\n".join([head] + _ind(body) + ["}"]), F
 
 
@@ -198,9 +198,11 @@ def kernels(spec):
 __global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double* __restrict__ gP,
     const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
     const int norm_quats) {{
-  __shared__ __attribute__((aligned(16))) double s_x[64 * {D}];
-  __shared__ __attribute__((aligned(16))) double s_P[64 * {EE}];
+  __shared__ __attribute__((aligned(16))) double s_x[64 * {D | 1}];
+  __shared__ __attribute__((aligned(16))) double s_P[64 * {EE | 1}];
+  __shared__ __attribute__((aligned(16))) double s_Q[{EE}];
   const int lane = threadIdx.x;
+  for (int i = lane; i < {EE}; i += 64) s_Q[i] = gQ[i];       // Q as LDS broadcast operands (36 SGPR pairs spilled otherwise)
   const int64_t tiles = (n + 63) >> 6;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
     const int64_t base = tile << 6;
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double*
     double x[{D}], P[{EE}];
     rn::lds_to_regs<{D}>(s_x, lane, x);
     rn::lds_to_regs<{EE}>(s_P, lane, P);
-    predict_regs(x, P, gQ, dt);
+    predict_regs(x, P, s_Q, dt);
     {norm}
     rn::wave_lds_sync();
     rn::regs_to_lds<{D}>(s_x, lane, x);
@@ -235,11 +237,15 @@ __global__ __launch_bounds__(64){kattr} void k_step_{k.kind}(double* __restrict_
     double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const double* __restrict__ gea,
     const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
     const int norm_quats, uint8_t* __restrict__ flags) {{
-  __shared__ __attribute__((aligned(16))) double s_x[64 * {D}];
-  __shared__ __attribute__((aligned(16))) double s_P[64 * {EE}];
-  __shared__ __attribute__((aligned(16))) double s_z[64 * {Z}];
-  __shared__ __attribute__((aligned(16))) double s_R[64 * {ZZ}];
+  __shared__ __attribute__((aligned(16))) double s_x[64 * {D | 1}];
+  __shared__ __attribute__((aligned(16))) double s_P[64 * {EE | 1}];
+  __shared__ __attribute__((aligned(16))) double s_z[64 * {Z | 1}];
+  __shared__ __attribute__((aligned(16))) double s_R[64 * {ZZ | 1}];
+  __shared__ __attribute__((aligned(16))) double s_Q[{EE}];
   const int lane = threadIdx.x;
+  if (DO_PREDICT) {{
+    for (int i = lane; i < {EE}; i += 64) s_Q[i] = gQ[i];
+  }}
   const int64_t tiles = (n + 63) >> 6;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
     const int64_t base = tile << 6;
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(64){kattr} void k_step_{k.kind}(double* __restrict_
       for (int i = 0; i < {ZZ}; i++) R[i] = gR[i];
     }}
     if (DO_PREDICT) {{
-      predict_regs(x, P, gQ, dt);
+      predict_regs(x, P, s_Q, dt);
       {norm}
     }}
     int fl = update_{k.kind}_regs(x, P, z, R{ea});
@@ -316,10 +322,12 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
     const int32_t* __restrict__ kinds, const double* __restrict__ dts, const int64_t T, double* __restrict__ gz,
     const double* __restrict__ gR, const int64_t n, const int norm_quats, uint8_t* __restrict__ flags,
     double* __restrict__ tx, double* __restrict__ tP) {{
-  __shared__ __attribute__((aligned(16))) double s_x[64 * {D}];
-  __shared__ __attribute__((aligned(16))) double s_P[64 * {EE}];
-  __shared__ __attribute__((aligned(16))) double s_z[64 * {zmax}];
+  __shared__ __attribute__((aligned(16))) double s_x[64 * {D | 1}];
+  __shared__ __attribute__((aligned(16))) double s_P[64 * {EE | 1}];
+  __shared__ __attribute__((aligned(16))) double s_z[64 * {zmax | 1}];
+  __shared__ __attribute__((aligned(16))) double s_Q[{EE}];
   const int lane = threadIdx.x;
+  for (int i = lane; i < {EE}; i += 64) s_Q[i] = gQ[i];
   const int64_t tiles = (n + 63) >> 6;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
     const int64_t base = tile << 6;
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       if (t + 1 < T) nxt.issue(gz + ((t + 1) * n + base) * {zmax}, cnt, lane);
       const int kind = kinds[t];
       const double dt = dts[t];
-      predict_regs(x, P, gQ, dt);
+      predict_regs(x, P, s_Q, dt);
       {norm}
       int fl = 0;
       switch (kind) {{

@@ -97,14 +97,25 @@ __device__ __forceinline__ void reg_fence() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// Copy one tile (cnt <= 64 filters x EPF doubles, contiguous in HBM) into this wave's LDS region.
+// LDS image of a tile: filter f's record starts at f * lds_stride<EPF>() doubles.  An ODD stride makes the
+// lane-per-filter ds_read_b64 / ds_write_b64 accesses conflict-free (the linear layout costs 4-way conflicts on P,
+// 864 cycles per wave in the round-1 PMC run), but the index arithmetic of the padded copy cost more than the
+// conflicts it removed (measured: 10.7 -> 11.3 us per launch, 252 -> 256+ VGPRs), so the linear layout is the
+// default; -DRN_LDS_PAD=1 selects the padded one.  With the linear stride the div/mod below folds away.
+#ifndef RN_LDS_PAD
+#define RN_LDS_PAD 0
+#endif
+template <int EPF>
+__device__ __forceinline__ constexpr int lds_stride() { return RN_LDS_PAD ? (EPF | 1) : EPF; }
+
+// Copy one tile (cnt <= 64 filters x EPF doubles, contiguous in HBM) into this wave's LDS image.
 // Full tiles move as 16-byte vectors, lane l taking vectors l, l+64, ... (1 KiB per wave-instruction).
 template <int EPF>
 __device__ __forceinline__ void tile_g2l(const double* __restrict__ g, int cnt, double* lds, int lane) {
   constexpr int NV = 32 * EPF;                      // double2 vectors in a full tile
+  constexpr int STR = lds_stride<EPF>();
   if (cnt == WAVE) {
     const double2* __restrict__ g2 = reinterpret_cast<const double2*>(g);
-    double2* l2 = reinterpret_cast<double2*>(lds);
     double2 v[(NV + WAVE - 1) / WAVE];
 #pragma unroll
     for (int i = 0; i < (NV + WAVE - 1) / WAVE; i++) {
@@ -114,30 +125,110 @@ __device__ __forceinline__ void tile_g2l(const double* __restrict__ g, int cnt, 
 #pragma unroll
     for (int i = 0; i < (NV + WAVE - 1) / WAVE; i++) {
       const int idx = lane + i * WAVE;
-      if ((NV % WAVE == 0) || idx < NV) l2[idx] = v[i];
+      if ((NV % WAVE == 0) || idx < NV) {
+#if RN_LDS_PAD
+        const int e = 2 * idx;
+        const int f = e / EPF, k = e - f * EPF;
+        lds[f * STR + k] = v[i].x;
+        if (k + 1 < EPF) lds[f * STR + k + 1] = v[i].y; else lds[(f + 1) * STR] = v[i].y;
+#else
+        reinterpret_cast<double2*>(lds)[idx] = v[i];
+#endif
+      }
     }
   } else {
     const int total = cnt * EPF;
-    for (int idx = lane; idx < total; idx += WAVE) lds[idx] = g[idx];
+    for (int e = lane; e < total; e += WAVE) {
+      const int f = e / EPF, k = e - f * EPF;
+      lds[f * STR + k] = g[e];
+    }
   }
 }
 
 template <int EPF>
 __device__ __forceinline__ void tile_l2g(double* __restrict__ g, int cnt, const double* lds, int lane) {
   constexpr int NV = 32 * EPF;
+  constexpr int STR = lds_stride<EPF>();
   if (cnt == WAVE) {
     double2* __restrict__ g2 = reinterpret_cast<double2*>(g);
-    const double2* l2 = reinterpret_cast<const double2*>(lds);
 #pragma unroll
     for (int i = 0; i < (NV + WAVE - 1) / WAVE; i++) {
       const int idx = lane + i * WAVE;
-      if ((NV % WAVE == 0) || idx < NV) g2[idx] = l2[idx];
+      if ((NV % WAVE == 0) || idx < NV) {
+#if RN_LDS_PAD
+        const int e = 2 * idx;
+        const int f = e / EPF, k = e - f * EPF;
+        double2 v;
+        v.x = lds[f * STR + k];
+        v.y = (k + 1 < EPF) ? lds[f * STR + k + 1] : lds[(f + 1) * STR];
+        g2[idx] = v;
+#else
+        g2[idx] = reinterpret_cast<const double2*>(lds)[idx];
+#endif
+      }
     }
   } else {
     const int total = cnt * EPF;
-    for (int idx = lane; idx < total; idx += WAVE) g[idx] = lds[idx];
+    for (int e = lane; e < total; e += WAVE) {
+      const int f = e / EPF, k = e - f * EPF;
+      g[e] = lds[f * STR + k];
+    }
   }
 }
+
+// Register-staged prefetch of one tile (cnt <= 64 filters x EPF doubles): issue() starts the coalesced global
+// loads, commit() later drops them into the wave's LDS image -- the loads fly while the caller computes.
+template <int EPF>
+struct TilePrefetch {
+  static constexpr int NV = 32 * EPF;
+  static constexpr int IT = (NV + WAVE - 1) / WAVE;
+  static constexpr int STR = RN_LDS_PAD ? (EPF | 1) : EPF;
+  double2 v[IT];
+  double s[EPF];
+  __device__ __forceinline__ void issue(const double* __restrict__ g, int cnt, int lane) {
+    if (cnt == WAVE) {
+      const double2* __restrict__ g2 = reinterpret_cast<const double2*>(g);
+#pragma unroll
+      for (int i = 0; i < IT; i++) {
+        const int idx = lane + i * WAVE;
+        if ((NV % WAVE == 0) || idx < NV) v[i] = g2[idx];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < EPF; i++) {
+        const int idx = lane + i * WAVE;
+        if (idx < cnt * EPF) s[i] = g[idx];
+      }
+    }
+  }
+  __device__ __forceinline__ void commit(double* lds, int cnt, int lane) const {
+    if (cnt == WAVE) {
+#pragma unroll
+      for (int i = 0; i < IT; i++) {
+        const int idx = lane + i * WAVE;
+        if ((NV % WAVE == 0) || idx < NV) {
+#if RN_LDS_PAD
+          const int e = 2 * idx;
+          const int f = e / EPF, k = e - f * EPF;
+          lds[f * STR + k] = v[i].x;
+          if (k + 1 < EPF) lds[f * STR + k + 1] = v[i].y; else lds[(f + 1) * STR] = v[i].y;
+#else
+          reinterpret_cast<double2*>(lds)[idx] = v[i];
+#endif
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < EPF; i++) {
+        const int e = lane + i * WAVE;
+        if (e < cnt * EPF) {
+          const int f = e / EPF, k = e - f * EPF;
+          lds[f * STR + k] = s[i];
+        }
+      }
+    }
+  }
+};
 
 // Copy `nd` contiguous doubles (nd <= MAXD, source 16-byte aligned) between HBM and this wave's LDS as
 // 16-byte vectors, all loads issued before the first LDS store so they overlap.
@@ -175,48 +266,6 @@ __device__ __forceinline__ void copy_l2g(double* __restrict__ g, int nd, const d
   if ((nd & 1) && lane == 0) g[nd - 1] = lds[nd - 1];
 }
 
-// Register-staged prefetch of one tile (cnt <= 64 filters x EPF doubles): issue() starts the coalesced global
-// loads, commit() later drops them into the wave's LDS image -- the loads fly while the caller computes.
-template <int EPF>
-struct TilePrefetch {
-  static constexpr int NV = 32 * EPF;
-  static constexpr int IT = (NV + WAVE - 1) / WAVE;
-  double2 v[IT];
-  double s[(EPF + 0)];
-  __device__ __forceinline__ void issue(const double* __restrict__ g, int cnt, int lane) {
-    if (cnt == WAVE) {
-      const double2* __restrict__ g2 = reinterpret_cast<const double2*>(g);
-#pragma unroll
-      for (int i = 0; i < IT; i++) {
-        const int idx = lane + i * WAVE;
-        if ((NV % WAVE == 0) || idx < NV) v[i] = g2[idx];
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < EPF; i++) {
-        const int idx = lane + i * WAVE;
-        if (idx < cnt * EPF) s[i] = g[idx];
-      }
-    }
-  }
-  __device__ __forceinline__ void commit(double* lds, int cnt, int lane) const {
-    if (cnt == WAVE) {
-      double2* l2 = reinterpret_cast<double2*>(lds);
-#pragma unroll
-      for (int i = 0; i < IT; i++) {
-        const int idx = lane + i * WAVE;
-        if ((NV % WAVE == 0) || idx < NV) l2[idx] = v[i];
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < EPF; i++) {
-        const int idx = lane + i * WAVE;
-        if (idx < cnt * EPF) lds[idx] = s[i];
-      }
-    }
-  }
-};
-
 // Register-staged prefetch of up to MAXD contiguous doubles (one or two filters' P records): issue() starts the
 // coalesced loads, commit() drops them into LDS later, so they fly while the previous pair is being processed.
 template <int MAXD>
@@ -246,17 +295,17 @@ struct PairPrefetch {
   }
 };
 
-// lane-per-filter register <-> LDS (filter `lane` owns lds[lane*EPF .. lane*EPF+EPF))
+// lane-per-filter register <-> LDS (filter `lane` owns lds[lane*STR .. lane*STR+EPF), STR = lds_stride<EPF>())
 template <int EPF>
 __device__ __forceinline__ void lds_to_regs(const double* lds, int lane, double (&r)[EPF]) {
 #pragma unroll
-  for (int k = 0; k < EPF; k++) r[k] = lds[lane * EPF + k];
+  for (int k = 0; k < EPF; k++) r[k] = lds[lane * lds_stride<EPF>() + k];
 }
 
 template <int EPF>
 __device__ __forceinline__ void regs_to_lds(double* lds, int lane, const double (&r)[EPF]) {
 #pragma unroll
-  for (int k = 0; k < EPF; k++) lds[lane * EPF + k] = r[k];
+  for (int k = 0; k < EPF; k++) lds[lane * lds_stride<EPF>() + k] = r[k];
 }
 
 // S = L L^T, lower triangle of S is read; iL[i] = 1 / L[i][i].  Fully unrolled, lives in VGPRs.
