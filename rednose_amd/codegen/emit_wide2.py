@@ -30,7 +30,7 @@ def _ind(lines, n=2):
   return [pad + s for s in lines]
 
 
-SCHED_FENCE = "rn::reg_fence();"
+SCHED_FENCE = "rn::reg_fence();" if os.environ.get("RN_WIDE_FENCES", "0") == "1" else ""
 
 
 def _fenced(lines, every):
@@ -191,10 +191,10 @@ def device_functions(spec):
   b += ["if (act) {", "#pragma unroll", f"  for (int i = 0; i < {E}; i++) sP[cc * {E} + i] = a[i];", "}", "rn::wave_lds_sync();",
         "#pragma unroll", f"for (int k = 0; k < {E}; k++) a[k] = sP[k * {E} + cc];"]
   for i in range(E):
-    b.append(f"col[{i}] = {sum_terms(term(cf, f'a[{kk}]') for kk, cf in Fs.row_nz(i))} + dt*gQ[{i} * {E} + cc];")
+    b.append(f"col[{i}] = {sum_terms(term(cf, f'a[{kk}]') for kk, cf in Fs.row_nz(i))} + dt*qcol[{i}];")
   b += ["rn::wave_lds_sync();", "if (act) {", "#pragma unroll", f"  for (int k = 0; k < {E}; k++) sP[k * {E} + cc] = col[k];", "}",
         "rn::wave_lds_sync();"]
-  out.append("\n".join(["__device__ {INL} void mat_predict(double* sP, const double* __restrict__ gQ, const double* sl, const int cc, const bool act) {"]
+  out.append("\n".join([f"__device__ {INL} void mat_predict(double* sP, const double (&qcol)[{E}], const double* sl, const int cc, const bool act) {{"]
                         + _ind(b) + ["}"]))
 
   # ---- phase 2: update, matrix part ----------------------------------------------------------------------
@@ -274,7 +274,7 @@ def kernels(spec):
     A(f"{tmpl}__global__ {lbs} void {kname}(double* __restrict__ gx, double* __restrict__ gP,")
     A(f"    {sig_obs}const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,")
     A(f"    const int norm_quats{flags_arg}) {{")
-    A(f"  __shared__ __attribute__((aligned(16))) double s_P[2 * {EE}];")
+    A(f"  __shared__ __attribute__((aligned(16))) double s_P[2][2 * {EE}];     // double buffer: pair p computes, pair p+1 lands")
     A(f"  __shared__ __attribute__((aligned(16))) double s_x[FT2 * {D} + 2];")
     if upd:
       A(f"  __shared__ __attribute__((aligned(16))) double s_z[FT2 * {Z} + 2];")
@@ -286,6 +286,9 @@ def kernels(spec):
     A(f"  const int c = lane % {G_LANES};")
     A(f"  const bool act = c < {E};")
     A("  const int cc = act ? c : 0;")
+    A(f"  double qcol[{E}];                          // column cc of Q, resident for the whole launch")
+    A("#pragma unroll")
+    A(f"  for (int i = 0; i < {E}; i++) qcol[i] = ({dop} && gQ != nullptr) ? gQ[i * {E} + cc] : 0.0;")
     A("  const int64_t tiles = (n + FT2 - 1) / FT2;")
     A("  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {")
     A("    const int64_t base = tile * FT2;")
@@ -294,8 +297,7 @@ def kernels(spec):
     A(f"    rn::copy_g2l<FT2 * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);")
     if upd:
       A(f"    rn::copy_g2l<FT2 * {Z}>(gz + base * {Z}, cnt * {Z}, s_z, lane);")
-    A(f"    rn::PairPrefetch<{EE}> pf;")
-    A(f"    pf.issue(gP + base * {EE}, (cnt < 2 ? cnt : 2) * {EE}, lane);")
+    A(f"    rn::async_copy_g2l<2 * {EE}>(gP + base * {EE}, (cnt < 2 ? cnt : 2) * {EE}, s_P[0], lane);")
     A("    rn::wave_lds_sync();")
     A("    if (lane < cnt) {")
     A("      double* sl = s_sl + lane * SLOT;")
@@ -314,16 +316,17 @@ def kernels(spec):
     A("    const int npairs = (cnt + 1) >> 1;")
     A("    for (int p = 0; p < npairs; p++) {")
     A("      const int pcnt = (cnt - 2 * p) < 2 ? (cnt - 2 * p) : 2;")
-    A(f"      pf.commit(s_P, pcnt * {EE}, lane);")
+    A("      double* sPc = s_P[p & 1];")
+    A("      rn::async_wait();                        // pair p has landed (issued one iteration ago)")
     A("      rn::wave_lds_sync();")
-    A(f"      if (p + 1 < npairs) pf.issue(gP + (base + 2 * (p + 1)) * {EE}, ((cnt - 2 * (p + 1)) < 2 ? (cnt - 2 * (p + 1)) : 2) * {EE}, lane);")
+    A(f"      if (p + 1 < npairs) rn::async_copy_g2l<2 * {EE}>(gP + (base + 2 * (p + 1)) * {EE}, ((cnt - 2 * (p + 1)) < 2 ? (cnt - 2 * (p + 1)) : 2) * {EE}, s_P[(p + 1) & 1], lane);")
     A("      const int gg = g < pcnt ? g : 0;")
     A("      const bool on = act && g < pcnt;")
     A("      double* sl = s_sl + (2 * p + gg) * SLOT;")
-    A(f"      if ({dop}) mat_predict(s_P + gg * {EE}, gQ, sl, cc, on);")
+    A(f"      if ({dop}) mat_predict(sPc + gg * {EE}, qcol, sl, cc, on);")
     if upd:
-      A(f"      mat_update_{k.kind}(s_P + gg * {EE}, r_per_filter ? gR + (base + 2 * p + gg) * {ZZ} : gR, sl, sl, s_G + gg * {Z * E}, s_K + gg * {Z * E}, cc, on);")
-    A(f"      rn::copy_l2g<2 * {EE}>(gP + (base + 2 * p) * {EE}, pcnt * {EE}, s_P, lane);")
+      A(f"      mat_update_{k.kind}(sPc + gg * {EE}, r_per_filter ? gR + (base + 2 * p + gg) * {ZZ} : gR, sl, sl, s_G + gg * {Z * E}, s_K + gg * {Z * E}, cc, on);")
+    A(f"      rn::copy_l2g<2 * {EE}>(gP + (base + 2 * p) * {EE}, pcnt * {EE}, sPc, lane);")
     A("      rn::wave_lds_sync();")
     A("    }")
     A("    // ---------------- phase 3: lane l = filter l, inject the error state, write x / y / flags ---------")

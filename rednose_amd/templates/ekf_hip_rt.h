@@ -120,7 +120,7 @@ __device__ __forceinline__ void tile_g2l(const double* __restrict__ g, int cnt, 
 #pragma unroll
     for (int i = 0; i < (NV + WAVE - 1) / WAVE; i++) {
       const int idx = lane + i * WAVE;
-      if ((NV % WAVE == 0) || idx < NV) v[i] = g2[idx];
+      v[i] = g2[((NV % WAVE == 0) || idx < NV) ? idx : NV - 1];       // unconditional, clamped (see copy_g2l)
     }
 #pragma unroll
     for (int i = 0; i < (NV + WAVE - 1) / WAVE; i++) {
@@ -191,13 +191,14 @@ struct TilePrefetch {
 #pragma unroll
       for (int i = 0; i < IT; i++) {
         const int idx = lane + i * WAVE;
-        if ((NV % WAVE == 0) || idx < NV) v[i] = g2[idx];
+        v[i] = g2[((NV % WAVE == 0) || idx < NV) ? idx : NV - 1];     // unconditional, clamped (see copy_g2l)
       }
     } else {
+      const int last = cnt * EPF - 1;
 #pragma unroll
       for (int i = 0; i < EPF; i++) {
         const int idx = lane + i * WAVE;
-        if (idx < cnt * EPF) s[i] = g[idx];
+        s[i] = g[idx <= last ? idx : last];
       }
     }
   }
@@ -239,10 +240,14 @@ __device__ __forceinline__ void copy_g2l(const double* __restrict__ g, int nd, d
   const double2* __restrict__ g2 = reinterpret_cast<const double2*>(g);
   double2* l2 = reinterpret_cast<double2*>(lds);
   double2 v[IT];
+  // Loads are UNCONDITIONAL on a clamped index: a predicated `if (idx < nv) v[i] = ...` demotes v[] to scratch and
+  // hipcc then waits for every load before the next one (load, s_waitcnt vmcnt(0), scratch_store, ...), which
+  // serialised the whole HBM latency IT times per copy (61 % of the live kernel's cycles in the round-1 PMC run).
+  const int last = nv > 0 ? nv - 1 : 0;
 #pragma unroll
   for (int i = 0; i < IT; i++) {
     const int idx = lane + i * WAVE;
-    if (idx < nv) v[i] = g2[idx];
+    v[i] = g2[idx < nv ? idx : last];
   }
 #pragma unroll
   for (int i = 0; i < IT; i++) {
@@ -266,34 +271,61 @@ __device__ __forceinline__ void copy_l2g(double* __restrict__ g, int nd, const d
   if ((nd & 1) && lane == 0) g[nd - 1] = lds[nd - 1];
 }
 
-// Register-staged prefetch of up to MAXD contiguous doubles (one or two filters' P records): issue() starts the
-// coalesced loads, commit() drops them into LDS later, so they fly while the previous pair is being processed.
+// Register-staged prefetch of up to MAXD contiguous doubles per filter, two filters (one or two P records):
+// pair_issue() starts the coalesced loads into a caller-owned register array, pair_commit() drops them into LDS
+// later, so they fly while the previous pair is being processed.  Plain arrays, not a struct: as struct members
+// the staging registers were demoted to scratch (load, wait, scratch_store per element).
 template <int MAXD>
-struct PairPrefetch {
-  static constexpr int IT = (MAXD + WAVE - 1) / WAVE;          // MAXD doubles per filter, two filters -> MAXD double2
-  double2 v[IT];
-  double tail;
-  __device__ __forceinline__ void issue(const double* __restrict__ g, int nd, int lane) {
-    const int nv = nd >> 1;
-    const double2* __restrict__ g2 = reinterpret_cast<const double2*>(g);
+__device__ __forceinline__ void pair_issue(double2 (&v)[(MAXD + WAVE - 1) / WAVE], double& tail, const double* __restrict__ g,
+                                           int nd, int lane) {
+  constexpr int IT = (MAXD + WAVE - 1) / WAVE;
+  const int nv = nd >> 1;
+  const int last = nv > 0 ? nv - 1 : 0;
+  const double2* __restrict__ g2 = reinterpret_cast<const double2*>(g);
 #pragma unroll
-    for (int i = 0; i < IT; i++) {
-      const int idx = lane + i * WAVE;
-      if (idx < nv) v[i] = g2[idx];
-    }
-    if ((nd & 1) && lane == 0) tail = g[nd - 1];
+  for (int i = 0; i < IT; i++) {
+    const int idx = lane + i * WAVE;
+    v[i] = g2[idx < nv ? idx : last];          // unconditional, clamped (see copy_g2l)
   }
-  __device__ __forceinline__ void commit(double* lds, int nd, int lane) const {
-    const int nv = nd >> 1;
-    double2* l2 = reinterpret_cast<double2*>(lds);
+  tail = g[nd > 0 ? nd - 1 : 0];
+}
+
+template <int MAXD>
+__device__ __forceinline__ void pair_commit(const double2 (&v)[(MAXD + WAVE - 1) / WAVE], const double tail, double* lds, int nd,
+                                            int lane) {
+  constexpr int IT = (MAXD + WAVE - 1) / WAVE;
+  const int nv = nd >> 1;
+  double2* l2 = reinterpret_cast<double2*>(lds);
 #pragma unroll
-    for (int i = 0; i < IT; i++) {
-      const int idx = lane + i * WAVE;
-      if (idx < nv) l2[idx] = v[i];
-    }
-    if ((nd & 1) && lane == 0) lds[nd - 1] = tail;
+  for (int i = 0; i < IT; i++) {
+    const int idx = lane + i * WAVE;
+    if (idx < nv) l2[idx] = v[i];
   }
-};
+  if ((nd & 1) && lane == 0) lds[nd - 1] = tail;
+}
+
+// Asynchronous HBM -> LDS copy of `nd` contiguous doubles (16-byte aligned source, LDS image linear) with
+// global_load_lds_dwordx4: no VGPR staging, the data lands in LDS while the wave keeps computing.  Each
+// wave-instruction writes one 1 KiB stripe: LDS address = uniform base + lane * 16.  The consumer must call
+// async_wait() (s_waitcnt vmcnt(0)) and then wave_lds_sync() before reading the image.
+template <int MAXD>
+__device__ __forceinline__ void async_copy_g2l(const double* __restrict__ g, int nd, double* lds, int lane) {
+  constexpr int IT = (MAXD / 2 + WAVE - 1) / WAVE;
+  const int nv = nd >> 1;
+#pragma unroll
+  for (int i = 0; i < IT; i++) {
+    const int idx = lane + i * WAVE;
+    if (idx < nv) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 2 * idx),
+                                       (__attribute__((address_space(3))) void*)(lds + 2 * i * WAVE), 16, 0, 0);
+    }
+  }
+  if ((nd & 1) && lane == 0) lds[nd - 1] = g[nd - 1];
+}
+
+__device__ __forceinline__ void async_wait() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
+}
 
 // lane-per-filter register <-> LDS (filter `lane` owns lds[lane*STR .. lane*STR+EPF), STR = lds_stride<EPF>())
 template <int EPF>
