@@ -207,9 +207,10 @@ __global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double*
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
     const int64_t base = tile << 6;
     const int cnt = (n - base) < 64 ? (int)(n - base) : 64;
-    rn::tile_g2l<{D}>(gx + base * {D}, cnt, s_x, lane);
-    rn::tile_g2l<{EE}>(gP + base * {EE}, cnt, s_P, lane);
+    rn::tile_g2l_async<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_g2l_async<{EE}>(gP + base * {EE}, cnt, s_P, lane);
     const double dt = (gdt != nullptr && lane < cnt) ? gdt[base + lane] : dt_scalar;
+    rn::async_wait();
     rn::wave_lds_sync();
     double x[{D}], P[{EE}];
     rn::lds_to_regs<{D}>(s_x, lane, x);
@@ -250,12 +251,13 @@ __global__ __launch_bounds__(64){kattr} void k_step_{k.kind}(double* __restrict_
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
     const int64_t base = tile << 6;
     const int cnt = (n - base) < 64 ? (int)(n - base) : 64;
-    rn::tile_g2l<{D}>(gx + base * {D}, cnt, s_x, lane);
-    rn::tile_g2l<{EE}>(gP + base * {EE}, cnt, s_P, lane);
-    rn::tile_g2l<{Z}>(gz + base * {Z}, cnt, s_z, lane);
-    if (r_per_filter) rn::tile_g2l<{ZZ}>(gR + base * {ZZ}, cnt, s_R, lane);
+    rn::tile_g2l_async<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_g2l_async<{EE}>(gP + base * {EE}, cnt, s_P, lane);
+    rn::tile_g2l_async<{Z}>(gz + base * {Z}, cnt, s_z, lane);
+    if (r_per_filter) rn::tile_g2l_async<{ZZ}>(gR + base * {ZZ}, cnt, s_R, lane);
     double dt = dt_scalar;
     if (DO_PREDICT && gdt != nullptr && lane < cnt) dt = gdt[base + lane];
+    rn::async_wait();
     rn::wave_lds_sync();
     double x[{D}], P[{EE}], z[{Z}], R[{ZZ}];
     rn::lds_to_regs<{D}>(s_x, lane, x);

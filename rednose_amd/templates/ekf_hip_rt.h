@@ -304,6 +304,14 @@ __device__ __forceinline__ void pair_commit(const double2 (&v)[(MAXD + WAVE - 1)
   if ((nd & 1) && lane == 0) lds[nd - 1] = tail;
 }
 
+// A generic pointer into LDS carries the LDS byte offset in its low 32 bits; building the address_space(3) pointer
+// from that integer avoids the generic->local addrspacecast (its null check trips an hipcc 7.2 backend assertion,
+// "V_CMP_NE_U32 $src_shared_base: incorrect register class", when the pointer comes through a function argument).
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+__device__ __forceinline__ lds_void_ptr lds_offset_ptr(const double* p) {
+  return (lds_void_ptr)(uint32_t)(uintptr_t)p;
+}
+
 // Asynchronous HBM -> LDS copy of `nd` contiguous doubles (16-byte aligned source, LDS image linear) with
 // global_load_lds_dwordx4: no VGPR staging, the data lands in LDS while the wave keeps computing.  Each
 // wave-instruction writes one 1 KiB stripe: LDS address = uniform base + lane * 16.  The consumer must call
@@ -316,8 +324,7 @@ __device__ __forceinline__ void async_copy_g2l(const double* __restrict__ g, int
   for (int i = 0; i < IT; i++) {
     const int idx = lane + i * WAVE;
     if (idx < nv) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 2 * idx),
-                                       (__attribute__((address_space(3))) void*)(lds + 2 * i * WAVE), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 2 * idx), lds_offset_ptr(lds + 2 * i * WAVE), 16, 0, 0);
     }
   }
   if ((nd & 1) && lane == 0) lds[nd - 1] = g[nd - 1];
@@ -325,6 +332,28 @@ __device__ __forceinline__ void async_copy_g2l(const double* __restrict__ g, int
 
 __device__ __forceinline__ void async_wait() {
   __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
+}
+
+// tile_g2l with direct HBM -> LDS transfers for full tiles (no VGPR staging, no ds_write); the caller must
+// async_wait() before the wave_lds_sync() that precedes the first read of the image.
+template <int EPF>
+__device__ __forceinline__ void tile_g2l_async(const double* __restrict__ g, int cnt, double* lds, int lane) {
+#if RN_LDS_PAD
+  tile_g2l<EPF>(g, cnt, lds, lane);
+#else
+  constexpr int NV = 32 * EPF;
+  if (cnt == WAVE) {
+#pragma unroll
+    for (int i = 0; i < (NV + WAVE - 1) / WAVE; i++) {
+      const int idx = lane + i * WAVE;
+      if ((NV % WAVE == 0) || idx < NV) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 2 * idx), lds_offset_ptr(lds + 2 * i * WAVE), 16, 0, 0);
+      }
+    }
+  } else {
+    tile_g2l<EPF>(g, cnt, lds, lane);
+  }
+#endif
 }
 
 // lane-per-filter register <-> LDS (filter `lane` owns lds[lane*STR .. lane*STR+EPF), STR = lds_stride<EPF>())
