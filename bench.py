@@ -234,6 +234,44 @@ def main():
                           "hbm_bytes_moved": moved, "achieved_GBs": moved / (ms * 1e-3) / 1e9,
                           "note": "state resident in VGPRs for T steps; bound by fp64 VALU issue, not HBM"}
 
+  if not args.no_extras and world == 1 and args.model == "kinematic6":
+    # BASELINE config 4: live with the Mahalanobis gate on ECEF_POS, forward pass keeping the filtered trace, then the
+    # batched RTS backward pass.  T = 210 steps (1 s of IMU@100Hz + GNSS@10Hz), batch 16384, 2 % GNSS outliers.
+    from examples import ensure_generated
+    from examples.live_kf import LiveKalman as L
+    from rednose_amd.helpers.ekf_sym import BatchedEKF
+    gen = ensure_generated(["live_maha"])
+    nb = 16384
+    f = BatchedEKF(gen, "live_maha", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22, batch=nb, device=dev, quaternion_idxs=[3],
+                   maha_test_kinds=[12])
+    f._folder = gen
+    x0, P0, sched = live_stream(torch, L, f, nb, 210, dev, rank)
+    kinds = np.array([s_[0] for s_ in sched], dtype=np.int32)
+    tsl = np.array([s_[1] for s_ in sched])
+    zsl = torch.stack([s_[2].expand(nb, 3) for s_ in sched]).contiguous()
+    gsel = torch.rand((int((kinds == 12).sum()), nb), device=dev) < 0.02
+    zsl[torch.as_tensor(np.where(kinds == 12)[0], device=dev)] += gsel[..., None] * 500.0 * torch.randn((gsel.shape[0], nb, 3), dtype=torch.float64, device=dev)
+    Rs = {int(k): np.atleast_2d(L.obs_noise[int(k)]) for k in set(kinds.tolist())}
+    res = {}
+    for rep in range(2):
+      f.init_state(x0, P0, None)
+      e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+      e0.record()
+      _, tx, tP, fl = f.run(tsl, kinds, zsl.clone(), Rs, trace=True, flags=True)
+      e1.record()
+      xs, Ps = f.rts_smooth(tx, tP, tsl, inplace=True)
+      e2.record()
+      torch.cuda.synchronize()
+      res = {"fwd_ms": e0.elapsed_time(e1), "bwd_ms": e1.elapsed_time(e2)}
+    assert torch.isfinite(xs).all() and torch.isfinite(Ps).all()
+    T4 = len(kinds)
+    extra["live_maha_rts"] = {"batch": nb, "T": T4, "forward_steps_per_s": nb * T4 / (res["fwd_ms"] * 1e-3),
+                              "backward_steps_per_s": nb * (T4 - 1) / (res["bwd_ms"] * 1e-3), "forward_ms": res["fwd_ms"], "backward_ms": res["bwd_ms"],
+                              "gated_fraction_of_gnss": float(fl[torch.as_tensor(np.where(kinds == 12)[0], device=dev)].float().mean()),
+                              "trace_bytes": int(tx.numel() + tP.numel()) * 8,
+                              "note": "forward = fused batch_run with filtered trace + gate flags; backward = batch_rts recomputing the predicted pairs"}
+    del tx, tP, xs, Ps, zsl
+
   if rank == 0:
     launch_s = r["dev_ms"] * 1e-3 / K
     achieved = r["bytes_per_step"] * n / launch_s / 1e9

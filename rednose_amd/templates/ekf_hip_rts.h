@@ -104,49 +104,40 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
       if (norm_quats) Model::normalize(x1k);
       if (c == 0 && g < cnt) Model::F(xk, dt, Fm);
       wave_lds_sync();
-      // M = Fk Pk_k^T : lane c forms column c, M[i][c] = sum_m F[i][m] Pk[c][m]
-      double mcol[E];
-#pragma unroll
+      // M = Fk Pk_k^T : lane c forms column c, M[i][c] = sum_m F[i][m] Pk[c][m].  The i loops of the dense E x E
+      // products stay rolled (operands in LDS, dynamic row address): fully unrolled they needed > 512 registers
+      // and 7 KB of scratch per lane.
+#pragma unroll 1
       for (int i = 0; i < E; i++) {
         double s = 0.0;
 #pragma unroll
         for (int m = 0; m < E; m++) s += Fm[i * E + m] * prow[m];
-        mcol[i] = s;
-      }
-      if (on) {
-#pragma unroll
-        for (int i = 0; i < E; i++) M[i * E + c] = mcol[i];
+        if (on) M[i * E + c] = s;
       }
       wave_lds_sync();
-      // Pk1_k = Fk (Pk_k Fk^T) + dt Q : column c, using row c of M (= column c of Pk_k Fk^T)
-      double p1col[E];
+      // Pk1_k = Fk (Pk_k Fk^T) + dt Q : column c, using row c of M (= column c of Pk_k Fk^T); Dm = Pk1_n - Pk1_k
       {
         double mrow[E];
 #pragma unroll
         for (int m = 0; m < E; m++) mrow[m] = M[cc * E + m];
-#pragma unroll
+        const bool first = (k == T - 2);     // recursion start: smoothed(T-1) := predicted(T-1)  (estimates[-1][0], [2])
+#pragma unroll 1
         for (int i = 0; i < E; i++) {
           double s = 0.0;
 #pragma unroll
           for (int m = 0; m < E; m++) s += Fm[i * E + m] * mrow[m];
-          p1col[i] = s + dt * s_Q[i * E + cc];
+          const double v = s + dt * s_Q[i * E + cc];
+          if (on) {
+            L[i * E + c] = v;
+            if (first) Nn[i * E + c] = v;
+            Dm[i * E + c] = Nn[i * E + c] - v;
+          }
         }
-      }
-      if (on) {
-#pragma unroll
-        for (int i = 0; i < E; i++) L[i * E + c] = p1col[i];
       }
       wave_lds_sync();
-
       if (k == T - 2) {
-        // recursion start: smoothed(T-1) := predicted(T-1)   (estimates[-1][0], [2])
 #pragma unroll
         for (int i = 0; i < D; i++) xn1[i] = x1k[i];
-        if (on) {
-#pragma unroll
-          for (int i = 0; i < E; i++) Nn[i * E + c] = p1col[i];
-        }
-        wave_lds_sync();
       }
       if (norm_quats) Model::normalize(xn1);
       // smoothed step k+1 is final now: write it out (state after the in-place renormalisation)
@@ -158,50 +149,40 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
       copy_l2g<FPW * D>(xs + ((k + 1) * n + base) * D, cnt * D, s_x, lane);
       copy_l2g<FPW * EE>(Ps + ((k + 1) * n + base) * EE, cnt * EE, s_N, lane);
 
-      // Dm = Pk1_n - Pk1_k (column c)
-      if (on) {
-#pragma unroll
-        for (int i = 0; i < E; i++) Dm[i * E + c] = Nn[i * E + c] - p1col[i];
-      }
-
-      // ---- Cholesky of Pk1_k in LDS, lane c owns row c -------------------------------------------------
-      {
-        double lrow[E];
-#pragma unroll
-        for (int j = 0; j < E; j++) {
-          double s = L[cc * E + j];
-#pragma unroll
-          for (int m = 0; m < j; m++) s -= lrow[m] * L[j * E + m];
-          if (c == j) {
-            const double ljj = sqrt(s);
-            lrow[j] = ljj;
-            if (g < cnt) { L[j * E + j] = ljj; sil[j] = 1.0 / ljj; }
-          }
-          wave_lds_sync();
-          if (c > j) {
-            lrow[j] = s * sil[j];
-            if (on) L[c * E + j] = lrow[j];
-          }
-          wave_lds_sync();
+      // ---- Cholesky of Pk1_k in LDS (left-looking by columns), lane c owns row c; loops stay rolled -------------
+#pragma unroll 1
+      for (int j = 0; j < E; j++) {
+        double s = L[cc * E + j];
+#pragma unroll 2
+        for (int m = 0; m < j; m++) s -= L[cc * E + m] * L[j * E + m];
+        if (c == j && g < cnt) {
+          const double ljj = sqrt(s);
+          L[j * E + j] = ljj;
+          sil[j] = 1.0 / ljj;
         }
+        wave_lds_sync();
+        if (c > j && on) L[c * E + j] = s * sil[j];
+        wave_lds_sync();
       }
-      // ---- Ck^T = Pk1_k^-1 M : lane c solves for column c ------------------------------------------------
+      // ---- Ck^T = Pk1_k^-1 M : lane c solves for column c IN PLACE in its own column of M -----------------------
+#pragma unroll 1
+      for (int i = 0; i < E; i++) {
+        double s = M[i * E + cc];
+#pragma unroll 2
+        for (int m = 0; m < i; m++) s -= L[i * E + m] * M[m * E + cc];
+        if (on) M[i * E + c] = s * sil[i];
+      }
+#pragma unroll 1
+      for (int i = E - 1; i >= 0; i--) {
+        double s = M[i * E + cc];
+#pragma unroll 2
+        for (int m = i + 1; m < E; m++) s -= L[m * E + i] * M[m * E + cc];
+        if (on) M[i * E + c] = s * sil[i];
+      }
+      // column c of X = Ck^T is row c of Ck
       double ck[E];
 #pragma unroll
-      for (int i = 0; i < E; i++) {
-        double s = mcol[i];
-#pragma unroll
-        for (int m = 0; m < i; m++) s -= L[i * E + m] * ck[m];
-        ck[i] = s * sil[i];
-      }
-#pragma unroll
-      for (int i = E - 1; i >= 0; i--) {
-        double s = ck[i];
-#pragma unroll
-        for (int m = i + 1; m < E; m++) s -= L[m * E + i] * ck[m];
-        ck[i] = s * sil[i];
-      }
-      // ck[j] = X[j][c] = Ck[c][j]: row c of Ck
+      for (int j = 0; j < E; j++) ck[j] = M[j * E + cc];
       if (on) {
 #pragma unroll
         for (int j = 0; j < E; j++) C[c * E + j] = ck[j];
@@ -220,27 +201,26 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
         Model::err(xk, delta, xn1);          // xk_n, becomes xk1_n of the next (older) step
       }
       // ---- covariance: Pk_n = Pk_k + (Ck Dm) Ck^T, row c -----------------------------------------------
+      wave_lds_sync();           // every lane has taken its right-hand side out of M: M becomes the T = Ck Dm buffer
+#pragma unroll 1
+      for (int m = 0; m < E; m++) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < E; j++) s += ck[j] * Dm[j * E + m];
+        if (on) M[c * E + m] = s;
+      }
+      wave_lds_sync();
       {
         double trow[E];
 #pragma unroll
+        for (int j = 0; j < E; j++) trow[j] = M[cc * E + j];
+#pragma unroll 1
         for (int m = 0; m < E; m++) {
-          double s = 0.0;
-#pragma unroll
-          for (int j = 0; j < E; j++) s += ck[j] * Dm[j * E + m];
-          trow[m] = s;
-        }
-#pragma unroll
-        for (int m = 0; m < E; m++) {
-          double s = prow[m];
+          double s = A[cc * E + m];
 #pragma unroll
           for (int j = 0; j < E; j++) s += trow[j] * C[m * E + j];
-          prow[m] = s;
+          if (on) Nn[c * E + m] = s;          // Pk1_n of the next (older) step; Dm already holds what was needed of the old one
         }
-      }
-      wave_lds_sync();           // everyone is done reading Nn / Dm / C
-      if (on) {
-#pragma unroll
-        for (int m = 0; m < E; m++) Nn[c * E + m] = prow[m];
       }
       wave_lds_sync();
     }
