@@ -8,12 +8,14 @@ the HBM roofline on live (round-1 profile).  Here a wavefront owns a tile of FT 
   phase 1  lane l = filter l of the tile (FT lanes active): x, z -> f, F non-zeros, normalise, h, He = H.H_mod
            non-zeros, y = z - h; results go to the filter's scalar SLOT in LDS.  One evaluation per filter.
   phase 2  for each pair of filters: the 32-lane-group-per-filter covariance algebra of emit_wide.py, but every
-           x-dependent coefficient is an LDS broadcast read from the slot; the next pair's P record is prefetched
-           into registers while the current pair computes.  dx goes back to the slot.
+           x-dependent coefficient is an LDS broadcast read from the slot; the next pair's P record streams
+           HBM -> LDS asynchronously (global_load_lds_dwordx4, double buffer) while the current pair computes.
+           dx goes back to the slot.
   phase 3  lane l = filter l again: x' = err_fun(x, dx), renormalise, x / y / flags leave through LDS, coalesced.
 
 The algebra and its order are unchanged (see emit_wide.py / emit_small.py docstrings); only who evaluates the
-scalars changed, so the results are bit-identical to the first structure.
+scalars changed.  Results agree with the first structure to rounding (different instruction streams contract
+FMAs differently), which tests/test_gpu_run.py bounds.
 """
 import os
 
