@@ -21,10 +21,9 @@ Algebra emitted (reference lines in /root/reference/rednose/templates/ekf_c.c):
                   which is the same polynomial in the same inputs -- including the property that the
                   rounding error of B is cancelled to first order by the correction term.
 """
-import os
-
 import sympy as sp
 
+from rednose_amd.codegen import tuning
 from rednose_amd.codegen.lower import Block, vector_names
 from rednose_amd.codegen.emit_common import SMat, term, sum_terms
 
@@ -168,20 +167,10 @@ def update_regs(spec, k):
   return "\n".join([head] + _ind(b) + ["}"]), He
 
 
-def _tune():
-  """Generation-time tuning knobs (A/B experiments): RN_TUNE="waves=1" -> amdgpu_waves_per_eu(1,1) on the step kernels."""
-  out = {}
-  for kv in os.environ.get("RN_TUNE", "").split(","):
-    if "=" in kv:
-      k, v = kv.split("=")
-      out[k.strip()] = v.strip()
-  return out
-
-
 def kernels(spec):
   """Device functions + __global__ kernels of family S for every kind."""
-  tune = _tune()
-  kattr = f" __attribute__((amdgpu_waves_per_eu({tune['waves']}, {tune['waves']})))" if "waves" in tune else ""
+  waves = tuning.current().small_waves
+  kattr = f" __attribute__((amdgpu_waves_per_eu({waves}, {waves})))" if waves else ""
   D, E = spec.dim_x, spec.dim_err
   EE = E * E
   out = []

@@ -1,9 +1,10 @@
-"""Kernel family W ("lane group per filter"): one 32-lane half-wavefront per filter, lane c owns row c of P.
+"""Kernel family W ("lane group per filter"), state-resident structure: one 32-lane half-wavefront per filter,
+lane c owns row c of P, the nominal state x replicated in every lane of the group.
 
-Used when the covariance does not fit one lane's registers (live: D=23, E=22 -> P is 484 doubles).
-A wavefront owns 2 consecutive filters.  Their P records (2 x E*E doubles, contiguous in HBM) are pulled
-with 16-byte coalesced loads into the wave's private LDS image; lane c of a group then holds row c (and,
-when needed, column c) of its filter's P in VGPRs, and the nominal state x replicated in every lane.
+Used when the covariance does not fit one lane's registers (live: D=23, E=22 -> P is 484 doubles).  This structure
+is what the FUSED MULTI-STEP kernel `k_run` uses: P rows and x stay in VGPRs for T steps, only z / y and the optional
+trace cross HBM.  (It also provides step-granular kernels, kept for A/B runs -- tuning knob wide_struct=1; the
+default step-granular kernels are the three-phase ones of emit_wide2.py, 2.6x faster.)
 
   predict (ekf_c.c:8-33)    A = P F^T   row-local sparse mat-vec (F has ~33 non-trivial entries of 484)
                             --LDS transpose-->  column c of A;  P' = F A + dt Q  column-local
@@ -15,8 +16,8 @@ when needed, column c) of its filter's P in VGPRs, and the nominal state x repli
                             D[c,:] = K[c,:] R - C[c,:];  K broadcast;  P'[c,:] = B[c,:] + D[c,:] K^T
                             (the Joseph form of :115 with its rank-Z structure, see emit_small.py);
                             dx broadcast; x' = err_fun(x, dx) redundantly per lane.
-The x-dependent scalars (f, F, h, H.H_mod, err_fun) are CSE'd straight-line code evaluated by every lane of
-the group (SIMD makes the redundancy free in issue slots; distributing it is a later optimisation).
+The x-dependent scalars (f, F, h, H.H_mod, err_fun) are CSE'd straight-line code evaluated by every lane of the
+group; with the state resident there is no cheaper place to evaluate them.
 """
 import sympy as sp
 

@@ -17,10 +17,9 @@ The algebra and its order are unchanged (see emit_wide.py / emit_small.py docstr
 scalars changed.  Results agree with the first structure to rounding (different instruction streams contract
 FMAs differently), which tests/test_gpu_run.py bounds.
 """
-import os
-
 import sympy as sp
 
+from rednose_amd.codegen import tuning
 from rednose_amd.codegen.lower import Block, vector_names
 from rednose_amd.codegen.emit_common import SMat, term, sum_terms
 
@@ -32,32 +31,12 @@ def _ind(lines, n=2):
   return [pad + s for s in lines]
 
 
-SCHED_FENCE = "rn::reg_fence();" if os.environ.get("RN_WIDE_FENCES", "0") == "1" else ""
-
-
-def _fenced(lines, every):
-  """Insert a scheduling fence every `every` statements: keeps hipcc from hoisting dozens of LDS reads / CSE
-  temporaries at once (460 registers without it -> one wave per SIMD)."""
-  if every <= 0:
-    return list(lines)
-  out = []
-  for i, ln in enumerate(lines):
-    out.append(ln)
-    if (i + 1) % every == 0:
-      out.append(SCHED_FENCE)
-  return out
-
-
-def _knob(name, default):
-  return int(os.environ.get(name, str(default)))
-
-
 def _odd(n):
   return n if n & 1 else n + 1
 
 
 def tile_filters():
-  return int(os.environ.get("RN_WIDE_FT", "16"))
+  return tuning.current().wide_ft
 
 
 class Layout:
@@ -127,7 +106,7 @@ def _slotted(smat, var_list, off):
 
 def device_functions(spec):
   D, E = spec.dim_x, spec.dim_err
-  INL = "__noinline__" if os.environ.get("RN_WIDE_INLINE", "1") == "0" else "__forceinline__"
+  INL = "__forceinline__" if tuning.current().wide_inline else "__noinline__"
   pst, pstruct, F, f_vars = _lowered_predict(spec)
   obs = {k.kind: _lowered_obs(spec, k) for k in spec.kinds}
   lay = Layout(spec, f_vars, {kk: v[3] for kk, v in obs.items()})
@@ -139,7 +118,7 @@ def device_functions(spec):
   quat = "".join(f" rn::normalize_quat<{D}>(x, {q});" for q in spec.quaternion_idxs)
   normq = f"if (norm_quats) {{{quat} }}" if spec.quaternion_idxs else "(void)norm_quats;"
   b = [f"double x[{D}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = xin[i];"]
-  b += _fenced(pst, _knob("RN_WIDE_FENCE1", 0))
+  b += list(pst)
   for i, v in enumerate(f_vars):
     b.append(f"sl[{lay.OFF_F + i}] = {v};")
   for i in range(D):
@@ -156,7 +135,7 @@ def device_functions(spec):
     Z = k.zdim
     b = [f"double x[{D}], z[{Z}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = sl[{lay.OFF_X} + i];",
          "#pragma unroll", f"for (int i = 0; i < {Z}; i++) z[i] = zin[i];"]
-    b += _fenced(stmts, _knob("RN_WIDE_FENCE1", 0))
+    b += list(stmts)
     for i in range(Z):
       kind, val = st[f"hx_{i}"]
       hx = f"hx_{i}" if kind == 'expr' else repr(float(val))
@@ -185,7 +164,6 @@ def device_functions(spec):
 
   # ---- phase 2: predict, matrix part (P in sP -> P' in sP) ------------------------------------------------
   Fs = _slotted(F, f_vars, lay.OFF_F)
-  ch = max(1, _knob("RN_WIDE_CHUNK", 6))
   b = [f"const double dt = sl[{lay.OFF_DT}];", f"double row[{E}], a[{E}], col[{E}];", "#pragma unroll",
        f"for (int j = 0; j < {E}; j++) row[j] = sP[cc * {E} + j];"]
   for i in range(E):
@@ -213,12 +191,10 @@ def device_functions(spec):
       b.append(f"const double Gt_{zi} = {sum_terms(term(cf, f'row[{kk}]') for kk, cf in nz)};")
     b.append("if (act) { " + " ".join(f"sG[{zi} * {E} + cc] = G_{zi};" for zi in range(Z)) + " }")
     b.append("rn::wave_lds_sync();")
-    b.append(SCHED_FENCE)
     b.append(f"double HPH[{Z * Z}], Rl[{Z * Z}], S[{Z * Z}], L[{Z * Z}], iL[{Z}];")
     for zi in range(Z):
       for w in range(Z):
         b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))};")
-      b.append(SCHED_FENCE)
     b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}", f"rn::chol_factor<{Z}>(S, L, iL);",
           "int gated = 0;"]
     if k.maha_test:
@@ -229,23 +205,16 @@ def device_functions(spec):
     b.append(f"double kk[{Z}] = {{{', '.join(f'Gt_{zi}' for zi in range(Z))}}};")
     b.append(f"rn::chol_solve<{Z}>(L, iL, kk);")
     b.append("const double dxc = " + " + ".join(f"kk[{zi}]*sl[{lay.OFF_Y + zi}]" for zi in range(Z)) + ";")
-    ch = _knob("RN_WIDE_CHUNK", 6)
     for j in range(E):
       b.append(f"row[{j}] -= " + " + ".join(f"kk[{zi}]*sG[{zi * E + j}]" for zi in range(Z)) + ";")
-      if (j + 1) % ch == 0:
-        b.append(SCHED_FENCE)
-    b.append(SCHED_FENCE)
     for zi in range(Z):
       c = sum_terms(term(cf, f"row[{j}]") for j, cf in Hs.row_nz(zi))
       kr = " + ".join(f"kk[{w}]*Rl[{w * Z + zi}]" for w in range(Z))
       b.append(f"const double Dm_{zi} = ({kr}) - ({c});")
-      b.append(SCHED_FENCE)
     b.append("if (act) { " + " ".join(f"sK[{zi} * {E} + cc] = kk[{zi}];" for zi in range(Z)) + f" sw[{lay.OFF_DX} + cc] = dxc; if (cc == 0) sw[{lay.OFF_FL}] = (double)gated; }}")
     b.append("rn::wave_lds_sync();")
     for j in range(E):
       b.append(f"row[{j}] += " + " + ".join(f"Dm_{zi}*sK[{zi * E + j}]" for zi in range(Z)) + ";")
-      if (j + 1) % ch == 0:
-        b.append(SCHED_FENCE)
     b += ["if (act) {", "#pragma unroll", f"  for (int j = 0; j < {E}; j++) sP[cc * {E} + j] = row[j];", "}", "rn::wave_lds_sync();"]
     out.append("\n".join([f"__device__ {INL} void mat_update_{k.kind}(double* sP, const double* __restrict__ gR, const double* sl, double* sw, "
                           "double* sG, double* sK, const int cc, const bool act) {"] + _ind(b) + ["}"]))
@@ -259,8 +228,8 @@ def kernels(spec):
   fn_text, lay = device_functions(spec)
   out = [f"// ---- family W, three-phase step kernels (tile of {FT} filters per wavefront, slot = {lay.SLOT} doubles) ----",
          f"constexpr int FT2 = {FT};", f"constexpr int SLOT = {lay.SLOT};", fn_text]
-  lb = os.environ.get("RN_WIDE_LB", "")
-  lbs = f"__launch_bounds__(64, {lb})" if lb and lb != "0" else "__launch_bounds__(64)"
+  tune = tuning.current()
+  lbs = f"__launch_bounds__(64, {tune.wide_lb})" if tune.wide_lb else "__launch_bounds__(64)"
 
   def kernel(kname, k=None):
     upd = k is not None
@@ -276,7 +245,8 @@ def kernels(spec):
     A(f"{tmpl}__global__ {lbs} void {kname}(double* __restrict__ gx, double* __restrict__ gP,")
     A(f"    {sig_obs}const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,")
     A(f"    const int norm_quats{flags_arg}) {{")
-    A(f"  __shared__ __attribute__((aligned(16))) double s_P[2][2 * {EE}];     // double buffer: pair p computes, pair p+1 lands")
+    DB = 1 if tune.wide_db else 0
+    A(f"  __shared__ __attribute__((aligned(16))) double s_P[{1 + DB}][2 * {EE}];     // double buffer: pair p computes, pair p+1 lands")
     A(f"  __shared__ __attribute__((aligned(16))) double s_x[FT2 * {D} + 2];")
     if upd:
       A(f"  __shared__ __attribute__((aligned(16))) double s_z[FT2 * {Z} + 2];")
@@ -299,7 +269,8 @@ def kernels(spec):
     A(f"    rn::copy_g2l<FT2 * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);")
     if upd:
       A(f"    rn::copy_g2l<FT2 * {Z}>(gz + base * {Z}, cnt * {Z}, s_z, lane);")
-    A(f"    rn::async_copy_g2l<2 * {EE}>(gP + base * {EE}, (cnt < 2 ? cnt : 2) * {EE}, s_P[0], lane);")
+    if DB:
+      A(f"    rn::async_copy_g2l<2 * {EE}>(gP + base * {EE}, (cnt < 2 ? cnt : 2) * {EE}, s_P[0], lane);")
     A("    rn::wave_lds_sync();")
     A("    if (lane < cnt) {")
     A("      double* sl = s_sl + lane * SLOT;")
@@ -318,10 +289,16 @@ def kernels(spec):
     A("    const int npairs = (cnt + 1) >> 1;")
     A("    for (int p = 0; p < npairs; p++) {")
     A("      const int pcnt = (cnt - 2 * p) < 2 ? (cnt - 2 * p) : 2;")
-    A("      double* sPc = s_P[p & 1];")
-    A("      rn::async_wait();                        // pair p has landed (issued one iteration ago)")
-    A("      rn::wave_lds_sync();")
-    A(f"      if (p + 1 < npairs) rn::async_copy_g2l<2 * {EE}>(gP + (base + 2 * (p + 1)) * {EE}, ((cnt - 2 * (p + 1)) < 2 ? (cnt - 2 * (p + 1)) : 2) * {EE}, s_P[(p + 1) & 1], lane);")
+    if DB:
+      A("      double* sPc = s_P[p & 1];")
+      A("      rn::async_wait();                        // pair p has landed (issued one iteration ago)")
+      A("      rn::wave_lds_sync();")
+      A(f"      if (p + 1 < npairs) rn::async_copy_g2l<2 * {EE}>(gP + (base + 2 * (p + 1)) * {EE}, ((cnt - 2 * (p + 1)) < 2 ? (cnt - 2 * (p + 1)) : 2) * {EE}, s_P[(p + 1) & 1], lane);")
+    else:
+      A("      double* sPc = s_P[0];                   // single buffer: the co-resident wave hides the HBM latency")
+      A(f"      rn::async_copy_g2l<2 * {EE}>(gP + (base + 2 * p) * {EE}, pcnt * {EE}, sPc, lane);")
+      A("      rn::async_wait();")
+      A("      rn::wave_lds_sync();")
     A("      const int gg = g < pcnt ? g : 0;")
     A("      const bool on = act && g < pcnt;")
     A("      double* sl = s_sl + (2 * p + gg) * SLOT;")

@@ -89,14 +89,6 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Compiler-only fence: no instruction is emitted, but values loaded from LDS before it are not kept in registers
-// across it and the scheduler does not move code over it.  Used by the generated covariance algebra to bound live
-// ranges (without it hipcc keeps ~460 registers live in the wide-family update and occupancy drops to 1 wave/SIMD).
-__device__ __forceinline__ void reg_fence() {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
-
 // LDS image of a tile: filter f's record starts at f * lds_stride<EPF>() doubles.  An ODD stride makes the
 // lane-per-filter ds_read_b64 / ds_write_b64 accesses conflict-free (the linear layout costs 4-way conflicts on P,
 // 864 cycles per wave in the round-1 PMC run), but the index arithmetic of the padded copy cost more than the
@@ -269,39 +261,6 @@ __device__ __forceinline__ void copy_l2g(double* __restrict__ g, int nd, const d
     if (idx < nv) g2[idx] = l2[idx];
   }
   if ((nd & 1) && lane == 0) g[nd - 1] = lds[nd - 1];
-}
-
-// Register-staged prefetch of up to MAXD contiguous doubles per filter, two filters (one or two P records):
-// pair_issue() starts the coalesced loads into a caller-owned register array, pair_commit() drops them into LDS
-// later, so they fly while the previous pair is being processed.  Plain arrays, not a struct: as struct members
-// the staging registers were demoted to scratch (load, wait, scratch_store per element).
-template <int MAXD>
-__device__ __forceinline__ void pair_issue(double2 (&v)[(MAXD + WAVE - 1) / WAVE], double& tail, const double* __restrict__ g,
-                                           int nd, int lane) {
-  constexpr int IT = (MAXD + WAVE - 1) / WAVE;
-  const int nv = nd >> 1;
-  const int last = nv > 0 ? nv - 1 : 0;
-  const double2* __restrict__ g2 = reinterpret_cast<const double2*>(g);
-#pragma unroll
-  for (int i = 0; i < IT; i++) {
-    const int idx = lane + i * WAVE;
-    v[i] = g2[idx < nv ? idx : last];          // unconditional, clamped (see copy_g2l)
-  }
-  tail = g[nd > 0 ? nd - 1 : 0];
-}
-
-template <int MAXD>
-__device__ __forceinline__ void pair_commit(const double2 (&v)[(MAXD + WAVE - 1) / WAVE], const double tail, double* lds, int nd,
-                                            int lane) {
-  constexpr int IT = (MAXD + WAVE - 1) / WAVE;
-  const int nv = nd >> 1;
-  double2* l2 = reinterpret_cast<double2*>(lds);
-#pragma unroll
-  for (int i = 0; i < IT; i++) {
-    const int idx = lane + i * WAVE;
-    if (idx < nv) l2[idx] = v[i];
-  }
-  if ((nd & 1) && lane == 0) lds[nd - 1] = tail;
 }
 
 // A generic pointer into LDS carries the LDS byte offset in its low 32 bits; building the address_space(3) pointer
