@@ -29,14 +29,15 @@ def source_digest(*texts):
   for hdr in ("ekf_hip_rt.h", "ekf_hip_rts.h"):
     with open(os.path.join(TEMPLATE_DIR, hdr), "rb") as f:
       h.update(f.read())
-  h.update(" ".join(HIPCC_FLAGS).encode())
+  h.update((" ".join(HIPCC_FLAGS) + os.environ.get("RN_HIPCC_FLAGS", "")).encode())
   return h.hexdigest()
 
 
 def compile_filter(folder, name, extra_flags=(), verbose=False):
   src = os.path.join(folder, f"{name}.hip")
   lib = os.path.join(folder, f"lib{name}.so")
-  cmd = [find_hipcc()] + HIPCC_FLAGS + list(extra_flags) + ["-I", TEMPLATE_DIR, "-x", "hip", src, "-o", lib]
+  extra_flags = list(extra_flags) + os.environ.get("RN_HIPCC_FLAGS", "").split()     # A/B experiments only
+  cmd = [find_hipcc()] + HIPCC_FLAGS + extra_flags + ["-I", TEMPLATE_DIR, "-x", "hip", src, "-o", lib]
   if verbose:
     print(" ".join(cmd))
   res = subprocess.run(cmd, capture_output=True, text=True)

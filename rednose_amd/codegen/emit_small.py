@@ -167,8 +167,8 @@ def update_regs(spec, k):
   return "\n".join([head] + _ind(b) + ["}"]), He
 
 
-def kernels(spec):
-  """Device functions + __global__ kernels of family S for every kind."""
+def kernels(spec, step_kernels=True):
+  """Device functions + __global__ kernels of family S for every kind (step_kernels=False: only what k_run needs)."""
   waves = tuning.current().small_waves
   kattr = f" __attribute__((amdgpu_waves_per_eu({waves}, {waves})))" if waves else ""
   D, E = spec.dim_x, spec.dim_err
@@ -182,7 +182,8 @@ def kernels(spec):
   quat = "".join(f" rn::normalize_quat<{D}>(x, {q});" for q in spec.quaternion_idxs)
   norm = f"if (norm_quats) {{{quat} }}" if spec.quaternion_idxs else "(void)norm_quats;"
 
-  out.append(f"""
+  if step_kernels:
+   out.append(f"""
 // ---- predict only: one launch propagates n filters by dt -------------------------------------------
 __global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double* __restrict__ gP,
     const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double*
   }}
 }}
 """)
-  for k in spec.kinds:
+  for k in (spec.kinds if step_kernels else []):
     Z = k.zdim
     ZZ = Z * Z
     ea = ", gea" if k.ea_sym is not None else ""

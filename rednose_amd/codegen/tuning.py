@@ -12,6 +12,9 @@ environment variable RN_TUNE, e.g.  RN_TUNE="wide_ft=8,wide_lb=2" python bench.p
   wide_db       1        double-buffered asynchronous P prefetch; 0 = single buffer (only sensible with wide_lb=2)
   wide_inline   1        0 = phase functions __noinline__: each fits 256 registers but pays scratch frames: 237 us
   small_waves   0        amdgpu_waves_per_eu(n, n) on the lane-per-filter step kernels: 1 -> k6 35 us/launch vs 9.5 us
+  small_lpf     1        lanes per filter in the family-S step kernels: 2 = lane PAIR per filter (emit_small2.py: half the
+                         rows per lane, DPP exchanges, 2 waves per SIMD): k6 9.8-10.0 us/launch vs 9.4 us -- parity-green but
+                         not faster, the two waves of a SIMD still move in lockstep through load / compute / store
 """
 import os
 from dataclasses import dataclass, fields
@@ -25,6 +28,7 @@ class Tuning:
   wide_db: int = 1
   wide_inline: int = 1
   small_waves: int = 0
+  small_lpf: int = 1
 
 
 def current():

@@ -328,6 +328,14 @@ __device__ __forceinline__ void regs_to_lds(double* lds, int lane, const double 
   for (int k = 0; k < EPF; k++) lds[lane * lds_stride<EPF>() + k] = r[k];
 }
 
+// Value held by the other lane of an (even, odd) lane pair: two DPP moves (quad_perm [1,0,3,2]), no LDS traffic.
+__device__ __forceinline__ double pair_xchg(const double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
 // S = L L^T, lower triangle of S is read; iL[i] = 1 / L[i][i].  Fully unrolled, lives in VGPRs.
 template <int Z>
 __device__ __forceinline__ void chol_factor(const double (&S)[Z * Z], double (&L)[Z * Z], double (&iL)[Z]) {
