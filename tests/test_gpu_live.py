@@ -126,3 +126,45 @@ def test_maha_gate_live(env):
   o.batch_step(12, xr, Pr, zr, g["R"], L.Q, 0.0, do_predict=False)
   assert_close(f.state(), xr, rtol=1e-10, floor=1e-12)
   assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-9, floor=1e-11)
+
+
+def test_per_filter_R_and_dt_wide_family(env):
+  """Ragged batch (n = 19: full tile + ragged pairs), per-filter R (n, Z, Z) and per-filter dt (n,) through the three-phase kernels."""
+  torch, gen, L = env
+  from oracle_lib import OracleLib
+  o = OracleLib("live")
+  g = golden("live_single_steps.npz")
+  rng = np.random.default_rng(77)
+  n = 19
+  idx = rng.integers(0, g["x_in"].shape[0], size=n)
+  x0 = g["x_in"][idx] + rng.normal(size=(n, 23)) * 1e-3
+  P0 = g["P_in"][idx] * rng.uniform(0.5, 2.0, size=(n, 1, 1))
+  dts = rng.uniform(0.0, 0.05, size=n)
+  A = rng.normal(size=(n, 3, 3)) * 0.1
+  Rn = (np.eye(3)[None] + A @ A.transpose(0, 2, 1)) * 0.025**2
+  f = _filter(env, n)
+  f.init_state(x0, P0, 0.0)
+  z = rng.normal(size=(n, 3)) * 0.03
+  f.predict_dt(dts)
+  y = f.update(4, z.copy(), Rn)
+  torch.cuda.synchronize()
+  xr, Pr, zr = x0.copy(), P0.copy(), z.copy()
+  o.batch_step(4, xr, Pr, zr, Rn, L.Q, dts, quat_idx=3)
+  assert_close(f.state(), xr, rtol=1e-11, floor=1e-13)
+  assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-10, floor=1e-12)
+  assert_close(y.cpu().numpy(), zr, rtol=1e-9, atol=1e-12)
+
+
+def test_nonfinite_state_is_flagged_not_fatal(env):
+  torch, gen, L = env
+  n = 6
+  f = _filter(env, n)
+  x0 = np.tile(L.initial_x, (n, 1))
+  x0[2, 8] = np.nan
+  f.init_state(x0, np.diag(L.initial_P_diag), 0.0)
+  f.predict_and_update_batch(0.01, 4, np.zeros((n, 3)), L.obs_noise[4])
+  torch.cuda.synchronize()
+  fl = f.flags.cpu().numpy()
+  assert (fl[2] & 2) == 2 and (np.delete(fl, 2) & 2).sum() == 0
+  X = f.state()
+  assert np.isfinite(np.delete(X, 2, axis=0)).all()

@@ -106,3 +106,40 @@ def test_live_maha_run_flags(env):
   assert flr[out_t][bad].all() and flr.sum() >= bad.sum()
   assert_close(f.state(), xr, rtol=1e-7, floor=1e-9)
   assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-6, floor=1e-8)
+
+
+def test_degenerate_sizes(env):
+  """Empty batch / empty schedule / single-step smoothing must be no-ops, not crashes (C ABI level)."""
+  import ctypes
+  torch, gen = env
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  from examples.kinematic6_kf import Kinematic6Kalman as K6
+  f = BatchedEKF(gen, "kinematic6", K6.Q, K6.initial_x, np.diag(K6.initial_P_diag), 6, 6, batch=5)
+  lib = f._lib
+  p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+  kd = torch.ones(1, dtype=torch.int32, device=f.device); dd = torch.zeros(1, dtype=torch.float64, device=f.device)
+  zz = torch.zeros((1, 5, 3), dtype=torch.float64, device=f.device); Rd = torch.eye(3, dtype=torch.float64, device=f.device).reshape(1, 9).contiguous()
+  x_before = f.state().copy()
+  assert lib.kinematic6_batch_run(p(f.x), p(f.P), p(f.Q), p(kd), p(dd), 0, p(zz), p(Rd), 5, 0, None, None, None, None) == 0     # T = 0
+  assert lib.kinematic6_batch_run(p(f.x), p(f.P), p(f.Q), p(kd), p(dd), 1, p(zz), p(Rd), 0, 0, None, None, None, None) == 0     # n = 0
+  torch.cuda.synchronize()
+  assert np.array_equal(f.state(), x_before)
+  # single-estimate smoothing: nothing to smooth, the filtered pair comes back
+  tx = torch.randn((1, 5, 6), dtype=torch.float64, device=f.device); tP = torch.eye(6, dtype=torch.float64, device=f.device).repeat(1, 5, 1, 1)
+  xs, Ps = f.rts_smooth(tx, tP, np.array([0.0]))
+  torch.cuda.synchronize()
+  assert torch.equal(xs, tx) and torch.equal(Ps, tP)
+
+
+def test_million_filter_batch_properties(env):
+  """Beyond the 256 MiB Infinity Cache (755 MB of state): grid-stride path, every filter identical -> results identical."""
+  torch, gen = env
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  from examples.kinematic6_kf import Kinematic6Kalman as K6
+  n = 1 << 20
+  f = BatchedEKF(gen, "kinematic6", K6.Q, K6.initial_x, np.diag(K6.initial_P_diag), 6, 6, batch=n)
+  z = torch.full((n, 3), 0.25, dtype=torch.float64, device=f.device)
+  for i in range(3):
+    f.predict_and_update_batch(0.01 * i, 1, z.clone(), K6.obs_noise[1])
+  torch.cuda.synchronize()
+  assert bool((f.x == f.x[0]).all()) and bool((f.P == f.P[0]).all()) and bool(torch.isfinite(f.P).all())
