@@ -48,6 +48,8 @@ extern "C" {
 
 /* per observation kind k (the integer is part of the symbol):
  *   replaces {name}_update_{k}, ekf_sym.py:149-152 -> update<Z,3,MAHA>(), ekf_c.c:37-121 */
+/* one per gen_code global_var v: void {name}_set_{v}(double x)  -- ekf_sym.py:166-171; writes a device global */
+
 #define RN_DECLARE_SCALAR_KIND(name, k)                                                                          \
   void RN_FN(name, update_##k)(double *in_x, double *in_P, double *in_z, double *in_R, double *in_ea);             \
   void RN_FN(name, h_##k)(double *state, double *ea, double *out);       /* predicted observation, Z         */   \

@@ -1,0 +1,63 @@
+"""global_vars (reference: ekf_sym.py:129-132,166-171 -- run-time scalars settable through {name}_set_{var}).
+CPU part: the generated sources declare the device global and export the setter.  GPU part: a model whose process
+model uses a run-time gain must match the same model with the gain baked in as a literal."""
+import os
+
+import numpy as np
+import pytest
+import sympy as sp
+
+from conftest import REPO
+
+
+def _model(gain):
+  state_sym = sp.MatrixSymbol('state', 2, 1)
+  state = sp.Matrix(state_sym)
+  dt = sp.Symbol('dt')
+  f_sym = state + dt * sp.Matrix([gain * state[1, 0], 0])
+  obs = [[sp.Matrix([state[0, 0]]), 1, None]]
+  return dict(f_sym=f_sym, dt_sym=dt, x_sym=state_sym, obs_eqs=obs, dim_x=2, dim_err=2)
+
+
+@pytest.fixture(scope="module")
+def libs():
+  from rednose_amd.helpers.ekf_sym import gen_code
+  folder = os.path.join(REPO, "generated")
+  g = sp.Symbol('gain')
+  gen_code(folder, "gv_runtime", global_vars=[g], **_model(g))
+  gen_code(folder, "gv_literal", **_model(sp.Float(2.5)))
+  return folder
+
+
+def test_setter_is_generated_and_exported(libs):
+  import ctypes
+  with open(os.path.join(libs, "gv_runtime.h"), encoding="utf-8") as f:
+    assert "void gv_runtime_set_gain(double x);" in f.read()
+  with open(os.path.join(libs, "gv_runtime.hip"), encoding="utf-8") as f:
+    assert "__device__ double gain" in f.read()
+  assert hasattr(ctypes.CDLL(os.path.join(libs, "libgv_runtime.so")), "gv_runtime_set_gain")
+
+
+@pytest.mark.gpu
+def test_runtime_global_equals_literal(libs):
+  import torch
+  from rednose_amd.helpers.ekf_sym import EKF_sym, BatchedEKF
+  Q = np.diag([0.01, 4.0]); x0 = np.array([0.5, 0.3]); P0 = np.eye(2)
+  a = EKF_sym(libs, "gv_runtime", Q, x0, P0, 2, 2, global_vars=["gain"])
+  a.set_global("gain", 2.5)
+  n = 100
+  rng = np.random.default_rng(0)
+  X0 = rng.normal(size=(n, 2))
+  fa = BatchedEKF(libs, "gv_runtime", Q, x0, P0, 2, 2, batch=n); fa.init_state(X0, P0, 0.0)
+  fb = BatchedEKF(libs, "gv_literal", Q, x0, P0, 2, 2, batch=n); fb.init_state(X0, P0, 0.0)
+  for i in range(1, 6):
+    z = rng.normal(size=(n, 1))
+    fa.predict_and_update_batch(0.01 * i, 1, z.copy(), np.array([[0.01]]))
+    fb.predict_and_update_batch(0.01 * i, 1, z.copy(), np.array([[0.01]]))
+  torch.cuda.synchronize()
+  assert torch.equal(fa.x, fb.x) and torch.equal(fa.P, fb.P)
+  a.set_global("gain", 0.0)          # with a zero gain the position no longer integrates the velocity
+  fa.init_state(X0, P0, 0.0)
+  fa.predict(1.0)
+  torch.cuda.synchronize()
+  assert np.array_equal(fa.state(), X0)
