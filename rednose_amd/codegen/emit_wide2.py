@@ -129,6 +129,10 @@ def device_functions(spec):
   b += ["#pragma unroll", f"for (int i = 0; i < {D}; i++) sl[{lay.OFF_X} + i] = x[i];"]
   out.append("\n".join(["__device__ {INL} void scal_predict(const double* xin, const double dt, double* sl, const int norm_quats) {"] + _ind(b) + ["}"]))
 
+  b = [f"double x[{D}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = xin[i];", normq,
+       "#pragma unroll", f"for (int i = 0; i < {D}; i++) sl[{lay.OFF_X} + i] = x[i];"]
+  out.append("\n".join(["__device__ {INL} void scal_keep(const double* xin, double* sl, const int norm_quats) {"] + _ind(b) + ["}"]))
+
   # ---- phase 1: scalars of each observation kind ---------------------------------------------------
   for k in spec.kinds:
     stmts, st, He, he_vars = obs[k.kind]
@@ -261,6 +265,9 @@ def kernels(spec):
     A(f"  double qcol[{E}];                          // column cc of Q, resident for the whole launch")
     A("#pragma unroll")
     A(f"  for (int i = 0; i < {E}; i++) qcol[i] = ({dop} && gQ != nullptr) ? gQ[i * {E} + cc] : 0.0;")
+    A("  // predict with a uniform dt == 0 (a second observation at the same timestamp) is the identity on (x, P) for finite")
+    A("  // states: F = I + dt A = I and dt Q = 0 exactly, so the covariance phase is skipped; results are unchanged.")
+    A(f"  const bool do_pred = {dop} && !(gdt == nullptr && dt_scalar == 0.0);")
     A("  const int64_t tiles = (n + FT2 - 1) / FT2;")
     A("  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {")
     A("    const int64_t base = tile * FT2;")
@@ -274,12 +281,11 @@ def kernels(spec):
     A("    rn::wave_lds_sync();")
     A("    if (lane < cnt) {")
     A("      double* sl = s_sl + lane * SLOT;")
-    A(f"      if ({dop}) {{")
+    A("      if (do_pred) {")
     A("        const double dt = gdt != nullptr ? gdt[base + lane] : dt_scalar;")
     A(f"        scal_predict(s_x + lane * {D}, dt, sl, norm_quats);")
     A("      } else {")
-    A("#pragma unroll")
-    A(f"        for (int i = 0; i < {D}; i++) sl[{lay.OFF_X} + i] = s_x[lane * {D} + i];")
+    A(f"        scal_keep(s_x + lane * {D}, sl, {dop} ? norm_quats : 0);      // predict(dt = 0) still renormalises")
     A("      }")
     if upd:
       A(f"      scal_obs_{k.kind}(sl, s_z + lane * {Z});")
@@ -302,7 +308,7 @@ def kernels(spec):
     A("      const int gg = g < pcnt ? g : 0;")
     A("      const bool on = act && g < pcnt;")
     A("      double* sl = s_sl + (2 * p + gg) * SLOT;")
-    A(f"      if ({dop}) mat_predict(sPc + gg * {EE}, qcol, sl, cc, on);")
+    A(f"      if (do_pred) mat_predict(sPc + gg * {EE}, qcol, sl, cc, on);")
     if upd:
       A(f"      mat_update_{k.kind}(sPc + gg * {EE}, r_per_filter ? gR + (base + 2 * p + gg) * {ZZ} : gR, sl, sl, s_G + gg * {Z * E}, s_K + gg * {Z * E}, cc, on);")
     A(f"      rn::copy_l2g<2 * {EE}>(gP + (base + 2 * p) * {EE}, pcnt * {EE}, sPc, lane);")
