@@ -357,7 +357,20 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       if (t + 1 < T && lane < cnt * {zmax}) zn = gz[((t + 1) * n + base) * {zmax} + lane];
       const int kind = kinds[t];
       const double dt = dts[t];
-      predict_wide<true>(x, row, col, s_P + gg * {EE}, s_Q, dt, cc, on);
+      if (dt != 0.0) {{
+        predict_wide<true>(x, row, col, s_P + gg * {EE}, s_Q, dt, cc, on);
+      }} else {{
+        // predict(dt = 0) is the identity on (x, P) for finite states (F = I, dt Q = 0): only the column view of P
+        // that the update needs is rebuilt, through one LDS transpose
+        if (on) {{
+#pragma unroll
+          for (int j = 0; j < {E}; j++) s_P[g * {EE} + c * {E} + j] = row[j];
+        }}
+        rn::wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < {E}; k++) col[k] = s_P[gg * {EE} + k * {E} + cc];
+        rn::wave_lds_sync();
+      }}
       {norm}
       int fl = 0;
       switch (kind) {{
