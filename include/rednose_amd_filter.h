@@ -96,6 +96,10 @@ extern "C" {
    * bit1 = non-finite state after the update */                                                               \
   int RN_FN(name, batch_update_##k)(double *x, double *P, double *z, const double *R, int r_per_filter,          \
                                     const double *ea, int64_t n, int norm_quats, uint8_t *flags, void *stream);  \
+  /* Mahalanobis distance d2 = y^T (He P He^T + R)^-1 y of an observation, nothing modified; replaces the Python-only \
+   * EKF_sym.maha_test (/root/reference/rednose/helpers/ekf_sym.py:626-649) for n filters */                      \
+  int RN_FN(name, batch_maha_##k)(const double *x, const double *P, const double *z, const double *R,            \
+                                  int r_per_filter, const double *ea, int64_t n, double *d2, void *stream);      \
   /* fused predict + update: ONE launch, state crosses HBM once (EKFSym::predict_and_update_batch with a       \
    * single observation, ekf_sym.cc:158-194) */                                                                \
   int RN_FN(name, batch_predict_update_##k)(double *x, double *P, const double *Q, const double *dt_vec,         \

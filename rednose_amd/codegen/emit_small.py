@@ -167,6 +167,93 @@ def update_regs(spec, k):
   return "\n".join([head] + _ind(b) + ["}"]), He
 
 
+def maha_regs(spec, k):
+  """d2 = y^T (He P He^T + R)^-1 y for one observation, state untouched (reference: EKF_sym.maha_test, ekf_sym.py:626-649)."""
+  D, E, Z = spec.dim_x, spec.dim_err, k.zdim
+  names = dict(vector_names(spec.x_sym, 'x'))
+  Herr = sp.Matrix(k.H_sym) * sp.Matrix(spec.H_mod_sym)
+  blk = Block(names, tmp_prefix="mt")
+  for i in range(Z):
+    blk.add(f"hx_{i}", k.h_sym[i])
+  fmtH = lambda i, j: f"He_{i}_{j}"  # noqa: E731
+  for i in range(Z):
+    for j in range(E):
+      blk.add(fmtH(i, j), Herr[i, j])
+  stmts, st = blk.lower()
+  He = SMat.from_structure(Z, E, st, fmtH)
+  b = list(stmts)
+  b.append(f"double v[{Z}], S[{Z * Z}], L[{Z * Z}], iL[{Z}];")
+  for i in range(Z):
+    kind, val = st[f"hx_{i}"]
+    hx = f"hx_{i}" if kind == 'expr' else repr(float(val))
+    b.append(f"v[{i}] = z[{i}] - {hx};")
+  for zi in range(Z):
+    nz = He.row_nz(zi)
+    for j in range(E):
+      b.append(f"const double G_{zi}_{j} = {sum_terms(term(c, f'P[{kk * E + j}]') for kk, c in nz)};")
+  for zi in range(Z):
+    for w in range(Z):
+      b.append(f"S[{zi * Z + w}] = {sum_terms(term(c, f'G_{zi}_{j}') for j, c in He.row_nz(w))} + R[{zi * Z + w}];")
+  b.append(f"rn::chol_factor<{Z}>(S, L, iL);")
+  b.append(f"rn::chol_forward<{Z}>(L, iL, v);")
+  b.append("return " + " + ".join(f"v[{i}]*v[{i}]" for i in range(Z)) + ";")
+  head = (f"__device__ __forceinline__ double maha_{k.kind}_regs(const double (&x)[{D}], const double (&P)[{E * E}], "
+          f"const double (&z)[{Z}], const double (&R)[{Z * Z}]) {{")
+  return "\n".join([head] + _ind(b) + ["}"])
+
+
+def maha_kernels(spec):
+  D, E = spec.dim_x, spec.dim_err
+  EE = E * E
+  out = []
+  for k in spec.kinds:
+    Z = k.zdim
+    ZZ = Z * Z
+    out.append(maha_regs(spec, k))
+    out.append(f"""
+__global__ __launch_bounds__(64) void k_maha_{k.kind}(const double* __restrict__ gx, const double* __restrict__ gP,
+    const double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const int64_t n,
+    double* __restrict__ d2) {{
+  __shared__ __attribute__((aligned(16))) double s_x[64 * {D | 1}];
+  __shared__ __attribute__((aligned(16))) double s_P[64 * {EE | 1}];
+  __shared__ __attribute__((aligned(16))) double s_z[64 * {Z | 1}];
+  __shared__ __attribute__((aligned(16))) double s_R[64 * {ZZ | 1}];
+  const int lane = threadIdx.x;
+  const int64_t tiles = (n + 63) >> 6;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
+    const int64_t base = tile << 6;
+    const int cnt = (n - base) < 64 ? (int)(n - base) : 64;
+    rn::tile_g2l_async<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_g2l_async<{EE}>(gP + base * {EE}, cnt, s_P, lane);
+    rn::tile_g2l_async<{Z}>(gz + base * {Z}, cnt, s_z, lane);
+    if (r_per_filter) rn::tile_g2l_async<{ZZ}>(gR + base * {ZZ}, cnt, s_R, lane);
+    rn::async_wait();
+    rn::wave_lds_sync();
+    double x[{D}], P[{EE}], z[{Z}], R[{ZZ}];
+    rn::lds_to_regs<{D}>(s_x, lane, x);
+    rn::lds_to_regs<{EE}>(s_P, lane, P);
+    rn::lds_to_regs<{Z}>(s_z, lane, z);
+    if (r_per_filter) {{
+      rn::lds_to_regs<{ZZ}>(s_R, lane, R);
+    }} else {{
+#pragma unroll
+      for (int i = 0; i < {ZZ}; i++) R[i] = gR[i];
+    }}
+    const double d = maha_{k.kind}_regs(x, P, z, R);
+    if (lane < cnt) d2[base + lane] = d;
+    rn::wave_lds_sync();
+  }}
+}}
+""")
+  return "\n".join(out)
+
+
+def launch_maha(kind):
+  return f"""  const int64_t tiles = (n + 63) >> 6;
+  hipLaunchKernelGGL(k_maha_{kind}, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     x, P, z, R, r_per_filter, n, d2);"""
+
+
 def kernels(spec, step_kernels=True):
   """Device functions + __global__ kernels of family S for every kind (step_kernels=False: only what k_run needs)."""
   waves = tuning.current().small_waves

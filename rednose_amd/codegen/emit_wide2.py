@@ -341,6 +341,86 @@ def kernels(spec):
   return "\n".join(out)
 
 
+def maha_kernels(spec):
+  """Standalone Mahalanobis distance (reference: EKF_sym.maha_test, ekf_sym.py:626-649): d2 per filter, state untouched."""
+  D, E = spec.dim_x, spec.dim_err
+  EE = E * E
+  FT = tile_filters()
+  obs = {k.kind: _lowered_obs(spec, k) for k in spec.kinds}
+  _, _, _, f_vars = _lowered_predict(spec)
+  lay = Layout(spec, f_vars, {kk: v[3] for kk, v in obs.items()})
+  out = []
+  for k in spec.kinds:
+    Z = k.zdim
+    ZZ = Z * Z
+    _, _, He, he_vars = obs[k.kind]
+    Hs = _slotted(He, he_vars, lay.OFF_HE)
+    b = [f"double col[{E}], R[{ZZ}];", "#pragma unroll", f"for (int kq = 0; kq < {E}; kq++) col[kq] = sP[kq * {E} + cc];",
+         "#pragma unroll", f"for (int i = 0; i < {ZZ}; i++) R[i] = gR[i];"]
+    for zi in range(Z):
+      b.append(f"const double G_{zi} = {sum_terms(term(cf, f'col[{kk}]') for kk, cf in Hs.row_nz(zi))};")
+    b.append("if (act) { " + " ".join(f"sG[{zi} * {E} + cc] = G_{zi};" for zi in range(Z)) + " }")
+    b.append("rn::wave_lds_sync();")
+    b.append(f"double S[{ZZ}], L[{ZZ}], iL[{Z}], v[{Z}];")
+    for zi in range(Z):
+      for w in range(Z):
+        b.append(f"S[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))} + R[{zi * Z + w}];")
+    for i in range(Z):
+      b.append(f"v[{i}] = sl[{lay.OFF_Y + i}];")
+    b += [f"rn::chol_factor<{Z}>(S, L, iL);", f"rn::chol_forward<{Z}>(L, iL, v);", "rn::wave_lds_sync();",
+          "return " + " + ".join(f"v[{i}]*v[{i}]" for i in range(Z)) + ";"]
+    out.append("\n".join([f"__device__ __forceinline__ double mat_maha_{k.kind}(const double* sP, const double* __restrict__ gR, const double* sl, "
+                          "double* sG, const int cc, const bool act) {"] + _ind(b) + ["}"]))
+    out.append(f"""
+__global__ __launch_bounds__(64) void k_maha_{k.kind}(const double* __restrict__ gx, const double* __restrict__ gP,
+    const double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const int64_t n,
+    double* __restrict__ d2) {{
+  __shared__ __attribute__((aligned(16))) double s_P[2 * {EE}];
+  __shared__ __attribute__((aligned(16))) double s_x[FT2 * {D} + 2];
+  __shared__ __attribute__((aligned(16))) double s_z[FT2 * {Z} + 2];
+  __shared__ __attribute__((aligned(16))) double s_G[2 * {Z * E}];
+  __shared__ __attribute__((aligned(16))) double s_sl[FT2 * SLOT];
+  const int lane = threadIdx.x;
+  const int g = lane / {G_LANES};
+  const int c = lane % {G_LANES};
+  const bool act = c < {E};
+  const int cc = act ? c : 0;
+  const int64_t tiles = (n + FT2 - 1) / FT2;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
+    const int64_t base = tile * FT2;
+    const int cnt = (n - base) < FT2 ? (int)(n - base) : FT2;
+    rn::copy_g2l<FT2 * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);
+    rn::copy_g2l<FT2 * {Z}>(gz + base * {Z}, cnt * {Z}, s_z, lane);
+    rn::wave_lds_sync();
+    if (lane < cnt) {{
+      double* sl = s_sl + lane * SLOT;
+      scal_keep(s_x + lane * {D}, sl, 0);
+      scal_obs_{k.kind}(sl, s_z + lane * {Z});
+    }}
+    rn::wave_lds_sync();
+    const int npairs = (cnt + 1) >> 1;
+    for (int p = 0; p < npairs; p++) {{
+      const int pcnt = (cnt - 2 * p) < 2 ? (cnt - 2 * p) : 2;
+      rn::copy_g2l<2 * {EE}>(gP + (base + 2 * p) * {EE}, pcnt * {EE}, s_P, lane);
+      rn::wave_lds_sync();
+      const int gg = g < pcnt ? g : 0;
+      const double d = mat_maha_{k.kind}(s_P + gg * {EE}, r_per_filter ? gR + (base + 2 * p + gg) * {ZZ} : gR, s_sl + (2 * p + gg) * SLOT,
+                                  s_G + gg * {Z * E}, cc, act && g < pcnt);
+      if (c == 0 && g < pcnt) d2[base + 2 * p + g] = d;
+      rn::wave_lds_sync();
+    }}
+  }}
+}}
+""")
+  return "\n".join(out)
+
+
+def launch_maha(kind):
+  return f"""  const int64_t tiles = (n + FT2 - 1) / FT2;
+  hipLaunchKernelGGL(k_maha_{kind}, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     x, P, z, R, r_per_filter, n, d2);"""
+
+
 def launch_predict():
   return """  const int64_t tiles = (n + FT2 - 1) / FT2;
   hipLaunchKernelGGL(k_predict, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,

@@ -61,3 +61,32 @@ def test_runtime_global_equals_literal(libs):
   fa.predict(1.0)
   torch.cuda.synchronize()
   assert np.array_equal(fa.state(), X0)
+
+
+# ------------------------------------------------------------------ extra_routines (ekf_sym.py:94-95, ekf.h:32)
+@pytest.fixture(scope="module")
+def extra_lib():
+  from rednose_amd.helpers.ekf_sym import gen_code
+  folder = os.path.join(REPO, "generated")
+  mdl = _model(sp.Float(1.0))
+  st = mdl["x_sym"]
+  other = sp.MatrixSymbol('other', 2, 1)
+  energy = sp.Matrix([[0.5 * st[1, 0]**2 + 9.81 * st[0, 0] + other[0, 0] * other[1, 0]]])
+  gen_code(folder, "gv_extra", extra_routines=[("energy", energy, [st, other])], **mdl)
+  return folder
+
+
+def test_extra_routine_is_exported(extra_lib):
+  import ctypes
+  with open(os.path.join(extra_lib, "gv_extra.h"), encoding="utf-8") as f:
+    assert "void gv_extra_energy(double *state, double *other, double *out);" in f.read()
+  assert hasattr(ctypes.CDLL(os.path.join(extra_lib, "libgv_extra.so")), "gv_extra_energy")
+
+
+@pytest.mark.gpu
+def test_extra_routine_value(extra_lib):
+  from rednose_amd.helpers import load_code
+  ffi, lib = load_code(extra_lib, "gv_extra")
+  x = np.array([2.0, 3.0]); o = np.array([0.5, 4.0]); out = np.zeros(1)
+  lib.gv_extra_energy(ffi.cast("double *", x.ctypes.data), ffi.cast("double *", o.ctypes.data), ffi.cast("double *", out.ctypes.data))
+  assert abs(out[0] - (0.5 * 9.0 + 9.81 * 2.0 + 2.0)) < 1e-12

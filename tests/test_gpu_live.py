@@ -168,3 +168,28 @@ def test_nonfinite_state_is_flagged_not_fatal(env):
   assert (fl[2] & 2) == 2 and (np.delete(fl, 2) & 2).sum() == 0
   X = f.state()
   assert np.isfinite(np.delete(X, 2, axis=0)).all()
+
+
+def test_batched_maha_test_matches_reference_decisions(env):
+  """{name}_batch_maha_{kind}: decisions of the reference's own maha_test() (golden) and distances vs numpy; state untouched."""
+  torch, gen, L = env
+  g = golden("live_maha.npz")
+  n = g["x"].shape[0]
+  f = _filter(env, n)
+  f.init_state(g["x"], g["P"], 0.0)
+  x_before, P_before = f.x.clone(), f.P.clone()
+  ok = f.maha_test(12, g["z"], g["R"])
+  d2 = f.maha_dist(12, g["z"], g["R"]).cpu().numpy()
+  torch.cuda.synchronize()
+  assert np.array_equal(ok.cpu().numpy(), g["accepted"])
+  assert torch.equal(f.x, x_before) and torch.equal(f.P, P_before)
+  y = g["z"] - g["x"][:, :3]
+  S = g["P"][:, :3, :3] + g["R"][None]
+  want = np.einsum("ni,ni->n", y, np.linalg.solve(S, y[..., None])[..., 0])
+  assert_close(d2, want, rtol=1e-9)
+  # a non-trivial Jacobian (gyro) on a ragged batch
+  m = 5
+  h = _filter(env, m)
+  h.init_state(g["x"][:m], g["P"][:m], 0.0)
+  d4 = h.maha_dist(4, np.zeros((m, 3)), L.obs_noise[4]).cpu().numpy()
+  assert np.isfinite(d4).all() and (d4 >= 0).all()

@@ -264,3 +264,22 @@ def test_batched_rewind_matches_reference_class(gen_dir, torch_cuda):
   h.predict_and_update_batch(1.0, 1, np.zeros((4, 1)), R)
   with pytest.raises(AssertionError):
     h.predict_and_update_batch(0.5, 1, np.zeros((4, 1)), R)
+
+
+def test_batched_maha_dist_small_family(gen_dir, torch_cuda):
+  torch = torch_cuda
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  from examples.kinematic6_kf import Kinematic6Kalman as K6
+  n = 333
+  rng = np.random.default_rng(12)
+  x0 = rng.normal(size=(n, 6)); P0 = _rand_spd(rng, n, 6, 0.01)
+  z = x0[:, :3] + rng.normal(size=(n, 3)) * 0.2
+  f = BatchedEKF(gen_dir, "kinematic6", K6.Q, x0[0], P0[0], 6, 6, batch=n)
+  f.init_state(x0, P0, 0.0)
+  d2 = f.maha_dist(1, z, K6.obs_noise[1]).cpu().numpy()
+  y = z - x0[:, :3]
+  S = P0[:, :3, :3] + K6.obs_noise[1][None]
+  want = np.einsum("ni,ni->n", y, np.linalg.solve(S, y[..., None])[..., 0])
+  assert_close(d2, want, rtol=1e-10)
+  from rednose_amd.helpers.chi2_lookup import chi2_ppf
+  assert np.array_equal(f.maha_test(1, z, K6.obs_noise[1]).cpu().numpy(), ~(want > chi2_ppf(0.95, 3)))
