@@ -1,0 +1,47 @@
+// C++ driver for rednose_amd::EKFSymBatch: replays a (t, z) stream read from a text file through the kinematic filter
+// for a batch of identical filters and prints the final state / sqrt(diag P) of the first and last filter.
+// tests/test_gpu_cpp.py feeds it the stream of /root/reference/examples/test_kinematic_kf.py and checks the literals.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+#include "rednose_amd/ekf_sym_batch.hpp"
+
+int main(int argc, char** argv) {
+  if (argc < 4) {
+    std::fprintf(stderr, "usage: %s <generated_dir> <stream.txt> <batch>\n", argv[0]);
+    return 2;
+  }
+  const int64_t n = std::atoll(argv[3]);
+  try {
+    rednose_amd::EKFSymBatch kf(argv[1], "kinematic", {0.1 * 0.1, 0.0, 0.0, 2.0 * 2.0}, {0.5, 0.0}, {1.0, 0.0, 0.0, 1.0}, n);
+    std::ifstream in(argv[2]);
+    std::vector<double> zs(n);
+    double* z_dev = nullptr;
+    if (hipMalloc((void**)&z_dev, sizeof(double) * n) != hipSuccess) return 3;
+    const double R[1] = {0.1 * 0.1};
+    double t, z;
+    long steps = 0;
+    while (in >> t >> z) {
+      std::fill(zs.begin(), zs.end(), z);
+      if (hipMemcpy(z_dev, zs.data(), sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) return 3;
+      if (!kf.predict_and_update_batch(t, 1, z_dev, R)) return 4;
+      steps++;
+    }
+    // a late observation must be rejected, an unknown kind must throw
+    const bool late = kf.predict_and_update_batch(0.0, 1, z_dev, R);
+    bool threw = false;
+    try { kf.predict_and_update_batch(1e9, 7, z_dev, R); } catch (const std::out_of_range&) { threw = true; }
+    kf.synchronize();
+    const std::vector<double> x = kf.state(), P = kf.covs();
+    std::printf("steps %ld late_rejected %d unknown_kind_threw %d filter_time %.17g\n", steps, late ? 0 : 1, threw ? 1 : 0, kf.get_filter_time());
+    for (int64_t i : {(int64_t)0, n - 1})
+      std::printf("x %.17g %.17g std %.17g %.17g\n", x[i * 2], x[i * 2 + 1], std::sqrt(P[i * 4]), std::sqrt(P[i * 4 + 3]));
+    (void)hipFree(z_dev);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "exception: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
