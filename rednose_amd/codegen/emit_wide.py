@@ -37,7 +37,7 @@ def _even(n):
   return n + (n & 1)
 
 
-def predict_fn(spec):
+def predict_fn(spec, rts=False):
   D, E, M = spec.dim_x, spec.dim_err, spec.dim_main_err
   names = {**vector_names(spec.x_sym, 'x'), spec.dt_sym: 'dt'}
   blk = Block(names, tmp_prefix="pt")
@@ -54,6 +54,9 @@ def predict_fn(spec):
   b.append(f"double a[{E}];")
   for i in range(E):
     b.append(f"a[{i}] = {sum_terms(term(cf, f'row[{k}]') for k, cf in F.row_nz(i))};")
+  if rts:
+    b.append("#pragma unroll")
+    b.append(f"for (int i = 0; i < {E}; i++) arow[i] = a[i];       // column c of M = F P^T, the smoother's right-hand side")
   b.append("if (act) {")
   b.append("#pragma unroll")
   b.append(f"  for (int i = 0; i < {E}; i++) sP[cc * {E} + i] = a[i];")
@@ -76,8 +79,12 @@ def predict_fn(spec):
   for i in range(D):
     kind, val = st[f"xn_{i}"]
     b.append(f"x[{i}] = xn_{i};" if kind == 'expr' else f"x[{i}] = {float(val)!r};")
-  head = (f"template <bool WANT_ROW>\n__device__ __forceinline__ void predict_wide(double (&x)[{D}], double (&row)[{E}], double (&col)[{E}], "
-          "double* sP, const double* sQ, const double dt, const int cc, const bool act) {")
+  if rts:
+    head = (f"__device__ __forceinline__ void predict_wide_rts(double (&x)[{D}], double (&row)[{E}], double (&arow)[{E}], double (&col)[{E}], "
+            "double* sP, const double* sQ, const double dt, const int cc, const bool act) {\n  constexpr bool WANT_ROW = false;")
+  else:
+    head = (f"template <bool WANT_ROW>\n__device__ __forceinline__ void predict_wide(double (&x)[{D}], double (&row)[{E}], double (&col)[{E}], "
+            "double* sP, const double* sQ, const double dt, const int cc, const bool act) {")
   return "\n".join([head] + _ind(b) + ["}"])
 
 
@@ -170,6 +177,7 @@ def kernels(spec, step_kernels=True):
   zmax = max(k.zdim for k in spec.kinds)
   out = [f"constexpr int GL = {G_LANES};    // lanes per filter", f"constexpr int FPW = {FPW};   // filters per wavefront", ""]
   out.append(predict_fn(spec))
+  out.append(predict_fn(spec, rts=True))
   for k in spec.kinds:
     utxt, _ = update_fn(spec, k)
     out.append(utxt)

@@ -100,27 +100,42 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
       for (int j = 0; j < E; j++) prow[j] = A[cc * E + j];
 
       // ---- recompute the predicted pair of step k+1 exactly as the forward pass did ----------------------
-      Model::f(xk, dt, x1k);
-      if (norm_quats) Model::normalize(x1k);
-      if (c == 0 && g < cnt) Model::F(xk, dt, Fm);
-      wave_lds_sync();
-      // M = Fk Pk_k^T : lane c forms column c, M[i][c] = sum_m F[i][m] Pk[c][m].  The i loops of the dense E x E
-      // products stay rolled (operands in LDS, dynamic row address): fully unrolled they needed > 512 registers
-      // and 7 KB of scratch per lane.
-#pragma unroll 1
-      for (int i = 0; i < E; i++) {
-        double s = 0.0;
+      const bool first = (k == T - 2);     // recursion start: smoothed(T-1) := predicted(T-1)  (estimates[-1][0], [2])
+      if constexpr (Model::SPARSE) {
+        // generated sparse predict (F has ~33 non-trivial entries of 484): the same code the forward kernels run
+        double mcol[E], p1col[E];
 #pragma unroll
-        for (int m = 0; m < E; m++) s += Fm[i * E + m] * prow[m];
-        if (on) M[i * E + c] = s;
-      }
-      wave_lds_sync();
-      // Pk1_k = Fk (Pk_k Fk^T) + dt Q : column c, using row c of M (= column c of Pk_k Fk^T); Dm = Pk1_n - Pk1_k
-      {
+        for (int i = 0; i < D; i++) x1k[i] = xk[i];
+        Model::predict_cov(x1k, prow, mcol, p1col, L, s_Q, dt, cc, on);        // L <- Pk1_k (full matrix), x1k <- f(xk)
+        if (norm_quats) Model::normalize(x1k);
+        if (on) {
+#pragma unroll
+          for (int i = 0; i < E; i++) {
+            M[i * E + c] = mcol[i];
+            if (first) Nn[i * E + c] = p1col[i];
+            Dm[i * E + c] = Nn[i * E + c] - p1col[i];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < E; j++) prow[j] = A[cc * E + j];                 // predict_cov consumed the row registers
+      } else {
+        Model::f(xk, dt, x1k);
+        if (norm_quats) Model::normalize(x1k);
+        if (c == 0 && g < cnt) Model::F(xk, dt, Fm);
+        wave_lds_sync();
+        // M = Fk Pk_k^T : lane c forms column c, M[i][c] = sum_m F[i][m] Pk[c][m]; i loops stay rolled (operands in LDS)
+#pragma unroll 1
+        for (int i = 0; i < E; i++) {
+          double s = 0.0;
+#pragma unroll
+          for (int m = 0; m < E; m++) s += Fm[i * E + m] * prow[m];
+          if (on) M[i * E + c] = s;
+        }
+        wave_lds_sync();
+        // Pk1_k = Fk (Pk_k Fk^T) + dt Q : column c, using row c of M (= column c of Pk_k Fk^T); Dm = Pk1_n - Pk1_k
         double mrow[E];
 #pragma unroll
         for (int m = 0; m < E; m++) mrow[m] = M[cc * E + m];
-        const bool first = (k == T - 2);     // recursion start: smoothed(T-1) := predicted(T-1)  (estimates[-1][0], [2])
 #pragma unroll 1
         for (int i = 0; i < E; i++) {
           double s = 0.0;
@@ -152,9 +167,15 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
       // ---- Cholesky of Pk1_k in LDS (left-looking by columns), lane c owns row c; loops stay rolled -------------
 #pragma unroll 1
       for (int j = 0; j < E; j++) {
-        double s = L[cc * E + j];
+        double s = L[cc * E + j], s2 = 0.0;
+        int m = 0;
 #pragma unroll 2
-        for (int m = 0; m < j; m++) s -= L[cc * E + m] * L[j * E + m];
+        for (; m + 1 < j; m += 2) {
+          s -= L[cc * E + m] * L[j * E + m];
+          s2 -= L[cc * E + m + 1] * L[j * E + m + 1];
+        }
+        if (m < j) s -= L[cc * E + m] * L[j * E + m];
+        s += s2;
         if (c == j && g < cnt) {
           const double ljj = sqrt(s);
           L[j * E + j] = ljj;
@@ -167,17 +188,27 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
       // ---- Ck^T = Pk1_k^-1 M : lane c solves for column c IN PLACE in its own column of M -----------------------
 #pragma unroll 1
       for (int i = 0; i < E; i++) {
-        double s = M[i * E + cc];
+        double s = M[i * E + cc], s2 = 0.0;
+        int m = 0;
 #pragma unroll 2
-        for (int m = 0; m < i; m++) s -= L[i * E + m] * M[m * E + cc];
-        if (on) M[i * E + c] = s * sil[i];
+        for (; m + 1 < i; m += 2) {
+          s -= L[i * E + m] * M[m * E + cc];
+          s2 -= L[i * E + m + 1] * M[(m + 1) * E + cc];
+        }
+        if (m < i) s -= L[i * E + m] * M[m * E + cc];
+        if (on) M[i * E + c] = (s + s2) * sil[i];
       }
 #pragma unroll 1
       for (int i = E - 1; i >= 0; i--) {
-        double s = M[i * E + cc];
+        double s = M[i * E + cc], s2 = 0.0;
+        int m = i + 1;
 #pragma unroll 2
-        for (int m = i + 1; m < E; m++) s -= L[m * E + i] * M[m * E + cc];
-        if (on) M[i * E + c] = s * sil[i];
+        for (; m + 1 < E; m += 2) {
+          s -= L[m * E + i] * M[m * E + cc];
+          s2 -= L[(m + 1) * E + i] * M[(m + 1) * E + cc];
+        }
+        if (m < E) s -= L[m * E + i] * M[m * E + cc];
+        if (on) M[i * E + c] = (s + s2) * sil[i];
       }
       // column c of X = Ck^T is row c of Ck
       double ck[E];
@@ -204,10 +235,10 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
       wave_lds_sync();           // every lane has taken its right-hand side out of M: M becomes the T = Ck Dm buffer
 #pragma unroll 1
       for (int m = 0; m < E; m++) {
-        double s = 0.0;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};      // four independent chains: one accumulator would serialise 22 fp64 FMAs
 #pragma unroll
-        for (int j = 0; j < E; j++) s += ck[j] * Dm[j * E + m];
-        if (on) M[c * E + m] = s;
+        for (int j = 0; j < E; j++) acc[j & 3] += ck[j] * Dm[j * E + m];
+        if (on) M[c * E + m] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
       }
       wave_lds_sync();
       {
@@ -216,10 +247,10 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
         for (int j = 0; j < E; j++) trow[j] = M[cc * E + j];
 #pragma unroll 1
         for (int m = 0; m < E; m++) {
-          double s = A[cc * E + m];
+          double acc[4] = {A[cc * E + m], 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int j = 0; j < E; j++) s += trow[j] * C[m * E + j];
-          if (on) Nn[c * E + m] = s;          // Pk1_n of the next (older) step; Dm already holds what was needed of the old one
+          for (int j = 0; j < E; j++) acc[j & 3] += trow[j] * C[m * E + j];
+          if (on) Nn[c * E + m] = (acc[0] + acc[1]) + (acc[2] + acc[3]);   // Pk1_n of the next (older) step
         }
       }
       wave_lds_sync();
