@@ -188,10 +188,18 @@ def main():
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs a HIP device: rednose_amd has no CPU path")
-  torch.cuda.set_device(local_rank)
-  dev = torch.device(f"cuda:{local_rank}")
+  ndev = torch.cuda.device_count()
+  dev_index = local_rank % ndev                    # one rank per GPU; the modulo only matters for single-GPU dry runs
+  torch.cuda.set_device(dev_index)
+  dev = torch.device(f"cuda:{dev_index}")
   if world > 1:
-    dist.init_process_group(backend="nccl", device_id=dev)
+    # "nccl" is RCCL on ROCm.  RN_BENCH_BACKEND=gloo allows a functional dry run of this path with several ranks on ONE
+    # GPU (RCCL refuses duplicate devices); it is never used for reported numbers.
+    backend = os.environ.get("RN_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+      dist.init_process_group(backend="nccl", device_id=dev)
+    else:
+      dist.init_process_group(backend=backend)
 
   K, W = args.steps, args.warmup
   n = args.batch or (16384 if args.model == "live" else 65536)
@@ -200,12 +208,12 @@ def main():
 
   extra = {}
   if not args.no_extras and world == 1:
-    others = {"kinematic6": [("live", 16384, 420, 42), ("kinematic", 65536, 500, 50)],
+    others = {"kinematic6": [("live", 16384, 420, 42), ("kinematic", 65536, 500, 50), ("kinematic6", 1 << 20, 200, 20)],
               "live": [], "kinematic": []}[args.model]
     for om, on, oK, oW in others:
       o = run_model(torch, dist, args, om, on, oK, oW, dev, rank, world)
       ls = o["dev_ms"] * 1e-3 / oK
-      extra[om] = {"batch": on, "steps": oK, "value": on * oK / o["wall"], "unit": "steps/s", "launch_us": ls * 1e6,
+      extra[om if on != (1 << 20) else om + "_1M"] = {"batch": on, "steps": oK, "value": on * oK / o["wall"], "unit": "steps/s", "launch_us": ls * 1e6,
                    "algorithmic_bytes_per_filter_step": o["bytes_per_step"], "achieved_GBs": o["bytes_per_step"] * on / ls / 1e9,
                    "frac_of_8TBs": o["bytes_per_step"] * on / ls / 1e9 / HBM_PEAK_GBS, "kinds": o["kinds"]}
 
