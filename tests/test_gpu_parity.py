@@ -283,3 +283,29 @@ def test_batched_maha_dist_small_family(gen_dir, torch_cuda):
   assert_close(d2, want, rtol=1e-10)
   from rednose_amd.helpers.chi2_lookup import chi2_ppf
   assert np.array_equal(f.maha_test(1, z, K6.obs_noise[1]).cpu().numpy(), ~(want > chi2_ppf(0.95, 3)))
+
+
+def test_per_filter_filter_times(gen_dir, torch_cuda):
+  """Filters initialised at different times (per-filter filter_time / dt): the first step to a common
+  time uses a per-filter dt on the device; afterwards the batch shares one clock."""
+  torch = torch_cuda
+  from oracle_lib import OracleLib
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  from examples.kinematic6_kf import Kinematic6Kalman as K6
+  o = OracleLib("kinematic6")
+  n = 200
+  rng = np.random.default_rng(21)
+  x0 = rng.normal(size=(n, 6)); P0 = _rand_spd(rng, n, 6)
+  ft = rng.uniform(0.0, 0.9, size=n)
+  f = BatchedEKF(gen_dir, "kinematic6", K6.Q, x0[0], P0[0], 6, 6, batch=n)
+  f.init_state(x0, P0, ft)
+  z = rng.normal(size=(n, 3))
+  y = f.predict_and_update_batch(1.0, 1, z.copy(), K6.obs_noise[1])
+  torch.cuda.synchronize()
+  assert f.get_filter_time() == 1.0
+  xr, Pr, zr = x0.copy(), P0.copy(), z.copy()
+  o.batch_step(1, xr, Pr, zr, K6.obs_noise[1], K6.Q, 1.0 - ft)
+  assert_close(f.state(), xr); assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1)); assert_close(y.cpu().numpy(), zr, atol=1e-14 * np.abs(z).max())
+  f.init_state(x0, P0, ft)
+  with pytest.raises(AssertionError):
+    f.predict(0.5)                     # some filters are already past 0.5
