@@ -112,24 +112,24 @@ def update_regs(spec, k):
       b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(c, f'G_{zi}_{j}') for j, c in He.row_nz(w))};")
   b.append("#pragma unroll")
   b.append(f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}")
-  b.append(f"rn::chol_factor<{Z}>(S, L, iL);")
+  b.append(f"rn::spd_factor<{Z}>(S, L, iL);")
   b.append("int gated = 0;")
   if k.maha_test:
     b.append("{")
     b.append(f"  double v[{Z}] = {{{', '.join(f'y_{i}' for i in range(Z))}}};")
-    b.append(f"  rn::chol_forward<{Z}>(L, iL, v);")
-    b.append("  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]" for i in range(Z)) + ";")
+    b.append(f"  rn::spd_forward<{Z}>(L, iL, v);")
+    b.append("  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";")
     b.append(f"  if (d2 > {k.maha_thresh!r}) {{")
     b.append("    gated = 1;")
     b.append("#pragma unroll")
     b.append(f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}")
-    b.append(f"    rn::chol_factor<{Z}>(S, L, iL);")
+    b.append(f"    rn::spd_factor<{Z}>(S, L, iL);")
     b.append("  }")
     b.append("}")
   # K (E x Z): column j of Gt solved against S
   for j in range(E):
     b.append(f"double k_{j}[{Z}] = {{{', '.join(f'Gt_{zi}_{j}' for zi in range(Z))}}};")
-    b.append(f"rn::chol_solve<{Z}>(L, iL, k_{j});")
+    b.append(f"rn::spd_solve<{Z}>(L, iL, k_{j});")
   K = lambda i, zi: f"k_{i}[{zi}]"  # noqa: E731
   for j in range(E):
     b.append(f"const double dx_{j} = " + " + ".join(f"{K(j, zi)}*y_{zi}" for zi in range(Z)) + ";")
@@ -194,9 +194,9 @@ def maha_regs(spec, k):
   for zi in range(Z):
     for w in range(Z):
       b.append(f"S[{zi * Z + w}] = {sum_terms(term(c, f'G_{zi}_{j}') for j, c in He.row_nz(w))} + R[{zi * Z + w}];")
-  b.append(f"rn::chol_factor<{Z}>(S, L, iL);")
-  b.append(f"rn::chol_forward<{Z}>(L, iL, v);")
-  b.append("return " + " + ".join(f"v[{i}]*v[{i}]" for i in range(Z)) + ";")
+  b.append(f"rn::spd_factor<{Z}>(S, L, iL);")
+  b.append(f"rn::spd_forward<{Z}>(L, iL, v);")
+  b.append("return " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";")
   head = (f"__device__ __forceinline__ double maha_{k.kind}_regs(const double (&x)[{D}], const double (&P)[{E * E}], "
           f"const double (&z)[{Z}], const double (&R)[{Z * Z}]) {{")
   return "\n".join([head] + _ind(b) + ["}"])

@@ -126,17 +126,17 @@ def update_pair(spec, k):
       b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(c, f'G_{zi}_{j}') for j, c in He.row_nz(w))};")
   b.append("#pragma unroll")
   b.append(f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}")
-  b.append(f"rn::chol_factor<{Z}>(S, L, iL);")
+  b.append(f"rn::spd_factor<{Z}>(S, L, iL);")
   b.append("int gated = 0;")
   if k.maha_test:
-    b += ["{", f"  double v[{Z}] = {{{', '.join(f'y_{i}' for i in range(Z))}}};", f"  rn::chol_forward<{Z}>(L, iL, v);",
-          "  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]" for i in range(Z)) + ";", f"  if (d2 > {k.maha_thresh!r}) {{", "    gated = 1;",
+    b += ["{", f"  double v[{Z}] = {{{', '.join(f'y_{i}' for i in range(Z))}}};", f"  rn::spd_forward<{Z}>(L, iL, v);",
+          "  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";", f"  if (d2 > {k.maha_thresh!r}) {{", "    gated = 1;",
           "#pragma unroll", f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}",
-          f"    rn::chol_factor<{Z}>(S, L, iL);", "  }", "}"]
+          f"    rn::spd_factor<{Z}>(S, L, iL);", "  }", "}"]
   # K, own rows
   for r in range(HR):
     b.append(f"double k_{r}[{Z}] = {{{', '.join(f'Gt_{zi}_{r}' for zi in range(Z))}}};")
-    b.append(f"rn::chol_solve<{Z}>(L, iL, k_{r});")
+    b.append(f"rn::spd_solve<{Z}>(L, iL, k_{r});")
   # dx: own rows, then the full vector (both lanes inject the error into their copy of x)
   b.append(f"double dxt[{HR}], dxb[{HR}];")
   for r in range(HR):

@@ -118,22 +118,22 @@ def update_fn(spec, k):
       b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in He.row_nz(w))};")
   b.append("#pragma unroll")
   b.append(f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}")
-  b.append(f"rn::chol_factor<{Z}>(S, L, iL);")
+  b.append(f"rn::spd_factor<{Z}>(S, L, iL);")
   b.append("int gated = 0;")
   if k.maha_test:
     b.append("{")
     b.append(f"  double v[{Z}] = {{{', '.join(f'y_{i}' for i in range(Z))}}};")
-    b.append(f"  rn::chol_forward<{Z}>(L, iL, v);")
-    b.append("  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]" for i in range(Z)) + ";")
+    b.append(f"  rn::spd_forward<{Z}>(L, iL, v);")
+    b.append("  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";")
     b.append(f"  if (d2 > {k.maha_thresh!r}) {{")
     b.append("    gated = 1;")
     b.append("#pragma unroll")
     b.append(f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}")
-    b.append(f"    rn::chol_factor<{Z}>(S, L, iL);")
+    b.append(f"    rn::spd_factor<{Z}>(S, L, iL);")
     b.append("  }")
     b.append("}")
   b.append(f"double kk[{Z}] = {{{', '.join(f'Gt_{zi}' for zi in range(Z))}}};")
-  b.append(f"rn::chol_solve<{Z}>(L, iL, kk);                       // K[c][:]")
+  b.append(f"rn::spd_solve<{Z}>(L, iL, kk);                       // K[c][:]")
   b.append("const double dxc = " + " + ".join(f"kk[{zi}]*y_{zi}" for zi in range(Z)) + ";")
   # B row
   b.append("#pragma unroll")

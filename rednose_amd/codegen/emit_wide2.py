@@ -199,15 +199,15 @@ def device_functions(spec):
     for zi in range(Z):
       for w in range(Z):
         b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))};")
-    b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}", f"rn::chol_factor<{Z}>(S, L, iL);",
+    b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}", f"rn::spd_factor<{Z}>(S, L, iL);",
           "int gated = 0;"]
     if k.maha_test:
-      b += ["{", f"  double v[{Z}] = {{{', '.join(f'sl[{lay.OFF_Y + i}]' for i in range(Z))}}};", f"  rn::chol_forward<{Z}>(L, iL, v);",
-            "  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]" for i in range(Z)) + ";", f"  if (d2 > {k.maha_thresh!r}) {{", "    gated = 1;",
+      b += ["{", f"  double v[{Z}] = {{{', '.join(f'sl[{lay.OFF_Y + i}]' for i in range(Z))}}};", f"  rn::spd_forward<{Z}>(L, iL, v);",
+            "  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";", f"  if (d2 > {k.maha_thresh!r}) {{", "    gated = 1;",
             "#pragma unroll", f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}",
-            f"    rn::chol_factor<{Z}>(S, L, iL);", "  }", "}"]
+            f"    rn::spd_factor<{Z}>(S, L, iL);", "  }", "}"]
     b.append(f"double kk[{Z}] = {{{', '.join(f'Gt_{zi}' for zi in range(Z))}}};")
-    b.append(f"rn::chol_solve<{Z}>(L, iL, kk);")
+    b.append(f"rn::spd_solve<{Z}>(L, iL, kk);")
     b.append("const double dxc = " + " + ".join(f"kk[{zi}]*sl[{lay.OFF_Y + zi}]" for zi in range(Z)) + ";")
     for j in range(E):
       b.append(f"row[{j}] -= " + " + ".join(f"kk[{zi}]*sG[{zi * E + j}]" for zi in range(Z)) + ";")
@@ -367,8 +367,8 @@ def maha_kernels(spec):
         b.append(f"S[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))} + R[{zi * Z + w}];")
     for i in range(Z):
       b.append(f"v[{i}] = sl[{lay.OFF_Y + i}];")
-    b += [f"rn::chol_factor<{Z}>(S, L, iL);", f"rn::chol_forward<{Z}>(L, iL, v);", "rn::wave_lds_sync();",
-          "return " + " + ".join(f"v[{i}]*v[{i}]" for i in range(Z)) + ";"]
+    b += [f"rn::spd_factor<{Z}>(S, L, iL);", f"rn::spd_forward<{Z}>(L, iL, v);", "rn::wave_lds_sync();",
+          "return " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";"]
     out.append("\n".join([f"__device__ __forceinline__ double mat_maha_{k.kind}(const double* sP, const double* __restrict__ gR, const double* sl, "
                           "double* sG, const int cc, const bool act) {"] + _ind(b) + ["}"]))
     out.append(f"""

@@ -5,8 +5,8 @@
 //   * wave-private LDS transposition between the AoS batch layout in HBM (x:(N,D), P:(N,E,E),
 //     z:(N,Z) row-major, the natural numpy/torch batch of the reference's per-filter buffers) and a
 //     lane-per-filter register layout, with fully coalesced 16-byte global accesses;
-//   * in-register Cholesky factor / solve for the Z x Z innovation covariance (S is SPD; the
-//     reference uses fullPivLu, ekf_c.c:89,101 -- same solution up to rounding);
+//   * in-register square-root-free Cholesky (L D L^T) factor / solve for the Z x Z innovation covariance
+//     (S is SPD; the reference uses fullPivLu, ekf_c.c:89,101 -- same solution up to rounding);
 //   * host-side plumbing for the C ABI: error reporting, scratch buffers for the single-filter
 //     host-pointer entry points, launch geometry.
 // Written for CDNA4 only: 64-lane wavefronts, one wavefront per workgroup, no portability layer.
@@ -336,49 +336,63 @@ __device__ __forceinline__ double pair_xchg(const double v) {
   return __hiloint2double(hi, lo);
 }
 
-// S = L L^T, lower triangle of S is read; iL[i] = 1 / L[i][i].  Fully unrolled, lives in VGPRs.
+// Reciprocal for the factorisation below: v_rcp_f64 seed + two Newton steps (about 1 ulp).  The IEEE division
+// sequence hipcc emits for 1.0/d is ~10 DEPENDENT instructions; on this hardware a dependent fp64 instruction costs
+// ~40 cycles for a lone wavefront (tools/fp64_ilp.hip: 40.7 cycles per FMA with one chain, 10.8 with eight), and the
+// factorisation sits on the critical path of every update.  No denormal / overflow scaling: d is a variance.
+__device__ __forceinline__ double fast_recip(const double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+
+// S = L D L^T with unit lower-triangular L (lower triangle of S is read); iD[j] = 1 / D[j].  Square-root-free on
+// purpose: Cholesky's sqrt + reciprocal per column are two long dependent chains (see fast_recip).  S is the SPD
+// innovation covariance; the reference solves with fullPivLu (ekf_c.c:89,101) -- same solution up to rounding.
 template <int Z>
-__device__ __forceinline__ void chol_factor(const double (&S)[Z * Z], double (&L)[Z * Z], double (&iL)[Z]) {
+__device__ __forceinline__ void spd_factor(const double (&S)[Z * Z], double (&L)[Z * Z], double (&iD)[Z]) {
+  double D[Z];
 #pragma unroll
   for (int j = 0; j < Z; j++) {
     double d = S[j * Z + j];
 #pragma unroll
-    for (int k = 0; k < j; k++) d -= L[j * Z + k] * L[j * Z + k];
-    const double ljj = sqrt(d);
-    L[j * Z + j] = ljj;
-    iL[j] = 1.0 / ljj;
+    for (int k = 0; k < j; k++) d -= L[j * Z + k] * L[j * Z + k] * D[k];
+    D[j] = d;
+    iD[j] = fast_recip(d);
 #pragma unroll
     for (int i = j + 1; i < Z; i++) {
       double s = S[i * Z + j];
 #pragma unroll
-      for (int k = 0; k < j; k++) s -= L[i * Z + k] * L[j * Z + k];
-      L[i * Z + j] = s * iL[j];
+      for (int k = 0; k < j; k++) s -= L[i * Z + k] * L[j * Z + k] * D[k];
+      L[i * Z + j] = s * iD[j];
     }
   }
 }
 
-// forward substitution only: b <- L^{-1} b
+// b <- L^{-1} b (unit lower triangular).  The quadratic form b^T S^{-1} b is then sum_i b[i]^2 iD[i].
 template <int Z>
-__device__ __forceinline__ void chol_forward(const double (&L)[Z * Z], const double (&iL)[Z], double (&b)[Z]) {
+__device__ __forceinline__ void spd_forward(const double (&L)[Z * Z], const double (&iD)[Z], double (&b)[Z]) {
+  (void)iD;
 #pragma unroll
   for (int i = 0; i < Z; i++) {
     double s = b[i];
 #pragma unroll
     for (int k = 0; k < i; k++) s -= L[i * Z + k] * b[k];
-    b[i] = s * iL[i];
+    b[i] = s;
   }
 }
 
-// b <- (L L^T)^{-1} b
+// b <- (L D L^T)^{-1} b
 template <int Z>
-__device__ __forceinline__ void chol_solve(const double (&L)[Z * Z], const double (&iL)[Z], double (&b)[Z]) {
-  chol_forward<Z>(L, iL, b);
+__device__ __forceinline__ void spd_solve(const double (&L)[Z * Z], const double (&iD)[Z], double (&b)[Z]) {
+  spd_forward<Z>(L, iD, b);
 #pragma unroll
   for (int i = Z - 1; i >= 0; i--) {
-    double s = b[i];
+    double s = b[i] * iD[i];
 #pragma unroll
     for (int k = i + 1; k < Z; k++) s -= L[k * Z + i] * b[k];
-    b[i] = s * iL[i];
+    b[i] = s;
   }
 }
 
