@@ -41,6 +41,7 @@ MODELS = {
   "live_maha": dict(refscript="examples/live_kf.py", model="examples.live_kf:LiveKalman", rename="live_maha",
                     maha_test_kinds=[12]),
   "kinematic6": dict(model="examples.kinematic6_kf:Kinematic6Kalman"),
+  "kinematic9": dict(model="examples.kinematic9_kf:Kinematic9Kalman"),
   "kinematic6_maha": dict(model="examples.kinematic6_kf:Kinematic6Kalman", rename="kinematic6_maha",
                           maha_test_kinds=[1]),
 }

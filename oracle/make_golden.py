@@ -217,6 +217,39 @@ def rts_goldens():
                       Pk_k=inp["Pk_k"])
 
 
+def kinematic9_goldens(T=60):
+  """Mixed-kind stream (POSITION / RANGE / VELOCITY) of the 9-state constant-acceleration example through the
+  reference's numpy predict/update and rts_smooth: golden for the mid-size (7 filters per wavefront) kernels."""
+  import copy
+  import importlib.util   # by path: `examples` on this script's sys.path is the reference's package
+  spec = importlib.util.spec_from_file_location("rn_amd_kinematic9_kf", os.path.join(REPO, "examples", "kinematic9_kf.py"))
+  mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+  K9, ANCHOR = mod.Kinematic9Kalman, mod.ANCHOR
+  rng = np.random.default_rng(9)
+  f = ref_filter("kinematic9", K9.Q, K9.initial_x, np.diag(K9.initial_P_diag), 9, 9)
+  truth = np.array([0.5, 0.5, 0.5, 1.0, -0.5, 0.2, 0.3, 0.1, -0.2])
+  t, est, kinds, zs = 0.0, [], [], []
+  for i in range(T):
+    dt = float(rng.uniform(0.01, 0.05))
+    t += dt
+    truth[0:3] += dt * truth[3:6]; truth[3:6] += dt * truth[6:9]
+    k = (1, 2, 3)[i % 3]
+    if k == 1:
+      z = truth[0:3] + rng.normal(size=3) * 0.1
+    elif k == 2:
+      z = np.array([np.linalg.norm(truth[0:3] - np.array(ANCHOR))]) + rng.normal(size=1) * 0.2
+    else:
+      z = truth[3:6] + rng.normal(size=3) * 0.3
+    est.append(f.predict_and_update_batch(t, k, np.array([z]), np.array([K9.obs_noise[k]])))
+    kinds.append(k); zs.append(np.concatenate([z, np.zeros(3 - len(z))]))
+  xs_s, Ps_s = f.rts_smooth(copy.deepcopy(est), norm_quats=False)
+  np.savez_compressed(os.path.join(GOLD, "kinematic9_stream.npz"), kinds=np.array(kinds), zs=np.array(zs),
+                      ts=np.array([e[4] for e in est]), xk_km1=np.array([e[0] for e in est]), xk_k=np.array([e[1] for e in est]),
+                      Pk_km1=np.array([e[2] for e in est]), Pk_k=np.array([e[3] for e in est]),
+                      ys=np.array([np.concatenate([np.ravel(e[6][0]), np.zeros(3 - len(np.ravel(e[6][0])))]) for e in est]),
+                      xs_smooth=xs_s, Ps_smooth=Ps_s)
+
+
 def maha_goldens():
   """Gate DECISIONS of the reference's maha_test (ekf_sym.py:626-649; threshold = chi2_ppf(0.95, Z) from the
   reference's lookup table) on live ECEF_POS observations with and without gross outliers."""
@@ -245,5 +278,6 @@ if __name__ == "__main__":
   live_stream()
   rts_goldens()
   maha_goldens()
+  kinematic9_goldens()
   for fn in sorted(os.listdir(GOLD)):
     print(fn, os.path.getsize(os.path.join(GOLD, fn)))

@@ -23,7 +23,17 @@ from rednose_amd.codegen import tuning
 from rednose_amd.codegen.lower import Block, vector_names
 from rednose_amd.codegen.emit_common import SMat, term, sum_terms
 
-G_LANES = 32
+
+def group_lanes(spec):
+  """Lanes per filter in the matrix phase: one lane per row/column of P, groups packed back to back."""
+  return 32 if filters_per_wave(spec) == 2 else spec.dim_err     # two groups: one per 32-lane half (fewest LDS conflicts)
+
+
+def filters_per_wave(spec):
+  """Filters whose covariance algebra one wavefront does at a time (64 // dim_err, e.g. 3 for 21 error states:
+  63 of 64 lanes busy instead of 42 with two 32-lane groups)."""
+  fpw = tuning.current().wide_fpw
+  return fpw if fpw else max(2, 64 // spec.dim_err)
 
 
 def _ind(lines, n=2):
@@ -35,8 +45,10 @@ def _odd(n):
   return n if n & 1 else n + 1
 
 
-def tile_filters():
-  return tuning.current().wide_ft
+def tile_filters(spec):
+  """Filters per wavefront tile: the tuning value rounded up to whole groups."""
+  fpw = filters_per_wave(spec)
+  return -(-tuning.current().wide_ft // fpw) * fpw
 
 
 class Layout:
@@ -228,7 +240,9 @@ def device_functions(spec):
 def kernels(spec):
   D, E = spec.dim_x, spec.dim_err
   EE = E * E
-  FT = tile_filters()
+  FT = tile_filters(spec)
+  FPW = filters_per_wave(spec)
+  GL = group_lanes(spec)
   fn_text, lay = device_functions(spec)
   out = [f"// ---- family W, three-phase step kernels (tile of {FT} filters per wavefront, slot = {lay.SLOT} doubles) ----",
          f"constexpr int FT2 = {FT};", f"constexpr int SLOT = {lay.SLOT};", fn_text]
@@ -250,17 +264,20 @@ def kernels(spec):
     A(f"    {sig_obs}const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,")
     A(f"    const int norm_quats{flags_arg}) {{")
     DB = 1 if tune.wide_db else 0
-    A(f"  __shared__ __attribute__((aligned(16))) double s_P[{1 + DB}][2 * {EE}];     // double buffer: pair p computes, pair p+1 lands")
+    ODD = (FPW * EE) % 2 == 1 or (FT * EE) % 2 == 1       # can a group's record start on an odd double?
+    PBUF = (FPW * EE + (3 if ODD else 1)) // 2 * 2      # one slack double for the shifted image, whole 16-byte vectors
+    CPIN = "rn::async_copy_g2l_any" if ODD else "rn::async_copy_g2l"
+    A(f"  __shared__ __attribute__((aligned(16))) double s_P[{1 + DB}][{PBUF}];     // double buffer: group p computes, group p+1 lands")
     A(f"  __shared__ __attribute__((aligned(16))) double s_x[FT2 * {D} + 2];")
     if upd:
       A(f"  __shared__ __attribute__((aligned(16))) double s_z[FT2 * {Z} + 2];")
-      A(f"  __shared__ __attribute__((aligned(16))) double s_G[2 * {Z * E}];")
-      A(f"  __shared__ __attribute__((aligned(16))) double s_K[2 * {Z * E}];")
+      A(f"  __shared__ __attribute__((aligned(16))) double s_G[{FPW} * {Z * E}];")
+      A(f"  __shared__ __attribute__((aligned(16))) double s_K[{FPW} * {Z * E}];")
     A("  __shared__ __attribute__((aligned(16))) double s_sl[FT2 * SLOT];")
     A("  const int lane = threadIdx.x;")
-    A(f"  const int g = lane / {G_LANES};")
-    A(f"  const int c = lane % {G_LANES};")
-    A(f"  const bool act = c < {E};")
+    A(f"  const int g = lane / {GL};")
+    A(f"  const int c = lane % {GL};")
+    A(f"  const bool act = c < {E} && g < {FPW};")
     A("  const int cc = act ? c : 0;")
     A(f"  double qcol[{E}];                          // column cc of Q, resident for the whole launch")
     A("#pragma unroll")
@@ -277,7 +294,7 @@ def kernels(spec):
     if upd:
       A(f"    rn::copy_g2l<FT2 * {Z}>(gz + base * {Z}, cnt * {Z}, s_z, lane);")
     if DB:
-      A(f"    rn::async_copy_g2l<2 * {EE}>(gP + base * {EE}, (cnt < 2 ? cnt : 2) * {EE}, s_P[0], lane);")
+      A(f"    {CPIN}<{PBUF}>(gP + base * {EE}, (cnt < {FPW} ? cnt : {FPW}) * {EE}, s_P[0], lane);")
     A("    rn::wave_lds_sync();")
     A("    if (lane < cnt) {")
     A("      double* sl = s_sl + lane * SLOT;")
@@ -291,27 +308,32 @@ def kernels(spec):
       A(f"      scal_obs_{k.kind}(sl, s_z + lane * {Z});")
     A("    }")
     A("    rn::wave_lds_sync();")
-    A("    // ---------------- phase 2: 32-lane group per filter, covariance algebra ------------------------")
-    A("    const int npairs = (cnt + 1) >> 1;")
-    A("    for (int p = 0; p < npairs; p++) {")
-    A("      const int pcnt = (cnt - 2 * p) < 2 ? (cnt - 2 * p) : 2;")
+    A(f"    // ---------------- phase 2: {GL}-lane group per filter, {FPW} filters at a time, covariance algebra ----------")
+    A(f"    const int ngroups = (cnt + {FPW - 1}) / {FPW};")
+    A("    for (int p = 0; p < ngroups; p++) {")
+    A(f"      const int pcnt = (cnt - {FPW} * p) < {FPW} ? (cnt - {FPW} * p) : {FPW};")
+    A(f"      double* gPp = gP + (base + {FPW} * p) * {EE};")
+    A("      // a group record may start on an odd double (odd dim_err^2 x odd group index): the LDS image is then shifted")
+    A("      // by one double so that the 16-byte transfers stay aligned on both sides")
+    A("      const int sh = rn::odd_start(gPp);" if ODD else "      constexpr int sh = 0;                    // records of this model always start 16-byte aligned")
     if DB:
-      A("      double* sPc = s_P[p & 1];")
-      A("      rn::async_wait();                        // pair p has landed (issued one iteration ago)")
+      A("      double* sPb = s_P[p & 1];")
+      A("      rn::async_wait();                        // group p has landed (issued one iteration ago)")
       A("      rn::wave_lds_sync();")
-      A(f"      if (p + 1 < npairs) rn::async_copy_g2l<2 * {EE}>(gP + (base + 2 * (p + 1)) * {EE}, ((cnt - 2 * (p + 1)) < 2 ? (cnt - 2 * (p + 1)) : 2) * {EE}, s_P[(p + 1) & 1], lane);")
+      A(f"      if (p + 1 < ngroups) {CPIN}<{PBUF}>(gP + (base + {FPW} * (p + 1)) * {EE}, ((cnt - {FPW} * (p + 1)) < {FPW} ? (cnt - {FPW} * (p + 1)) : {FPW}) * {EE}, s_P[(p + 1) & 1], lane);")
     else:
-      A("      double* sPc = s_P[0];                   // single buffer: the co-resident wave hides the HBM latency")
-      A(f"      rn::async_copy_g2l<2 * {EE}>(gP + (base + 2 * p) * {EE}, pcnt * {EE}, sPc, lane);")
+      A("      double* sPb = s_P[0];                   // single buffer: the co-resident wave hides the HBM latency")
+      A(f"      {CPIN}<{PBUF}>(gPp, pcnt * {EE}, sPb, lane);")
       A("      rn::async_wait();")
       A("      rn::wave_lds_sync();")
+    A("      double* sPc = sPb + sh;")
     A("      const int gg = g < pcnt ? g : 0;")
     A("      const bool on = act && g < pcnt;")
-    A("      double* sl = s_sl + (2 * p + gg) * SLOT;")
+    A(f"      double* sl = s_sl + ({FPW} * p + gg) * SLOT;")
     A(f"      if (do_pred) mat_predict(sPc + gg * {EE}, qcol, sl, cc, on);")
     if upd:
-      A(f"      mat_update_{k.kind}(sPc + gg * {EE}, r_per_filter ? gR + (base + 2 * p + gg) * {ZZ} : gR, sl, sl, s_G + gg * {Z * E}, s_K + gg * {Z * E}, cc, on);")
-    A(f"      rn::copy_l2g<2 * {EE}>(gP + (base + 2 * p) * {EE}, pcnt * {EE}, sPc, lane);")
+      A(f"      mat_update_{k.kind}(sPc + gg * {EE}, r_per_filter ? gR + (base + {FPW} * p + gg) * {ZZ} : gR, sl, sl, s_G + gg * {Z * E}, s_K + gg * {Z * E}, cc, on);")
+    A(f"      rn::copy_l2g_any<{PBUF}>(gPp, pcnt * {EE}, sPb, sh, lane);" if ODD else f"      rn::copy_l2g<{PBUF}>(gPp, pcnt * {EE}, sPb, lane);")
     A("      rn::wave_lds_sync();")
     A("    }")
     A("    // ---------------- phase 3: lane l = filter l, inject the error state, write x / y / flags ---------")
@@ -345,7 +367,9 @@ def maha_kernels(spec):
   """Standalone Mahalanobis distance (reference: EKF_sym.maha_test, ekf_sym.py:626-649): d2 per filter, state untouched."""
   D, E = spec.dim_x, spec.dim_err
   EE = E * E
-  FT = tile_filters()
+  FT = tile_filters(spec)
+  FPW = filters_per_wave(spec)
+  GL = group_lanes(spec)
   obs = {k.kind: _lowered_obs(spec, k) for k in spec.kinds}
   _, _, _, f_vars = _lowered_predict(spec)
   lay = Layout(spec, f_vars, {kk: v[3] for kk, v in obs.items()})
@@ -353,6 +377,7 @@ def maha_kernels(spec):
   for k in spec.kinds:
     Z = k.zdim
     ZZ = Z * Z
+    PBUF = (FPW * EE + 3) // 2 * 2
     _, _, He, he_vars = obs[k.kind]
     Hs = _slotted(He, he_vars, lay.OFF_HE)
     b = [f"double col[{E}], R[{ZZ}];", "#pragma unroll", f"for (int kq = 0; kq < {E}; kq++) col[kq] = sP[kq * {E} + cc];",
@@ -375,15 +400,15 @@ def maha_kernels(spec):
 __global__ __launch_bounds__(64) void k_maha_{k.kind}(const double* __restrict__ gx, const double* __restrict__ gP,
     const double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const int64_t n,
     double* __restrict__ d2) {{
-  __shared__ __attribute__((aligned(16))) double s_P[2 * {EE}];
+  __shared__ __attribute__((aligned(16))) double s_P[{PBUF}];
   __shared__ __attribute__((aligned(16))) double s_x[FT2 * {D} + 2];
   __shared__ __attribute__((aligned(16))) double s_z[FT2 * {Z} + 2];
-  __shared__ __attribute__((aligned(16))) double s_G[2 * {Z * E}];
+  __shared__ __attribute__((aligned(16))) double s_G[{FPW} * {Z * E}];
   __shared__ __attribute__((aligned(16))) double s_sl[FT2 * SLOT];
   const int lane = threadIdx.x;
-  const int g = lane / {G_LANES};
-  const int c = lane % {G_LANES};
-  const bool act = c < {E};
+  const int g = lane / {GL};
+  const int c = lane % {GL};
+  const bool act = c < {E} && g < {FPW};
   const int cc = act ? c : 0;
   const int64_t tiles = (n + FT2 - 1) / FT2;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
@@ -398,15 +423,18 @@ __global__ __launch_bounds__(64) void k_maha_{k.kind}(const double* __restrict__
       scal_obs_{k.kind}(sl, s_z + lane * {Z});
     }}
     rn::wave_lds_sync();
-    const int npairs = (cnt + 1) >> 1;
-    for (int p = 0; p < npairs; p++) {{
-      const int pcnt = (cnt - 2 * p) < 2 ? (cnt - 2 * p) : 2;
-      rn::copy_g2l<2 * {EE}>(gP + (base + 2 * p) * {EE}, pcnt * {EE}, s_P, lane);
+    const int ngroups = (cnt + {FPW - 1}) / {FPW};
+    for (int p = 0; p < ngroups; p++) {{
+      const int pcnt = (cnt - {FPW} * p) < {FPW} ? (cnt - {FPW} * p) : {FPW};
+      const double* gPp = gP + (base + {FPW} * p) * {EE};
+      const int sh = {"rn::odd_start(gPp)" if (FPW * EE) % 2 or (FT * EE) % 2 else "0"};
+      rn::async_copy_g2l_any<{PBUF}>(gPp, pcnt * {EE}, s_P, lane);
+      rn::async_wait();
       rn::wave_lds_sync();
       const int gg = g < pcnt ? g : 0;
-      const double d = mat_maha_{k.kind}(s_P + gg * {EE}, r_per_filter ? gR + (base + 2 * p + gg) * {ZZ} : gR, s_sl + (2 * p + gg) * SLOT,
+      const double d = mat_maha_{k.kind}(s_P + sh + gg * {EE}, r_per_filter ? gR + (base + {FPW} * p + gg) * {ZZ} : gR, s_sl + ({FPW} * p + gg) * SLOT,
                                   s_G + gg * {Z * E}, cc, act && g < pcnt);
-      if (c == 0 && g < pcnt) d2[base + 2 * p + g] = d;
+      if (c == 0 && g < pcnt) d2[base + {FPW} * p + g] = d;
       rn::wave_lds_sync();
     }}
   }}

@@ -11,6 +11,8 @@ environment variable RN_TUNE, e.g.  RN_TUNE="wide_ft=8,wide_lb=2" python bench.p
                          spills 64-172 VGPRs to scratch: 87-138 us (0 = unconstrained, 1 wave per SIMD, 47 us)
   wide_db       1        double-buffered asynchronous P prefetch; 0 = single buffer (only sensible with wide_lb=2)
   wide_inline   1        0 = phase functions __noinline__: each fits 256 registers but pays scratch frames: 237 us
+  wide_fpw      0        filters per wavefront in the matrix phase: 0 = 64 // dim_err (dim_err-lane groups when that is > 2, e.g. 7 filters
+                         for 9 error states; live's 22 error states fit twice: two 32-lane groups); 2 = always two groups
   small_waves   0        amdgpu_waves_per_eu(n, n) on the lane-per-filter step kernels: 1 -> k6 35 us/launch vs 9.5 us
   small_lpf     1        lanes per filter in the family-S step kernels: 2 = lane PAIR per filter (emit_small2.py: half the
                          rows per lane, DPP exchanges, 2 waves per SIMD): k6 9.8-10.0 us/launch vs 9.4 us -- parity-green but
@@ -27,6 +29,7 @@ class Tuning:
   wide_lb: int = 0
   wide_db: int = 1
   wide_inline: int = 1
+  wide_fpw: int = 0
   small_waves: int = 0
   small_lpf: int = 1
 

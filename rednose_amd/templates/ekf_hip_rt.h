@@ -289,6 +289,26 @@ __device__ __forceinline__ void async_copy_g2l(const double* __restrict__ g, int
   if ((nd & 1) && lane == 0) lds[nd - 1] = g[nd - 1];
 }
 
+// Records that may start on an odd double (8-byte but not 16-byte aligned): the LDS image is shifted by `sh` = 0/1
+// doubles so that record element i lives at lds[sh + i] and every 16-byte transfer is aligned on both sides.  The
+// load starts one double early (the previous record's last element, always inside the same allocation); the store
+// writes the odd head and tail elements as scalars and never touches a neighbour's element.
+__device__ __forceinline__ int odd_start(const double* g) {
+  return (int)(((uintptr_t)g >> 3) & 1);
+}
+
+template <int MAXD>
+__device__ __forceinline__ void async_copy_g2l_any(const double* __restrict__ g, int nd, double* lds, int lane) {
+  const int sh = odd_start(g);
+  async_copy_g2l<MAXD>(g - sh, nd + sh, lds, lane);
+}
+
+template <int MAXD>
+__device__ __forceinline__ void copy_l2g_any(double* __restrict__ g, int nd, const double* lds, int sh, int lane) {
+  if (sh && lane == 0 && nd > 0) g[0] = lds[1];
+  copy_l2g<MAXD>(g + sh, nd - sh, lds + 2 * sh, lane);
+}
+
 __device__ __forceinline__ void async_wait() {
   __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
 }

@@ -1,0 +1,139 @@
+"""GPU parity for a mid-size filter (kinematic9: 9 error states, kernel family W with 7 filters per wavefront and
+odd-sized covariance records) against the golden stream produced by the reference's numpy path
+(tests/golden/kinematic9_stream.npz, oracle/make_golden.py) and against the oracle on random batches.
+Tolerances: single calls rtol 1e-12 (floor 1e-14 x row max); free-running streams 1e-9."""
+import numpy as np
+import pytest
+
+from conftest import assert_close, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+  import torch
+  assert torch.cuda.is_available()
+  from examples import ensure_generated
+  from examples.kinematic9_kf import Kinematic9Kalman
+  return torch, ensure_generated(["kinematic9"]), Kinematic9Kalman
+
+
+def _filter(env, n):
+  torch, gen, K9 = env
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  return BatchedEKF(gen, "kinematic9", K9.Q, K9.initial_x, np.diag(K9.initial_P_diag), 9, 9, batch=n)
+
+
+def _spd(rng, n, E):
+  A = rng.normal(size=(n, E, E)) * 0.3
+  return np.eye(E)[None] + A @ A.transpose(0, 2, 1)
+
+
+@pytest.mark.parametrize("n", [1, 6, 7, 8, 22, 500])
+def test_every_kind_vs_oracle_strict(env, n):
+  """Random states, all three kinds, fused and split launches; tiles of 21 filters in groups of 7 -> the sizes cover a
+  single filter, a partial group, a full group, group + 1, tile + 1 and many tiles with a ragged tail."""
+  torch, gen, K9 = env
+  from oracle_lib import OracleLib
+  o = OracleLib("kinematic9")
+  rng = np.random.default_rng(n)
+  x0 = rng.normal(size=(n, 9)); P0 = _spd(rng, n, 9)
+  f = _filter(env, n)
+  for k in (1, 2, 3):
+    Z = o.zdim(k)
+    R = K9.obs_noise[k]
+    for fused in (True, False):
+      z = rng.normal(size=(n, Z)) * 3
+      f.init_state(x0, P0, 0.0)
+      xr, Pr, zr = x0.copy(), P0.copy(), z.copy()
+      o.batch_step(k, xr, Pr, zr, R, K9.Q, 0.03)
+      if fused:
+        y = f.predict_and_update_batch(0.03, k, z.copy(), R)
+      else:
+        f.predict(0.03)
+        y = f.update(k, z.copy(), R)
+      torch.cuda.synchronize()
+      what = f"kind {k} n={n} fused={fused}"
+      assert_close(f.state(), xr, what=what + " x")
+      assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1), what=what + " P")
+      assert_close(y.cpu().numpy(), zr, atol=1e-14 * np.abs(z).max(), what=what + " y")
+
+
+def test_per_filter_R_and_dt(env):
+  torch, gen, K9 = env
+  from oracle_lib import OracleLib
+  o = OracleLib("kinematic9")
+  n = 45
+  rng = np.random.default_rng(7)
+  x0 = rng.normal(size=(n, 9)); P0 = _spd(rng, n, 9)
+  R = _spd(rng, n, 3) * 0.05
+  t0 = rng.uniform(0.0, 0.02, size=n)
+  z = rng.normal(size=(n, 3))
+  f = _filter(env, n)
+  f.init_state(x0, P0, t0)
+  y = f.predict_and_update_batch(0.05, 3, z.copy(), R)
+  torch.cuda.synchronize()
+  for i in range(n):
+    xi, Pi, zi = x0[i:i + 1].copy(), P0[i:i + 1].copy(), z[i:i + 1].copy()
+    o.batch_step(3, xi, Pi, zi, R[i], K9.Q, 0.05 - t0[i])
+    assert_close(f.state()[i:i + 1], xi, what=f"x[{i}]")
+    assert_close(f.covs()[i].reshape(1, -1), Pi.reshape(1, -1), what=f"P[{i}]")
+    assert_close(y.cpu().numpy()[i:i + 1], zi, atol=1e-14 * np.abs(z).max())
+
+
+def test_stream_and_smoother_vs_reference(env):
+  """Step-granular stream, fused run and RTS smoother against the reference's own numpy filter / rts_smooth."""
+  torch, gen, K9 = env
+  g = golden("kinematic9_stream.npz")
+  n = 10
+  kinds, ts = g["kinds"].astype(np.int32), g["ts"]
+  T = len(kinds)
+  zs = np.tile(g["zs"][:, None, :], (1, n, 1))
+  Rs = {k: K9.obs_noise[k] for k in (1, 2, 3)}
+  s = _filter(env, n)
+  for t in range(T):
+    k = int(kinds[t]); Z = Rs[k].shape[0]
+    y = s.predict_and_update_batch(float(ts[t]), k, zs[t, :, :Z].copy(), Rs[k])
+    for j in (0, n - 1):
+      assert_close(s.state()[j], g["xk_k"][t], rtol=1e-9, floor=1e-11, what=f"stream x t={t}")
+      assert_close(s.covs()[j].reshape(1, -1), g["Pk_k"][t].reshape(1, -1), rtol=1e-9, floor=1e-11, what=f"stream P t={t}")
+      assert_close(y.cpu().numpy()[j], g["ys"][t, :Z], rtol=1e-9, atol=1e-11, what=f"stream y t={t}")
+  f = _filter(env, n)
+  ys, tx, tP, _ = f.run(ts, kinds, zs.copy(), Rs, trace=True)
+  torch.cuda.synchronize()
+  X, P = tx.cpu().numpy(), tP.cpu().numpy()
+  for j in (0, n - 1):
+    assert_close(X[:, j], g["xk_k"], rtol=1e-9, floor=1e-11, what="fused run x")
+    assert_close(P[:, j].reshape(T, -1), g["Pk_k"].reshape(T, -1), rtol=1e-9, floor=1e-11, what="fused run P")
+  xs, Ps = f.rts_smooth(tx, tP, ts, norm_quats=False)
+  torch.cuda.synchronize()
+  xs, Ps = xs.cpu().numpy(), Ps.cpu().numpy()
+  for j in (0, n - 1):
+    assert_close(xs[:, j], g["xs_smooth"], rtol=1e-8, floor=1e-10, what="smoothed x")
+    assert_close(Ps[:, j].reshape(T, -1), g["Ps_smooth"].reshape(T, -1), rtol=1e-7, floor=1e-9, what="smoothed P")
+
+
+def test_maha_distance_vs_numpy(env):
+  torch, gen, K9 = env
+  from oracle_lib import OracleLib
+  o = OracleLib("kinematic9")
+  n = 30
+  rng = np.random.default_rng(11)
+  x0 = rng.normal(size=(n, 9)); P0 = _spd(rng, n, 9)
+  f = _filter(env, n)
+  f.init_state(x0, P0, 0.0)
+  for k in (1, 2, 3):
+    Z = o.zdim(k)
+    R = K9.obs_noise[k]
+    z = rng.normal(size=(n, Z)) * 2
+    d2 = f.maha_dist(k, z, R).cpu().numpy()
+    want = np.zeros(n)
+    for i in range(n):
+      h = np.zeros(Z); H = np.zeros(Z * 9)
+      o.call(f"h_{k}", x0[i], np.zeros(1), h); o.call(f"H_{k}", x0[i], np.zeros(1), H)
+      H = H.reshape(Z, 9)
+      y = z[i] - h
+      want[i] = y @ np.linalg.solve(H @ P0[i] @ H.T + R, y)
+    assert_close(d2, want, rtol=1e-11, what=f"maha kind {k}")
+  assert np.array_equal(f.state(), x0)
