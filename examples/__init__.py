@@ -5,7 +5,7 @@ GENERATED_DIR plays the role of the reference's examples/generated/ (produced th
 """
 import os
 
-GENERATED_DIR = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', 'generated'))
+GENERATED_DIR = os.path.abspath(os.environ.get("RN_GEN_DIR") or os.path.join(os.path.dirname(__file__), '..', 'generated'))
 
 
 def model_table():

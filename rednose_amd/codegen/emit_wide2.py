@@ -116,6 +116,58 @@ def _slotted(smat, var_list, off):
   return m
 
 
+def _lean_update(k, Hs, lay, E, rows_in_regs=False):
+  """Update with the covariance rows left in LDS: G / Gt read only the columns He touches, the Joseph correction
+  Dm = K R - B He^T is formed from Gt - K (He P He^T) (the same quantity, B = P - K G never materialised in registers),
+  and ONE rolled pass rewrites the lane's row in place:  P'[cc, j] = (P[cc, j] - sum_z K_z G[z, j]) + sum_z Dm_z K[j, z].
+  Live registers: a few dozen, so two or more wavefronts fit per SIMD."""
+  Z = k.zdim
+  U = tuning.current().wide_unroll
+  used = sorted({kk for zi in range(Z) for kk, _ in Hs.row_nz(zi)})
+  b = [f"double R[{Z * Z}];", f"double* pr = sP + cc * {E};"]
+  if rows_in_regs:
+    b += [f"double row[{E}];", "#pragma unroll", f"for (int j = 0; j < {E}; j++) row[j] = pr[j];"]
+    b += [f"const double col_{kk} = sP[{kk} * {E} + cc], row_{kk} = row[{kk}];" for kk in used]
+  else:
+    b += [f"const double col_{kk} = sP[{kk} * {E} + cc], row_{kk} = pr[{kk}];" for kk in used]
+  b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) R[i] = gR[i];"]
+  for zi in range(Z):
+    nz = Hs.row_nz(zi)
+    b.append(f"const double G_{zi} = {sum_terms(term(cf, f'col_{kk}') for kk, cf in nz)};")
+    b.append(f"const double Gt_{zi} = {sum_terms(term(cf, f'row_{kk}') for kk, cf in nz)};")
+  b.append("if (act) { " + " ".join(f"sG[{zi} * {E} + cc] = G_{zi};" for zi in range(Z)) + " }")
+  b.append("rn::wave_lds_sync();")
+  b.append(f"double HPH[{Z * Z}], Rl[{Z * Z}], S[{Z * Z}], L[{Z * Z}], iL[{Z}];")
+  for zi in range(Z):
+    for w in range(Z):
+      b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))};")
+  b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}", f"rn::spd_factor<{Z}>(S, L, iL);",
+        "int gated = 0;"]
+  if k.maha_test:
+    b += ["{", f"  double v[{Z}] = {{{', '.join(f'sl[{lay.OFF_Y + i}]' for i in range(Z))}}};", f"  rn::spd_forward<{Z}>(L, iL, v);",
+          "  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";", f"  if (d2 > {k.maha_thresh!r}) {{", "    gated = 1;",
+          "#pragma unroll", f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}",
+          f"    rn::spd_factor<{Z}>(S, L, iL);", "  }", "}"]
+  b.append(f"double kk[{Z}] = {{{', '.join(f'Gt_{zi}' for zi in range(Z))}}};")
+  b.append(f"rn::spd_solve<{Z}>(L, iL, kk);")
+  b.append("const double dxc = " + " + ".join(f"kk[{zi}]*sl[{lay.OFF_Y + zi}]" for zi in range(Z)) + ";")
+  for zi in range(Z):
+    c = f"Gt_{zi} - (" + " + ".join(f"kk[{w}]*HPH[{w * Z + zi}]" for w in range(Z)) + ")"
+    kr = " + ".join(f"kk[{w}]*Rl[{w * Z + zi}]" for w in range(Z))
+    b.append(f"const double Dm_{zi} = ({kr}) - ({c});")
+  b.append("if (act) { " + " ".join(f"sK[{zi} * {E} + cc] = kk[{zi}];" for zi in range(Z)) + f" sw[{lay.OFF_DX} + cc] = dxc; if (cc == 0) sw[{lay.OFF_FL}] = (double)gated; }}")
+  b.append("rn::wave_lds_sync();")
+  if rows_in_regs:
+    b += ["if (act) {", "#pragma unroll", f"  for (int j = 0; j < {E}; j++) {{",
+          "    const double bj = row[j] - (" + " + ".join(f"kk[{zi}]*sG[{zi * E} + j]" for zi in range(Z)) + ");",
+          "    pr[j] = bj + (" + " + ".join(f"Dm_{zi}*sK[{zi * E} + j]" for zi in range(Z)) + ");", "  }", "}", "rn::wave_lds_sync();"]
+    return b
+  b += ["if (act) {", f"#pragma unroll {U}", f"  for (int j = 0; j < {E}; j++) {{",
+        "    const double bj = pr[j] - (" + " + ".join(f"kk[{zi}]*sG[{zi * E} + j]" for zi in range(Z)) + ");",
+        "    pr[j] = bj + (" + " + ".join(f"Dm_{zi}*sK[{zi * E} + j]" for zi in range(Z)) + ");", "  }", "}", "rn::wave_lds_sync();"]
+  return b
+
+
 def device_functions(spec):
   D, E = spec.dim_x, spec.dim_err
   INL = "__forceinline__" if tuning.current().wide_inline else "__noinline__"
@@ -180,17 +232,32 @@ def device_functions(spec):
 
   # ---- phase 2: predict, matrix part (P in sP -> P' in sP) ------------------------------------------------
   Fs = _slotted(F, f_vars, lay.OFF_F)
-  b = [f"const double dt = sl[{lay.OFF_DT}];", f"double row[{E}], a[{E}], col[{E}];", "#pragma unroll",
-       f"for (int j = 0; j < {E}; j++) row[j] = sP[cc * {E} + j];"]
-  for i in range(E):
-    b.append(f"a[{i}] = {sum_terms(term(cf, f'row[{kk}]') for kk, cf in Fs.row_nz(i))};")
-  b += ["if (act) {", "#pragma unroll", f"  for (int i = 0; i < {E}; i++) sP[cc * {E} + i] = a[i];", "}", "rn::wave_lds_sync();",
-        "#pragma unroll", f"for (int k = 0; k < {E}; k++) a[k] = sP[k * {E} + cc];"]
-  for i in range(E):
-    b.append(f"col[{i}] = {sum_terms(term(cf, f'a[{kk}]') for kk, cf in Fs.row_nz(i))} + dt*qcol[{i}];")
-  b += ["rn::wave_lds_sync();", "if (act) {", "#pragma unroll", f"  for (int k = 0; k < {E}; k++) sP[k * {E} + cc] = col[k];", "}",
-        "rn::wave_lds_sync();"]
-  out.append("\n".join([f"__device__ {INL} void mat_predict(double* sP, const double (&qcol)[{E}], const double* sl, const int cc, const bool act) {{"]
+  lean = tuning.current().wide_lean
+  lean_p = lean == 1      # predict through LDS only in the fully lean variant
+  if lean_p:
+    # rows, then columns, pass through ONE register array; every result goes straight back to LDS (in place: the lane's
+    # own row / column is in registers, other lanes' are untouched), so nothing but the array stays live
+    b = [f"const double dt = sl[{lay.OFF_DT}];", f"double v[{E}];", "if (act) {", "#pragma unroll",
+         f"  for (int j = 0; j < {E}; j++) v[j] = sP[cc * {E} + j];"]
+    for i in range(E):
+      b.append(f"  sP[cc * {E} + {i}] = {sum_terms(term(cf, f'v[{kk}]') for kk, cf in Fs.row_nz(i))};")
+    b += ["}", "rn::wave_lds_sync();", "if (act) {", "#pragma unroll", f"  for (int k = 0; k < {E}; k++) v[k] = sP[k * {E} + cc];"]
+    for i in range(E):
+      b.append(f"  sP[{i} * {E} + cc] = {sum_terms(term(cf, f'v[{kk}]') for kk, cf in Fs.row_nz(i))} + dt*sQ[{i} * {E} + cc];")
+    b += ["}", "rn::wave_lds_sync();"]
+  else:
+    b = [f"const double dt = sl[{lay.OFF_DT}];", f"double row[{E}], a[{E}], col[{E}];", "#pragma unroll",
+         f"for (int j = 0; j < {E}; j++) row[j] = sP[cc * {E} + j];"]
+    for i in range(E):
+      b.append(f"a[{i}] = {sum_terms(term(cf, f'row[{kk}]') for kk, cf in Fs.row_nz(i))};")
+    b += ["if (act) {", "#pragma unroll", f"  for (int i = 0; i < {E}; i++) sP[cc * {E} + i] = a[i];", "}", "rn::wave_lds_sync();",
+          "#pragma unroll", f"for (int k = 0; k < {E}; k++) a[k] = sP[k * {E} + cc];"]
+    for i in range(E):
+      b.append(f"col[{i}] = {sum_terms(term(cf, f'a[{kk}]') for kk, cf in Fs.row_nz(i))} + dt*qcol[{i}];")
+    b += ["rn::wave_lds_sync();", "if (act) {", "#pragma unroll", f"  for (int k = 0; k < {E}; k++) sP[k * {E} + cc] = col[k];", "}",
+          "rn::wave_lds_sync();"]
+  qarg = "const double* sQ" if lean_p else f"const double (&qcol)[{E}]"
+  out.append("\n".join([f"__device__ {INL} void mat_predict(double* sP, {qarg}, const double* sl, const int cc, const bool act) {{"]
                         + _ind(b) + ["}"]))
 
   # ---- phase 2: update, matrix part ----------------------------------------------------------------------
@@ -198,40 +265,45 @@ def device_functions(spec):
     _, _, He, he_vars = obs[k.kind]
     Hs = _slotted(He, he_vars, lay.OFF_HE)
     Z = k.zdim
-    b = [f"double row[{E}], col[{E}], R[{Z * Z}];", "#pragma unroll", f"for (int j = 0; j < {E}; j++) row[j] = sP[cc * {E} + j];",
-         "#pragma unroll", f"for (int kq = 0; kq < {E}; kq++) col[kq] = sP[kq * {E} + cc];",
-         "#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) R[i] = gR[i];", "rn::wave_lds_sync();"]
-    for zi in range(Z):
-      nz = Hs.row_nz(zi)
-      b.append(f"const double G_{zi} = {sum_terms(term(cf, f'col[{kk}]') for kk, cf in nz)};")
-      b.append(f"const double Gt_{zi} = {sum_terms(term(cf, f'row[{kk}]') for kk, cf in nz)};")
-    b.append("if (act) { " + " ".join(f"sG[{zi} * {E} + cc] = G_{zi};" for zi in range(Z)) + " }")
-    b.append("rn::wave_lds_sync();")
-    b.append(f"double HPH[{Z * Z}], Rl[{Z * Z}], S[{Z * Z}], L[{Z * Z}], iL[{Z}];")
-    for zi in range(Z):
-      for w in range(Z):
-        b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))};")
-    b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}", f"rn::spd_factor<{Z}>(S, L, iL);",
-          "int gated = 0;"]
-    if k.maha_test:
-      b += ["{", f"  double v[{Z}] = {{{', '.join(f'sl[{lay.OFF_Y + i}]' for i in range(Z))}}};", f"  rn::spd_forward<{Z}>(L, iL, v);",
-            "  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";", f"  if (d2 > {k.maha_thresh!r}) {{", "    gated = 1;",
-            "#pragma unroll", f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}",
-            f"    rn::spd_factor<{Z}>(S, L, iL);", "  }", "}"]
-    b.append(f"double kk[{Z}] = {{{', '.join(f'Gt_{zi}' for zi in range(Z))}}};")
-    b.append(f"rn::spd_solve<{Z}>(L, iL, kk);")
-    b.append("const double dxc = " + " + ".join(f"kk[{zi}]*sl[{lay.OFF_Y + zi}]" for zi in range(Z)) + ";")
-    for j in range(E):
-      b.append(f"row[{j}] -= " + " + ".join(f"kk[{zi}]*sG[{zi * E + j}]" for zi in range(Z)) + ";")
-    for zi in range(Z):
-      c = sum_terms(term(cf, f"row[{j}]") for j, cf in Hs.row_nz(zi))
-      kr = " + ".join(f"kk[{w}]*Rl[{w * Z + zi}]" for w in range(Z))
-      b.append(f"const double Dm_{zi} = ({kr}) - ({c});")
-    b.append("if (act) { " + " ".join(f"sK[{zi} * {E} + cc] = kk[{zi}];" for zi in range(Z)) + f" sw[{lay.OFF_DX} + cc] = dxc; if (cc == 0) sw[{lay.OFF_FL}] = (double)gated; }}")
-    b.append("rn::wave_lds_sync();")
-    for j in range(E):
-      b.append(f"row[{j}] += " + " + ".join(f"Dm_{zi}*sK[{zi * E + j}]" for zi in range(Z)) + ";")
-    b += ["if (act) {", "#pragma unroll", f"  for (int j = 0; j < {E}; j++) sP[cc * {E} + j] = row[j];", "}", "rn::wave_lds_sync();"]
+    if lean == 1:
+      b = _lean_update(k, Hs, lay, E)
+    elif lean == 2:
+      b = _lean_update(k, Hs, lay, E, rows_in_regs=True)
+    else:
+      b = [f"double row[{E}], R[{Z * Z}];", "#pragma unroll", f"for (int j = 0; j < {E}; j++) row[j] = sP[cc * {E} + j];"]
+      b += [f"double col[{E}];", "#pragma unroll", f"for (int kq = 0; kq < {E}; kq++) col[kq] = sP[kq * {E} + cc];"]
+      b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) R[i] = gR[i];", "rn::wave_lds_sync();"]
+      for zi in range(Z):
+        nz = Hs.row_nz(zi)
+        b.append(f"const double G_{zi} = {sum_terms(term(cf, f'col[{kk}]') for kk, cf in nz)};")
+        b.append(f"const double Gt_{zi} = {sum_terms(term(cf, f'row[{kk}]') for kk, cf in nz)};")
+      b.append("if (act) { " + " ".join(f"sG[{zi} * {E} + cc] = G_{zi};" for zi in range(Z)) + " }")
+      b.append("rn::wave_lds_sync();")
+      b.append(f"double HPH[{Z * Z}], Rl[{Z * Z}], S[{Z * Z}], L[{Z * Z}], iL[{Z}];")
+      for zi in range(Z):
+        for w in range(Z):
+          b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))};")
+      b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}", f"rn::spd_factor<{Z}>(S, L, iL);",
+            "int gated = 0;"]
+      if k.maha_test:
+        b += ["{", f"  double v[{Z}] = {{{', '.join(f'sl[{lay.OFF_Y + i}]' for i in range(Z))}}};", f"  rn::spd_forward<{Z}>(L, iL, v);",
+              "  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";", f"  if (d2 > {k.maha_thresh!r}) {{", "    gated = 1;",
+              "#pragma unroll", f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}",
+              f"    rn::spd_factor<{Z}>(S, L, iL);", "  }", "}"]
+      b.append(f"double kk[{Z}] = {{{', '.join(f'Gt_{zi}' for zi in range(Z))}}};")
+      b.append(f"rn::spd_solve<{Z}>(L, iL, kk);")
+      b.append("const double dxc = " + " + ".join(f"kk[{zi}]*sl[{lay.OFF_Y + zi}]" for zi in range(Z)) + ";")
+      for j in range(E):
+        b.append(f"row[{j}] -= " + " + ".join(f"kk[{zi}]*sG[{zi * E + j}]" for zi in range(Z)) + ";")
+      for zi in range(Z):
+        c = sum_terms(term(cf, f"row[{j}]") for j, cf in Hs.row_nz(zi))
+        kr = " + ".join(f"kk[{w}]*Rl[{w * Z + zi}]" for w in range(Z))
+        b.append(f"const double Dm_{zi} = ({kr}) - ({c});")
+      b.append("if (act) { " + " ".join(f"sK[{zi} * {E} + cc] = kk[{zi}];" for zi in range(Z)) + f" sw[{lay.OFF_DX} + cc] = dxc; if (cc == 0) sw[{lay.OFF_FL}] = (double)gated; }}")
+      b.append("rn::wave_lds_sync();")
+      for j in range(E):
+        b.append(f"row[{j}] += " + " + ".join(f"Dm_{zi}*sK[{zi * E + j}]" for zi in range(Z)) + ";")
+      b += ["if (act) {", "#pragma unroll", f"  for (int j = 0; j < {E}; j++) sP[cc * {E} + j] = row[j];", "}", "rn::wave_lds_sync();"]
     out.append("\n".join([f"__device__ {INL} void mat_update_{k.kind}(double* sP, const double* __restrict__ gR, const double* sl, double* sw, "
                           "double* sG, double* sK, const int cc, const bool act) {"] + _ind(b) + ["}"]))
   return "\n".join(out).replace("{INL}", INL), lay
@@ -279,9 +351,14 @@ def kernels(spec):
     A(f"  const int c = lane % {GL};")
     A(f"  const bool act = c < {E} && g < {FPW};")
     A("  const int cc = act ? c : 0;")
-    A(f"  double qcol[{E}];                          // column cc of Q, resident for the whole launch")
-    A("#pragma unroll")
-    A(f"  for (int i = 0; i < {E}; i++) qcol[i] = ({dop} && gQ != nullptr) ? gQ[i * {E} + cc] : 0.0;")
+    if tune.wide_lean == 1:
+      A(f"  __shared__ __attribute__((aligned(16))) double s_Q[{EE}];      // process noise, staged once per wavefront")
+      A(f"  for (int i = lane; i < {EE}; i += 64) s_Q[i] = ({dop} && gQ != nullptr) ? gQ[i] : 0.0;")
+      A("  const double* qcol = s_Q;")
+    else:
+      A(f"  double qcol[{E}];                          // column cc of Q, resident for the whole launch")
+      A("#pragma unroll")
+      A(f"  for (int i = 0; i < {E}; i++) qcol[i] = ({dop} && gQ != nullptr) ? gQ[i * {E} + cc] : 0.0;")
     A("  // predict with a uniform dt == 0 (a second observation at the same timestamp) is the identity on (x, P) for finite")
     A("  // states: F = I + dt A = I and dt Q = 0 exactly, so the covariance phase is skipped; results are unchanged.")
     A(f"  const bool do_pred = {dop} && !(gdt == nullptr && dt_scalar == 0.0);")

@@ -13,10 +13,19 @@ environment variable RN_TUNE, e.g.  RN_TUNE="wide_ft=8,wide_lb=2" python bench.p
   wide_inline   1        0 = phase functions __noinline__: each fits 256 registers but pays scratch frames: 237 us
   wide_fpw      0        filters per wavefront in the matrix phase: 0 = 64 // dim_err (dim_err-lane groups when that is > 2, e.g. 7 filters
                          for 9 error states; live's 22 error states fit twice: two 32-lane groups); 2 = always two groups
+  wide_lean     0        1 = covariance rows stay in LDS (in-place rank-Z pass, only the columns He touches are read, Q from
+                         LDS): 199-229 VGPRs instead of 256 + 84..234 AGPRs, two waves per SIMD without spills -- but live
+                         46.4 us/launch at 1 wave/SIMD and 44.4 us at 2 waves/SIMD (ft=4, lb=2, db=0; smaller tiles repeat the
+                         16-lane scalar phase more often: 7.9 M VALU instructions vs 5.4 M) against 40.0 us for the default;
+                         2 = rows in registers, lean algebra (no column array, one fused rank-Z pass): 41.3 us.  Parity-green.
+  wide_unroll   2        unroll factor of the lean in-place pass (1: 65.9 us, 4: same as 2)
   small_waves   0        amdgpu_waves_per_eu(n, n) on the lane-per-filter step kernels: 1 -> k6 35 us/launch vs 9.5 us
   small_lpf     1        lanes per filter in the family-S step kernels: 2 = lane PAIR per filter (emit_small2.py: half the
                          rows per lane, DPP exchanges, 2 waves per SIMD): k6 9.8-10.0 us/launch vs 9.4 us -- parity-green but
                          not faster, the two waves of a SIMD still move in lockstep through load / compute / store
+Also measured, not kept as a knob: delaying every other group of 8 wavefronts with s_sleep so that load / compute / store
+phases of the two halves interleave (k6: 1.0 us delay -> 9.4 us, 2.9 us -> 10.8 us, none 9.1 us): the phases are latency-,
+not bandwidth-bound, so staggering only adds the delay.
 """
 import os
 from dataclasses import dataclass, fields
@@ -30,6 +39,8 @@ class Tuning:
   wide_db: int = 1
   wide_inline: int = 1
   wide_fpw: int = 0
+  wide_lean: int = 0
+  wide_unroll: int = 2
   small_waves: int = 0
   small_lpf: int = 1
 
