@@ -42,6 +42,7 @@ MODELS = {
                     maha_test_kinds=[12]),
   "kinematic6": dict(model="examples.kinematic6_kf:Kinematic6Kalman"),
   "kinematic9": dict(model="examples.kinematic9_kf:Kinematic9Kalman"),
+  "feature": dict(model="examples.feature_kf:FeatureKalman"),
   "kinematic6_maha": dict(model="examples.kinematic6_kf:Kinematic6Kalman", rename="kinematic6_maha",
                           maha_test_kinds=[1]),
 }
@@ -125,7 +126,8 @@ def port_codegen(cfg, name, out_dir):
   for k in spec.kinds:
     lines.append(f"const static double MAHA_THRESH_{k.kind} = {k.maha_thresh!r};")
     hdr.append(f"void {name}_update_{k.kind}(double *in_x, double *in_P, double *in_z, double *in_R, double *in_ea);")
-    post.append(f"  update<{k.zdim}, 3, {int(k.maha_test)}>(in_x, in_P, h_{k.kind}, H_{k.kind}, NULL, in_z, in_R, in_ea, MAHA_THRESH_{k.kind});")
+    he = f"He_{k.kind}" if k.He_sym is not None else "NULL"
+    post.append(f"  update<{k.zdim}, 3, {int(k.maha_test)}>(in_x, in_P, h_{k.kind}, H_{k.kind}, {he}, in_z, in_R, in_ea, MAHA_THRESH_{k.kind});")
   for line in c_header.split("\n"):
     if line.startswith("void "):
       hdr.append(f"void {name}_{line[5:line.index(')') + 1]};")
@@ -141,9 +143,7 @@ def parse_generated(cpp_text):
   thresh = {int(k): float(v) for k, v in re.findall(r"MAHA_THRESH_(\d+) = ([0-9.eE+-]+);", cpp_text)}
   updates = {}
   for z, maha, k, he in re.findall(r"update<(\d+), 3, (\d+)>\(in_x, in_P, h_(\d+), H_\d+, (\w+),", cpp_text):
-    if he != "NULL":
-      raise NotImplementedError("feature-track (He) kinds are not restated in the oracle")
-    updates[int(k)] = (int(z), int(maha))
+    updates[int(k)] = (int(z), int(maha), he)
   start = cpp_text.index("/*****")
   end = cpp_text.index("#include <eigen3/Eigen/Dense>")
   return dims, thresh, updates, cpp_text[start:end]
@@ -157,9 +157,9 @@ def emit_glue(name, dims, thresh, updates, sympy_block, header_text):
   out.append(f"static const oracle_model MDL = {{ {dims['DIM']}, {dims['EDIM']}, {dims['MEDIM']}, f_fun, F_fun, err_fun, inv_err_fun, H_mod_fun }};")
   out.append(f"void {name}_predict(double *in_x, double *in_P, double *in_Q, double dt) {{ oracle_predict(&MDL, in_x, in_P, in_Q, dt); }}")
   for k in kinds:
-    z, maha = updates[k]
+    z, maha, he = updates[k]
     out.append(f"void {name}_update_{k}(double *in_x, double *in_P, double *in_z, double *in_R, double *in_ea) {{"
-               f" oracle_update(&MDL, {z}, {maha}, {thresh[k]!r}, h_{k}, H_{k}, in_x, in_P, in_z, in_R, in_ea); }}")
+               f" oracle_update(&MDL, {z}, {maha}, {thresh[k]!r}, h_{k}, H_{k}, {he}, in_x, in_P, in_z, in_R, in_ea); }}")
   # thin wrappers for the sympy routines, from the reference-format header
   for line in header_text.split("\n"):
     m = re.match(rf"void {name}_(\w+)\((.*)\);", line)
@@ -174,7 +174,7 @@ def emit_glue(name, dims, thresh, updates, sympy_block, header_text):
   out.append(f"""
 static int upd_dispatch(int kind, double *x, double *P, double *z, const double *R, double *ea) {{
   switch (kind) {{
-{chr(10).join(f"    case {k}: return oracle_update(&MDL, {updates[k][0]}, {updates[k][1]}, {thresh[k]!r}, h_{k}, H_{k}, x, P, z, R, ea);" for k in kinds)}
+{chr(10).join(f"    case {k}: return oracle_update(&MDL, {updates[k][0]}, {updates[k][1]}, {thresh[k]!r}, h_{k}, H_{k}, {updates[k][2]}, x, P, z, R, ea);" for k in kinds)}
     default: return -1;
   }}
 }}
@@ -182,11 +182,10 @@ static int upd_dispatch(int kind, double *x, double *P, double *z, const double 
  * R:(Z,Z) shared or (n,Z,Z); kind < 0 => predict only; quat_idx < 0 => no renormalisation (ekf_sym.cc:196-219) */
 void {name}_oracle_batch_step(int kind, double *x, double *P, double *z, const double *R, int r_shared,
                               const double *Q, const double *dt, int dt_shared, int64_t n, int quat_idx,
-                              unsigned char *flags, int do_predict) {{
+                              unsigned char *flags, int do_predict, const double *ea) {{
   const int D = {dims['DIM']}, E = {dims['EDIM']};
   int Z = 0;
   switch (kind) {{ {" ".join(f"case {k}: Z = {updates[k][0]}; break;" for k in kinds)} default: break; }}
-  double ea[4] = {{0}};
   #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; i++) {{
     double *xi = x + i * D, *Pi = P + i * E * E;
@@ -196,12 +195,12 @@ void {name}_oracle_batch_step(int kind, double *x, double *P, double *z, const d
     }}
     if (kind >= 0) {{
       double eal[4] = {{0}};
+      if (ea) memcpy(eal, ea + i * 3, sizeof(double) * 3);      /* extra args of feature-track kinds: (n, 3) */
       int g = upd_dispatch(kind, xi, Pi, z + i * Z, r_shared ? R : R + i * Z * Z, eal);
       if (quat_idx >= 0) oracle_normalize_quat(xi, quat_idx);
       if (flags) flags[i] = (unsigned char)g;
     }}
   }}
-  (void)ea;
 }}
 /* T steps with a shared schedule: kinds[t], dts[t]; z laid out (T, n, ZMAX), R (T, ZMAX, ZMAX) shared per step.
  * Optional trace buffers (each may be NULL): xp (T,n,D) Pp (T,n,E,E) after predict; xf, Pf after update. */
@@ -266,7 +265,7 @@ def build(name, flavour="auto", cflags=None, suffix="", verbose=True):
 def _parse_port(cpp_text):
   dims = {k: int(re.search(rf"#define {k} (\d+)", cpp_text).group(1)) for k in ("DIM", "EDIM", "MEDIM")}
   thresh = {int(k): float(v) for k, v in re.findall(r"MAHA_THRESH_(\d+) = ([0-9.eE+-]+);", cpp_text)}
-  updates = {int(k): (int(z), int(m)) for z, m, k in re.findall(r"update<(\d+), 3, (\d+)>\(in_x, in_P, h_(\d+),", cpp_text)}
+  updates = {int(k): (int(z), int(m), he) for z, m, k, he in re.findall(r"update<(\d+), 3, (\d+)>\(in_x, in_P, h_(\d+), H_\d+, (\w+),", cpp_text)}
   start = cpp_text.index("/******  sympy C99 block (port)")
   end = cpp_text.index("#include <eigen3/Eigen/Dense>")
   return dims, thresh, updates, cpp_text[start:end]

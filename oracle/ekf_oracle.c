@@ -92,6 +92,58 @@ static void fullpiv_solve(double *S, double *B, double *X, int n, int m) {
   }
 }
 
+
+/*
+ * Basis of the right null space of M (rows x cols, row-major) by Gaussian elimination with FULL pivoting -- what
+ * Eigen's FullPivLU::kernel() computes for ekf_c.c:71 (A = Hea^T.fullPivLu().kernel()): with P M Q = L U and
+ * U = [U1 U2] (U1 rank x rank upper triangular), the kernel vectors are Q [-U1^-1 U2 ; I].  ker is cols x (cols - rank),
+ * row-major; returns the kernel dimension.  Rank threshold: |pivot| <= eps * max(rows, cols) * |largest pivot|
+ * (Eigen's default).  Any basis gives the same x and P; only the projected residual y depends on the choice.
+ */
+static int fullpiv_kernel(const double *M, int rows, int cols, double *ker) {
+  double U[OR_MAXZ * OR_MAXZ];
+  int colperm[OR_MAXZ];
+  memcpy(U, M, sizeof(double) * (size_t)rows * cols);
+  for (int j = 0; j < cols; j++) colperm[j] = j;
+  int rank = 0;
+  double maxpiv = 0.0;
+  const int steps = rows < cols ? rows : cols;
+  for (int k = 0; k < steps; k++) {
+    int pr = k, pc = k;
+    double best = 0.0;
+    for (int i = k; i < rows; i++)
+      for (int j = k; j < cols; j++) {
+        double a = fabs(U[i * cols + j]);
+        if (a > best) { best = a; pr = i; pc = j; }
+      }
+    if (k == 0) maxpiv = best;
+    if (best <= 2.220446049250313e-16 * (rows > cols ? rows : cols) * maxpiv) break;
+    if (pr != k) for (int j = 0; j < cols; j++) { double t = U[k * cols + j]; U[k * cols + j] = U[pr * cols + j]; U[pr * cols + j] = t; }
+    if (pc != k) {
+      for (int i = 0; i < rows; i++) { double t = U[i * cols + k]; U[i * cols + k] = U[i * cols + pc]; U[i * cols + pc] = t; }
+      int t = colperm[k]; colperm[k] = colperm[pc]; colperm[pc] = t;
+    }
+    for (int i = k + 1; i < rows; i++) {
+      double l = U[i * cols + k] / U[k * cols + k];
+      for (int j = k; j < cols; j++) U[i * cols + j] -= l * U[k * cols + j];
+    }
+    rank++;
+  }
+  const int nk = cols - rank;
+  for (int c = 0; c < nk; c++) {
+    double v[OR_MAXZ];
+    for (int i = rank - 1; i >= 0; i--) {            /* U1 v = -U2[:, c] */
+      double acc = -U[i * cols + rank + c];
+      for (int p = i + 1; p < rank; p++) acc -= U[i * cols + p] * v[p];
+      v[i] = acc / U[i * cols + i];
+    }
+    for (int j = 0; j < cols; j++) ker[j * nk + c] = 0.0;
+    for (int i = 0; i < rank; i++) ker[colperm[i] * nk + c] = v[i];
+    ker[colperm[rank + c] * nk + c] = 1.0;
+  }
+  return nk;
+}
+
 /* ekf_c.c:8-33 */
 void oracle_predict(const oracle_model *mdl, double *in_x, double *in_P, const double *in_Q, double dt) {
   const int D = mdl->dim, E = mdl->edim, M = mdl->medim;
@@ -142,15 +194,17 @@ void oracle_predict(const oracle_model *mdl, double *in_x, double *in_P, const d
   free(nx); free(F); free(Fm); free(T); free(T2); free(P);
 }
 
-/* ekf_c.c:37-121, Hea_fun == NULL branch (no in-tree model has feature kinds) */
-int oracle_update(const oracle_model *mdl, int Z, int maha_test, double maha_thresh,
-                  oracle_hfun h_fun, oracle_hfun H_fun,
+/* ekf_c.c:37-121; Hea_fun == NULL for ordinary kinds, the EADIM (= 3, ekf_sym.py:151) extra-argument Jacobian of a
+ * feature-track kind otherwise (:66-76: residual, H and R projected on the left null space of Hea) */
+int oracle_update(const oracle_model *mdl, int ZDIM, int maha_test, double maha_thresh,
+                  oracle_hfun h_fun, oracle_hfun H_fun, oracle_hfun Hea_fun,
                   double *in_x, double *in_P, double *in_z, const double *in_R, double *in_ea) {
   const int D = mdl->dim, E = mdl->edim;
+  int Z = ZDIM;
   int gated = 0;
   double hx[OR_MAXZ] = {0};
   double y[OR_MAXZ];
-  double *H = (double *)calloc((size_t)Z * D, sizeof(double));
+  double *H = (double *)calloc((size_t)ZDIM * D, sizeof(double));
   double *Hmod = (double *)calloc((size_t)E * D, sizeof(double));
   double *Herr = (double *)malloc(sizeof(double) * (size_t)Z * E);
   double *HP = (double *)malloc(sizeof(double) * (size_t)Z * E);
@@ -168,6 +222,42 @@ int oracle_update(const oracle_model *mdl, int Z, int maha_test, double maha_thr
   H_fun(in_x, in_ea, H);                                    /* :56 */
   for (int i = 0; i < Z; i++) y[i] = in_z[i] - hx[i];       /* :60 */
   memcpy(R, in_R, sizeof(double) * (size_t)Z * Z);          /* :75 */
+  if (Hea_fun) {                                            /* :66-72 */
+    enum { EADIM = 3 };
+    double Hea[OR_MAXZ * EADIM] = {0}, HeaT[EADIM * OR_MAXZ], A[OR_MAXZ * OR_MAXZ];
+    Hea_fun(in_x, in_ea, Hea);
+    for (int i = 0; i < ZDIM; i++) for (int j = 0; j < EADIM; j++) HeaT[j * ZDIM + i] = Hea[i * EADIM + j];
+    const int nk = fullpiv_kernel(HeaT, EADIM, ZDIM, A);   /* A: ZDIM x nk */
+    double yp[OR_MAXZ], RA[OR_MAXZ * OR_MAXZ], Rp[OR_MAXZ * OR_MAXZ];
+    double *Hp = (double *)calloc((size_t)ZDIM * D, sizeof(double));
+    for (int a = 0; a < nk; a++) {                          /* y = A^T y, H = A^T H */
+      double acc = 0.0;
+      for (int i = 0; i < ZDIM; i++) acc += A[i * nk + a] * y[i];
+      yp[a] = acc;
+      for (int j = 0; j < D; j++) {
+        double h = 0.0;
+        for (int i = 0; i < ZDIM; i++) h += A[i * nk + a] * H[i * D + j];
+        Hp[a * D + j] = h;
+      }
+    }
+    for (int i = 0; i < ZDIM; i++)                          /* R = A^T R A */
+      for (int a = 0; a < nk; a++) {
+        double acc = 0.0;
+        for (int j = 0; j < ZDIM; j++) acc += R[i * ZDIM + j] * A[j * nk + a];
+        RA[i * nk + a] = acc;
+      }
+    for (int a = 0; a < nk; a++)
+      for (int b = 0; b < nk; b++) {
+        double acc = 0.0;
+        for (int i = 0; i < ZDIM; i++) acc += A[i * nk + a] * RA[i * nk + b];
+        Rp[a * nk + b] = acc;
+      }
+    Z = nk;
+    memcpy(y, yp, sizeof(double) * (size_t)Z);
+    memcpy(H, Hp, sizeof(double) * (size_t)Z * D);
+    memcpy(R, Rp, sizeof(double) * (size_t)Z * Z);
+    free(Hp);
+  }
 
   mdl->H_mod_fun(in_x, Hmod);                               /* :83 */
   mm(H, Hmod, Herr, Z, D, E);                               /* :85 H_err = H * H_mod */
@@ -231,7 +321,7 @@ int oracle_update(const oracle_model *mdl, int Z, int maha_test, double maha_thr
 
   memcpy(in_x, xn, sizeof(double) * (size_t)D);             /* :118 */
   memcpy(in_P, Pn, sizeof(double) * (size_t)E * E);         /* :119 */
-  memcpy(in_z, y, sizeof(double) * (size_t)Z);              /* :120 y written back into z */
+  memcpy(in_z, y, sizeof(double) * (size_t)Z);              /* :120 y (y.rows() entries) written back into z */
 
   free(H); free(Hmod); free(Herr); free(HP); free(HPt); free(KT); free(IKH);
   free(T); free(Pn); free(KR); free(dx); free(xn);

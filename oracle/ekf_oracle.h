@@ -26,7 +26,7 @@ void oracle_predict(const oracle_model *mdl, double *in_x, double *in_P, const d
 
 /* returns 1 when the Mahalanobis gate fired (R was inflated), else 0 */
 int oracle_update(const oracle_model *mdl, int zdim, int maha_test, double maha_thresh,
-                  oracle_hfun h_fun, oracle_hfun H_fun,
+                  oracle_hfun h_fun, oracle_hfun H_fun, oracle_hfun Hea_fun /* NULL unless a feature-track kind */,
                   double *in_x, double *in_P, double *in_z, const double *in_R, double *in_ea);
 
 void oracle_normalize_quat(double *x, int idx);

@@ -72,16 +72,17 @@ class OracleLib:
     self._fn(sym, at)(*[(_ptr(a) if isinstance(a, np.ndarray) else float(a)) for a in args])
 
   # --- oracle-only batch drivers ---
-  def batch_step(self, kind, x, P, z, R, Q, dt, quat_idx=-1, flags=None, do_predict=True):
+  def batch_step(self, kind, x, P, z, R, Q, dt, quat_idx=-1, flags=None, do_predict=True, ea=None):
     n = x.shape[0]
     R = np.ascontiguousarray(R, dtype=np.float64)
     Q = np.ascontiguousarray(Q, dtype=np.float64)
     dt = np.ascontiguousarray(np.atleast_1d(dt), dtype=np.float64)
     r_shared = int(R.ndim == 2)
     f = self._fn("oracle_batch_step", [ctypes.c_int, _dp, _dp, _dp, _dp, ctypes.c_int, _dp, _dp, ctypes.c_int,
-                                       ctypes.c_int64, ctypes.c_int, _dp, ctypes.c_int])
+                                       ctypes.c_int64, ctypes.c_int, _dp, ctypes.c_int, _dp])
+    ea = None if ea is None else np.ascontiguousarray(ea, dtype=np.float64).reshape(n, 3)
     f(int(kind), _ptr(x), _ptr(P), _ptr(z), _ptr(R), r_shared, _ptr(Q), _ptr(dt), int(dt.size == 1), n,
-      int(quat_idx), _ptr(flags), int(do_predict))
+      int(quat_idx), _ptr(flags), int(do_predict), _ptr(ea))
 
   def batch_run(self, kinds, dts, x, P, z, R, Q, quat_idx=-1, flags=None, xp=None, Pp=None, xf=None, Pf=None):
     """z: (T, n, zmax) in/out, R: (T, zmax, zmax)."""

@@ -124,6 +124,43 @@ def test_maha_gate_matches_reference_decisions():
   assert np.allclose(x[gated], g["x"][gated], rtol=0, atol=1e-6)
 
 
+def test_msckf_feature_updates_and_block_predict_vs_reference_numpy():
+  """ekf_c.c:23-26 (block predict, MEDIM < EDIM) and :66-76 (null-space projection) against the reference's numpy
+  path (ekf_sym.py:541-556, :576-591).  x and P do not depend on the null-space basis; the projected residual does
+  (SVD basis there, LU kernel here), so y is compared through its basis-independent quadratic form."""
+  g = golden("feature_stream.npz")
+  o = OracleLib("feature")
+  assert (o.D, o.E, o.M) == (15, 15, 6) and o.zdim(2) == 6
+  R = np.eye(6) * 0.01**2
+  for i in range(g["upd_x_in"].shape[0]):
+    x, P, z = g["upd_x_in"][i].copy(), g["upd_P_in"][i].copy(), g["upd_z"][i].copy()
+    o.update(2, x, P, z, R, ea=np.concatenate([g["upd_ea"][i], [0.0]]))
+    assert_close(x, g["upd_x"][i], rtol=1e-9, floor=1e-11, what=f"feature update x[{i}]")
+    assert_close(P, g["upd_P"][i], rtol=1e-8, floor=1e-10, what=f"feature update P[{i}]")
+    # R is a multiple of the identity here: for an orthonormal basis |y|^2/r is the form y^T (A^T R A)^-1 y; the LU-kernel
+    # basis A gives the same number through (A^T A)^-1
+    He = np.zeros(18); o.call("He_2", g["upd_x_in"][i].copy(), g["upd_ea"][i].copy(), He)
+    u, sv, _ = np.linalg.svd(He.reshape(6, 3)); A = u[:, 3:]
+    hx = np.zeros(6); o.call("h_2", g["upd_x_in"][i].copy(), g["upd_ea"][i].copy(), hx)
+    want = np.linalg.norm(A.T @ (g["upd_z"][i] - hx))
+    assert abs(np.linalg.norm(g["upd_y"][i]) - want) < 1e-9 * max(1.0, want)
+  Q = np.diag([0.05**2] * 3 + [0.5**2] * 3 + [0.0] * 9)
+  x, P, t_prev = None, None, None
+  for t in range(len(g["ts"])):
+    if t == 0:
+      x, P, dt = np.concatenate([[0.0, 0.0, 0.0, 1.0, 0.5, 0.0], np.zeros(9)]), np.diag([0.25] * 3 + [1.0] * 3 + [0.25] * 9), 0.0
+    else:
+      x, P, dt = g["x_after"][t - 1].copy(), g["P_after"][t - 1].copy(), g["ts"][t] - g["ts"][t - 1]
+    o.predict(x, P, Q, dt)
+    assert_close(x, g["xk_km1"][t], rtol=1e-10, floor=1e-12, what=f"predict x t={t}")
+    assert_close(P, g["Pk_km1"][t], rtol=1e-10, floor=1e-12, what=f"predict P t={t}")
+    k = int(g["kinds"][t]); Z = 3 if k == 1 else 6
+    z = g["zs"][t, :Z].copy()
+    o.update(k, x, P, z, np.eye(Z) * (0.2**2 if k == 1 else 0.01**2), ea=np.concatenate([g["eas"][t], [0.0]]))
+    assert_close(x, g["xk_k"][t], rtol=1e-9, floor=1e-11, what=f"update x t={t}")
+    assert_close(P, g["Pk_k"][t], rtol=1e-8, floor=1e-10, what=f"update P t={t}")
+
+
 def test_thresholds_match_reference_table():
   from rednose_amd.helpers.chi2_lookup import chi2_ppf
   g = golden("live_maha.npz")
@@ -136,7 +173,7 @@ def test_thresholds_match_reference_table():
 
 
 @pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not built (needs /root/reference)")
-@pytest.mark.parametrize("name", ["kinematic", "live", "kinematic6"])
+@pytest.mark.parametrize("name", ["kinematic", "live", "kinematic6", "kinematic9", "feature"])
 def test_port_flavour_equals_ref_flavour(name):
   """Our model front end (examples/ + rednose_amd.codegen.spec) must generate the same functions as the reference."""
   a, b = OracleLib(name, "ref"), OracleLib(name, "port")
@@ -148,7 +185,7 @@ def test_port_flavour_equals_ref_flavour(name):
     kinds = [3, 4, 9, 10, 12, 13, 14, 19]
   else:
     x = rng.normal(size=a.D)
-    kinds = [1]
+    kinds = {"kinematic9": [1, 2, 3], "feature": [1, 2]}.get(name, [1])
   dt = 0.037
   def both(sym, *args, shape):
     oa, ob = np.zeros(shape), np.zeros(shape)
@@ -161,9 +198,11 @@ def test_port_flavour_equals_ref_flavour(name):
   both("err_fun", x, dx, shape=a.D)
   x2 = x + rng.normal(size=a.D) * 1e-3
   both("inv_err_fun", x, x2, shape=a.E)
-  ea = np.zeros(1)
+  ea = np.array([0.3, -0.2, 7.0])       # landmark of the feature kind; ignored by kinds without extra args
   for k in kinds:
     Z = a.zdim(k)
     assert b.zdim(k) == Z
     both(f"h_{k}", x, ea, shape=Z)
     both(f"H_{k}", x, ea, shape=Z * a.D)
+    if name == "feature" and k == 2:
+      both("He_2", x, ea, shape=Z * 3)
