@@ -57,6 +57,8 @@ int live_batch_maha_12(const double *x, const double *P, const double *z, const 
 int live_batch_maha_13(const double *x, const double *P, const double *z, const double *R, int r_per_filter, const double *ea, int64_t n, double *d2, void *stream);
 int live_batch_maha_14(const double *x, const double *P, const double *z, const double *R, int r_per_filter, const double *ea, int64_t n, double *d2, void *stream);
 int live_batch_maha_19(const double *x, const double *P, const double *z, const double *R, int r_per_filter, const double *ea, int64_t n, double *d2, void *stream);
+void live_msckf_dims(int *dims);
+int live_kind_eadim(int kind);
 int live_zmax(void);
 int live_batch_run(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts, int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, double *trace_x, double *trace_P, void *stream);
 int live_batch_rts(const double *xf, const double *Pf, const double *ts, int64_t T, const double *Q, int64_t n, int norm_quats, double *xs, double *Ps, void *stream);

@@ -66,6 +66,8 @@ extern "C" {
   void RN_FN(name, kinds)(int *out);                  /* observation kinds, EKF::kinds (ekf.h:18)            */   \
   int RN_FN(name, kind_zdim)(int kind);               /* Z of a kind, -1 if unknown                          */   \
   int RN_FN(name, kind_maha)(int kind);               /* 1 if generated with the Mahalanobis gate            */   \
+  int RN_FN(name, kind_eadim)(int kind);              /* extra arguments per observation of a kind (0: `ea` ignored) */ \
+  void RN_FN(name, msckf_dims)(int *dims);            /* dim_main, dim_main_err, dim_augment, dim_augment_err, N (ekf_sym.py:57-73) */ \
   int RN_FN(name, last_error)(void);                                                                             \
   const char *RN_FN(name, last_error_string)(void);                                                              \
   void RN_FN(name, clear_error)(void);                                                                           \
@@ -91,9 +93,18 @@ extern "C" {
   int RN_FN(name, batch_rts)(const double *xf, const double *Pf, const double *ts, int64_t T, const double *Q,     \
                              int64_t n, int norm_quats, double *xs, double *Ps, void *stream);
 
+/* MSCKF models only (gen_code msckf_params): window shift of EKF_sym.augment (ekf_sym.py:365-391) on n filters, in place */
+#define RN_DECLARE_BATCH_MSCKF(name)                                                                             \
+  int RN_FN(name, batch_augment)(double *x, double *P, int64_t n, void *stream);
+
+/* feature-track kinds of an MSCKF model additionally export the reference's extra-argument Jacobian:
+ *   void {name}_He_{k}(double *state, double *ea, double *out)   -- Z x 3, ekf_sym.py:110-113; their updates project the
+ *   residual, H and R on the left null space of it (ekf_c.c:66-76) and write Z - 3 residual rows back into z */
 #define RN_DECLARE_BATCH_KIND(name, k)                                                                           \
-  /* update only.  flags (n bytes, may be NULL): bit0 = Mahalanobis gate fired (R inflated, ekf_c.c:88-94),    \
-   * bit1 = non-finite state after the update */                                                               \
+  /* update only.  ea: (n, kind_eadim) extra arguments, one row per filter (NULL when the kind takes none).    \
+   * flags (n bytes, may be NULL): bit0 = Mahalanobis gate fired (R inflated, ekf_c.c:88-94),                  \
+   * bit1 = non-finite state after the update, bit2 = null-space projection failed (rank-deficient extra-argument  \
+   * Jacobian; the measurement is ignored like in ekf_sym.py:589-591) */                                        \
   int RN_FN(name, batch_update_##k)(double *x, double *P, double *z, const double *R, int r_per_filter,          \
                                     const double *ea, int64_t n, int norm_quats, uint8_t *flags, void *stream);  \
   /* Mahalanobis distance d2 = y^T (He P He^T + R)^-1 y of an observation, nothing modified; replaces the Python-only \

@@ -307,7 +307,8 @@ __global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double*
   for k in (spec.kinds if step_kernels else []):
     Z = k.zdim
     ZZ = Z * Z
-    ea = ", gea" if k.ea_sym is not None else ""
+    # extra arguments are per observation, i.e. per filter of the batch: (n, len(ea)) row-major
+    ea = f", gea + (base + (lane < cnt ? lane : 0)) * {int(sp.Matrix(k.ea_sym).shape[0])}" if k.ea_sym is not None else ""
     out.append(f"""
 // ---- kind {k.kind}: [predict +] update, state round-trips HBM once per launch --------------------------
 template <bool DO_PREDICT>
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       int fl = 0;
       switch (kind) {{
 {chr(10).join(cases)}
-        default: break;
+        default: fl = 8; break;      // kind not available in the fused run (unknown, or it takes extra arguments)
       }}
       {norm}
       // y(t) and the optional trace go out through LDS as coalesced 16-byte stores

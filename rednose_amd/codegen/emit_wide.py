@@ -170,6 +170,12 @@ def update_fn(spec, k):
   return "\n".join([head] + _ind(b) + ["}"]), He
 
 
+def run_kinds(spec):
+  """Kinds the fused multi-step run serves: its schedule (kinds[t], dts[t], R[t]) is shared by all filters and carries no
+  per-filter extra arguments, so kinds that take them (MSCKF feature tracks) stay step-granular (flag bit 8 if asked for)."""
+  return [k for k in spec.kinds if k.ea_sym is None]
+
+
 def kernels(spec, step_kernels=True):
   D, E = spec.dim_x, spec.dim_err
   EE = E * E
@@ -178,7 +184,7 @@ def kernels(spec, step_kernels=True):
   out = [f"constexpr int GL = {G_LANES};    // lanes per filter", f"constexpr int FPW = {FPW};   // filters per wavefront", ""]
   out.append(predict_fn(spec))
   out.append(predict_fn(spec, rts=True))
-  for k in spec.kinds:
+  for k in run_kinds(spec):
     utxt, _ = update_fn(spec, k)
     out.append(utxt)
   quat = "".join(f" rn::normalize_quat<{D}>(x, {q});" for q in spec.quaternion_idxs)
@@ -310,7 +316,7 @@ def run_kernel(spec, norm):
   DP = _even(D)
   zmax = max(k.zdim for k in spec.kinds)
   cases = []
-  for k in spec.kinds:
+  for k in run_kinds(spec):
     Z = k.zdim
     cases.append(f"""        case {k.kind}: {{
           double zk[{Z}], Rk[{Z * Z}];
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       int fl = 0;
       switch (kind) {{
 {chr(10).join(cases)}
-        default: break;
+        default: fl = 8; break;      // kind not available in the fused run (unknown, or it takes extra arguments)
       }}
       {norm}
       if (c == 0 && g < cnt) {{

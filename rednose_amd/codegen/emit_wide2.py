@@ -36,6 +36,13 @@ def filters_per_wave(spec):
   return fpw if fpw else max(2, 64 // spec.dim_err)
 
 
+EADIM = 3        # extra-argument dimension of feature-track kinds, hard-coded in the reference (ekf_sym.py:151)
+
+
+def ea_dim(k):
+  return 0 if k.ea_sym is None else int(sp.Matrix(k.ea_sym).shape[0])
+
+
 def _ind(lines, n=2):
   pad = " " * n
   return [pad + s for s in lines]
@@ -66,7 +73,13 @@ class Layout:
     self.OFF_DX = self.OFF_HE + self.nh
     self.OFF_DT = self.OFF_DX + E
     self.OFF_FL = self.OFF_DT + 1
-    self.SLOT = _odd(self.OFF_FL + 1)     # odd stride: lane-per-filter ds_*_b64 accesses hit 32 distinct bank pairs
+    # feature-track kinds (MSCKF): EADIM Householder reflectors of the extra-argument Jacobian (EADIM x Z entries +
+    # EADIM betas) and the projected noise (Z - EADIM)^2
+    feat = [k for k in spec.kinds if k.He_sym is not None]
+    self.zf = max([k.zdim for k in feat] + [0])
+    self.OFF_RF = self.OFF_FL + 1
+    self.OFF_RP = self.OFF_RF + (EADIM * self.zf + EADIM if feat else 0)
+    self.SLOT = _odd(self.OFF_RP + ((self.zf - EADIM) ** 2 if feat else 0))     # odd stride: lane-per-filter ds_*_b64 accesses hit 32 distinct bank pairs
 
 
 def _lowered_predict(spec):
@@ -88,6 +101,7 @@ def _lowered_predict(spec):
 def _lowered_obs(spec, k):
   E, Z = spec.dim_err, k.zdim
   names = dict(vector_names(spec.x_sym, 'x'))
+  names.update(vector_names(k.ea_sym, 'ea'))
   Herr = sp.Matrix(k.H_sym) * sp.Matrix(spec.H_mod_sym)
   blk = Block(names, tmp_prefix="ut")
   for i in range(Z):
@@ -96,10 +110,27 @@ def _lowered_obs(spec, k):
   for i in range(Z):
     for j in range(E):
       blk.add(fmtH(i, j), Herr[i, j])
+  if k.He_sym is not None:      # d h / d extra args (the reference's He_{kind}), Z x EADIM
+    assert tuple(k.He_sym.shape) == (Z, EADIM), "feature-track kinds take EADIM = 3 extra arguments (ekf_sym.py:151)"
+    for i in range(Z):
+      for j in range(EADIM):
+        blk.add(f"Hea_{i}_{j}", k.He_sym[i, j])
   stmts, st = blk.lower()
   He = SMat.from_structure(Z, E, st, fmtH)
   he_vars = [c[1] for row in He.e for c in row if c is not None and c[0] == 'var']
   return stmts, st, He, he_vars
+
+
+def _obs_call(k, project):
+  """Phase-1 call of kind k's scalar function for filter `lane` of the tile (extra args / R are per filter)."""
+  Z = k.zdim
+  feat = k.He_sym is not None
+  args = f"sl, s_z + lane * {Z}"
+  if ea_dim(k):
+    args += f", gea + (base + lane) * {ea_dim(k)}"
+  if feat:
+    args += f", r_per_filter ? gR + (base + lane) * {Z * Z} : gR"
+  return f"scal_obs_{k.kind}{'<' + project + '>' if feat else ''}({args})"
 
 
 def _slotted(smat, var_list, off):
@@ -117,30 +148,53 @@ def _slotted(smat, var_list, off):
 
 
 def _lean_update(k, Hs, lay, E, rows_in_regs=False):
-  """Update with the covariance rows left in LDS: G / Gt read only the columns He touches, the Joseph correction
-  Dm = K R - B He^T is formed from Gt - K (He P He^T) (the same quantity, B = P - K G never materialised in registers),
-  and ONE rolled pass rewrites the lane's row in place:  P'[cc, j] = (P[cc, j] - sum_z K_z G[z, j]) + sum_z Dm_z K[j, z].
-  Live registers: a few dozen, so two or more wavefronts fit per SIMD."""
-  Z = k.zdim
+  """Update with the Joseph correction Dm = K R - B He^T formed from Gt - K (He P He^T) (the same quantity, B = P - K G
+  never materialised), only the columns of P that He touches read, and ONE pass over the lane's row:
+  P'[cc, j] = (P[cc, j] - sum_z K_z G[z, j]) + sum_z Dm_z K[j, z].  rows_in_regs=False leaves the row in LDS (rolled
+  in-place pass, a few dozen live registers: two or more wavefronts per SIMD).
+
+  Feature-track kinds (k.He_sym, MSCKF): G, Gt and the rows of He P He^T are taken to the left null space of the
+  extra-argument Jacobian by the reflectors phase 1 left in the slot (ekf_c.c:66-76: H <- A^T H); everything after
+  that is the ordinary update with Z - EADIM rows and the projected y / R of the slot."""
+  Zf = k.zdim
+  feat = k.He_sym is not None
+  Z = Zf - EADIM if feat else Zf
   U = tuning.current().wide_unroll
-  used = sorted({kk for zi in range(Z) for kk, _ in Hs.row_nz(zi)})
+  used = sorted({kk for zi in range(Zf) for kk, _ in Hs.row_nz(zi)})
   b = [f"double R[{Z * Z}];", f"double* pr = sP + cc * {E};"]
   if rows_in_regs:
     b += [f"double row[{E}];", "#pragma unroll", f"for (int j = 0; j < {E}; j++) row[j] = pr[j];"]
     b += [f"const double col_{kk} = sP[{kk} * {E} + cc], row_{kk} = row[{kk}];" for kk in used]
   else:
     b += [f"const double col_{kk} = sP[{kk} * {E} + cc], row_{kk} = pr[{kk}];" for kk in used]
-  b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) R[i] = gR[i];"]
-  for zi in range(Z):
-    nz = Hs.row_nz(zi)
-    b.append(f"const double G_{zi} = {sum_terms(term(cf, f'col_{kk}') for kk, cf in nz)};")
-    b.append(f"const double Gt_{zi} = {sum_terms(term(cf, f'row_{kk}') for kk, cf in nz)};")
+  if feat:
+    b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) R[i] = sl[{lay.OFF_RP} + i];      // A^T R A (phase 1)", "(void)gR;"]
+    b.append(f"double G0[{Zf}] = {{" + ", ".join(sum_terms(term(cf, f'col_{kk}') for kk, cf in Hs.row_nz(zi)) for zi in range(Zf)) + "};")
+    b.append(f"double Gt0[{Zf}] = {{" + ", ".join(sum_terms(term(cf, f'row_{kk}') for kk, cf in Hs.row_nz(zi)) for zi in range(Zf)) + "};")
+    b.append(f"rn::apply_reflectors<{Zf}, {EADIM}>(sl + {lay.OFF_RF}, sl + {lay.OFF_RF + EADIM * Zf}, G0);")
+    b.append(f"rn::apply_reflectors<{Zf}, {EADIM}>(sl + {lay.OFF_RF}, sl + {lay.OFF_RF + EADIM * Zf}, Gt0);")
+    for zi in range(Z):
+      b.append(f"const double G_{zi} = G0[{EADIM + zi}], Gt_{zi} = Gt0[{EADIM + zi}];")
+    b.append(f"const double rank_deficient = sl[{lay.OFF_FL}];      // 4.0 when phase 1 found Hea rank deficient")
+  else:
+    b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) R[i] = gR[i];"]
+    for zi in range(Z):
+      nz = Hs.row_nz(zi)
+      b.append(f"const double G_{zi} = {sum_terms(term(cf, f'col_{kk}') for kk, cf in nz)};")
+      b.append(f"const double Gt_{zi} = {sum_terms(term(cf, f'row_{kk}') for kk, cf in nz)};")
   b.append("if (act) { " + " ".join(f"sG[{zi} * {E} + cc] = G_{zi};" for zi in range(Z)) + " }")
   b.append("rn::wave_lds_sync();")
   b.append(f"double HPH[{Z * Z}], Rl[{Z * Z}], S[{Z * Z}], L[{Z * Z}], iL[{Z}];")
-  for zi in range(Z):
-    for w in range(Z):
-      b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))};")
+  if feat:
+    for zi in range(Z):
+      b.append("{")
+      b.append(f"  double m[{Zf}] = {{" + ", ".join(sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w)) for w in range(Zf)) + "};")
+      b.append(f"  rn::apply_reflectors<{Zf}, {EADIM}>(sl + {lay.OFF_RF}, sl + {lay.OFF_RF + EADIM * Zf}, m);")
+      b += ["#pragma unroll", f"  for (int w = 0; w < {Z}; w++) HPH[{zi * Z} + w] = m[{EADIM} + w];", "}"]
+  else:
+    for zi in range(Z):
+      for w in range(Z):
+        b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))};")
   b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}", f"rn::spd_factor<{Z}>(S, L, iL);",
         "int gated = 0;"]
   if k.maha_test:
@@ -150,20 +204,19 @@ def _lean_update(k, Hs, lay, E, rows_in_regs=False):
           f"    rn::spd_factor<{Z}>(S, L, iL);", "  }", "}"]
   b.append(f"double kk[{Z}] = {{{', '.join(f'Gt_{zi}' for zi in range(Z))}}};")
   b.append(f"rn::spd_solve<{Z}>(L, iL, kk);")
+  if feat:     # the reference's numpy path ignores a measurement whose null-space projection failed (ekf_sym.py:589-591)
+    b += ["if (rank_deficient != 0.0) {", "#pragma unroll", f"  for (int i = 0; i < {Z}; i++) kk[i] = 0.0;", "}"]
   b.append("const double dxc = " + " + ".join(f"kk[{zi}]*sl[{lay.OFF_Y + zi}]" for zi in range(Z)) + ";")
   for zi in range(Z):
     c = f"Gt_{zi} - (" + " + ".join(f"kk[{w}]*HPH[{w * Z + zi}]" for w in range(Z)) + ")"
     kr = " + ".join(f"kk[{w}]*Rl[{w * Z + zi}]" for w in range(Z))
-    b.append(f"const double Dm_{zi} = ({kr}) - ({c});")
-  b.append("if (act) { " + " ".join(f"sK[{zi} * {E} + cc] = kk[{zi}];" for zi in range(Z)) + f" sw[{lay.OFF_DX} + cc] = dxc; if (cc == 0) sw[{lay.OFF_FL}] = (double)gated; }}")
+    b.append(f"const double Dm_{zi} = " + ("rank_deficient != 0.0 ? 0.0 : " if feat else "") + f"({kr}) - ({c});")
+  fl = "(double)gated + rank_deficient" if feat else "(double)gated"
+  b.append("if (act) { " + " ".join(f"sK[{zi} * {E} + cc] = kk[{zi}];" for zi in range(Z)) + f" sw[{lay.OFF_DX} + cc] = dxc; if (cc == 0) sw[{lay.OFF_FL}] = {fl}; }}")
   b.append("rn::wave_lds_sync();")
-  if rows_in_regs:
-    b += ["if (act) {", "#pragma unroll", f"  for (int j = 0; j < {E}; j++) {{",
-          "    const double bj = row[j] - (" + " + ".join(f"kk[{zi}]*sG[{zi * E} + j]" for zi in range(Z)) + ");",
-          "    pr[j] = bj + (" + " + ".join(f"Dm_{zi}*sK[{zi * E} + j]" for zi in range(Z)) + ");", "  }", "}", "rn::wave_lds_sync();"]
-    return b
-  b += ["if (act) {", f"#pragma unroll {U}", f"  for (int j = 0; j < {E}; j++) {{",
-        "    const double bj = pr[j] - (" + " + ".join(f"kk[{zi}]*sG[{zi * E} + j]" for zi in range(Z)) + ");",
+  src = "row[j]" if rows_in_regs else "pr[j]"
+  b += ["if (act) {", "#pragma unroll" if rows_in_regs else f"#pragma unroll {U}", f"  for (int j = 0; j < {E}; j++) {{",
+        f"    const double bj = {src} - (" + " + ".join(f"kk[{zi}]*sG[{zi * E} + j]" for zi in range(Z)) + ");",
         "    pr[j] = bj + (" + " + ".join(f"Dm_{zi}*sK[{zi * E} + j]" for zi in range(Z)) + ");", "  }", "}", "rn::wave_lds_sync();"]
   return b
 
@@ -201,16 +254,42 @@ def device_functions(spec):
   for k in spec.kinds:
     stmts, st, He, he_vars = obs[k.kind]
     Z = k.zdim
+    EA = ea_dim(k)
+    feat = k.He_sym is not None
     b = [f"double x[{D}], z[{Z}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = sl[{lay.OFF_X} + i];",
          "#pragma unroll", f"for (int i = 0; i < {Z}; i++) z[i] = zin[i];"]
+    if EA:
+      b += [f"double ea[{EA}];", "#pragma unroll", f"for (int i = 0; i < {EA}; i++) ea[i] = eain[i];"]
     b += list(stmts)
-    for i in range(Z):
-      kind, val = st[f"hx_{i}"]
-      hx = f"hx_{i}" if kind == 'expr' else repr(float(val))
-      b.append(f"sl[{lay.OFF_Y + i}] = z[{i}] - {hx};")
+    val = lambda nm: nm if st[nm][0] == 'expr' else repr(float(st[nm][1] or 0.0))  # noqa: E731
     for i, v in enumerate(he_vars):
       b.append(f"sl[{lay.OFF_HE + i}] = {v};")
-    out.append("\n".join([f"__device__ {INL} void scal_obs_{k.kind}(double* sl, const double* zin) {{"] + _ind(b) + ["}"]))
+    if not feat:
+      for i in range(Z):
+        b.append(f"sl[{lay.OFF_Y + i}] = z[{i}] - {val(f'hx_{i}')};")
+    else:
+      # ekf_c.c:66-76: residual and R go to the left null space of Hea; the reflectors stay in the slot for phase 2
+      Zp = Z - EADIM
+      b.append(f"double y[{Z}] = {{{', '.join(f'z[{i}] - ' + val(f'hx_{i}') for i in range(Z))}}};")
+      b.append("if (PROJECT) {")
+      hea = ", ".join(("0.0" if st[f"Hea_{i}_{j}"][0] == 'zero' else ("1.0" if st[f"Hea_{i}_{j}"][0] == 'one' else val(f"Hea_{i}_{j}")))
+                      for i in range(Z) for j in range(EADIM))
+      b += [f"  double Hea[{Z * EADIM}] = {{{hea}}};", f"  double u[{EADIM * Z}], beta[{EADIM}];",
+            f"  const bool ok = rn::householder_qr<{Z}, {EADIM}>(Hea, u, beta);",
+            f"  rn::apply_reflectors<{Z}, {EADIM}>(u, beta, y);",
+            "#pragma unroll", f"  for (int i = 0; i < {EADIM * Z}; i++) sl[{lay.OFF_RF} + i] = u[i];",
+            "#pragma unroll", f"  for (int i = 0; i < {EADIM}; i++) sl[{lay.OFF_RF + EADIM * Z} + i] = beta[i];",
+            "#pragma unroll", f"  for (int i = 0; i < {Zp}; i++) sl[{lay.OFF_Y} + i] = ok ? y[{EADIM} + i] : 0.0;",
+            "#pragma unroll", f"  for (int i = {Zp}; i < {Z}; i++) sl[{lay.OFF_Y} + i] = z[i];      // y has Z - EADIM rows (ekf_c.c:120)",
+            f"  sl[{lay.OFF_FL}] = ok ? 0.0 : 4.0;",
+            f"  double Rm[{Z * Z}];", "#pragma unroll", f"  for (int i = 0; i < {Z * Z}; i++) Rm[i] = gRf[i];",
+            f"  rn::project_noise<{Z}, {EADIM}>(u, beta, Rm);",
+            "#pragma unroll", f"  for (int a = 0; a < {Zp}; a++) {{", "#pragma unroll",
+            f"    for (int c = 0; c < {Zp}; c++) sl[{lay.OFF_RP} + a * {Zp} + c] = Rm[({EADIM} + a) * {Z} + {EADIM} + c];", "  }",
+            "} else {", "#pragma unroll", f"  for (int i = 0; i < {Z}; i++) sl[{lay.OFF_Y} + i] = y[i];", "}"]
+    tmpl = "template <bool PROJECT>\n" if feat else ""
+    sig = "double* sl, const double* zin" + (", const double* eain" if EA else "") + (", const double* gRf" if feat else "")
+    out.append("\n".join([f"{tmpl}__device__ {{INL}} void scal_obs_{k.kind}({sig}) {{"] + _ind(b) + ["}"]))
 
   # ---- phase 3: error injection ----------------------------------------------------------------------
   nom, delta = spec.err_eqs[1], spec.err_eqs[2]
@@ -267,7 +346,7 @@ def device_functions(spec):
     Z = k.zdim
     if lean == 1:
       b = _lean_update(k, Hs, lay, E)
-    elif lean == 2:
+    elif lean == 2 or k.He_sym is not None:
       b = _lean_update(k, Hs, lay, E, rows_in_regs=True)
     else:
       b = [f"double row[{E}], R[{Z * Z}];", "#pragma unroll", f"for (int j = 0; j < {E}; j++) row[j] = sP[cc * {E} + j];"]
@@ -382,7 +461,7 @@ def kernels(spec):
     A(f"        scal_keep(s_x + lane * {D}, sl, {dop} ? norm_quats : 0);      // predict(dt = 0) still renormalises")
     A("      }")
     if upd:
-      A(f"      scal_obs_{k.kind}(sl, s_z + lane * {Z});")
+      A(f"      {_obs_call(k, 'true')};")
     A("    }")
     A("    rn::wave_lds_sync();")
     A(f"    // ---------------- phase 2: {GL}-lane group per filter, {FPW} filters at a time, covariance algebra ----------")
@@ -420,7 +499,7 @@ def kernels(spec):
       A(f"      int fl = scal_inject(sl, s_x + lane * {D}, norm_quats);")
       A("#pragma unroll")
       A(f"      for (int i = 0; i < {Z}; i++) s_z[lane * {Z} + i] = sl[{lay.OFF_Y} + i];")
-      A(f"      if (flags != nullptr) flags[base + lane] = (uint8_t)(fl | (sl[{lay.OFF_FL}] != 0.0 ? 1 : 0));")
+      A(f"      if (flags != nullptr) flags[base + lane] = (uint8_t)(fl | (int)sl[{lay.OFF_FL}]);     // 1 gated, 4 projection failed")
     else:
       A("#pragma unroll")
       A(f"      for (int i = 0; i < {D}; i++) s_x[lane * {D} + i] = sl[{lay.OFF_X} + i];")
@@ -475,8 +554,9 @@ def maha_kernels(spec):
                           "double* sG, const int cc, const bool act) {"] + _ind(b) + ["}"]))
     out.append(f"""
 __global__ __launch_bounds__(64) void k_maha_{k.kind}(const double* __restrict__ gx, const double* __restrict__ gP,
-    const double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const int64_t n,
-    double* __restrict__ d2) {{
+    const double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const double* __restrict__ gea,
+    const int64_t n, double* __restrict__ d2) {{
+  (void)gea;
   __shared__ __attribute__((aligned(16))) double s_P[{PBUF}];
   __shared__ __attribute__((aligned(16))) double s_x[FT2 * {D} + 2];
   __shared__ __attribute__((aligned(16))) double s_z[FT2 * {Z} + 2];
@@ -497,7 +577,7 @@ __global__ __launch_bounds__(64) void k_maha_{k.kind}(const double* __restrict__
     if (lane < cnt) {{
       double* sl = s_sl + lane * SLOT;
       scal_keep(s_x + lane * {D}, sl, 0);
-      scal_obs_{k.kind}(sl, s_z + lane * {Z});
+      {_obs_call(k, 'false')};
     }}
     rn::wave_lds_sync();
     const int ngroups = (cnt + {FPW - 1}) / {FPW};
@@ -523,7 +603,7 @@ __global__ __launch_bounds__(64) void k_maha_{k.kind}(const double* __restrict__
 def launch_maha(kind):
   return f"""  const int64_t tiles = (n + FT2 - 1) / FT2;
   hipLaunchKernelGGL(k_maha_{kind}, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
-                     x, P, z, R, r_per_filter, n, d2);"""
+                     x, P, z, R, r_per_filter, ea, n, d2);"""
 
 
 def launch_predict():

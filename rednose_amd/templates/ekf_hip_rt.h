@@ -367,6 +367,87 @@ __device__ __forceinline__ double fast_recip(const double d) {
   return r;
 }
 
+// ---- left null space of the extra-argument Jacobian (MSCKF, /root/reference/rednose/templates/ekf_c.c:66-76) --------
+// The reference projects the residual, H and R of a feature-track observation on A = kernel(Hea^T) (Eigen fullPivLu;
+// numpy twin: SVD null space, ekf_sym.py:20-26,583).  Any basis of that null space gives the same x and P; we use the
+// orthonormal one that falls out of a Householder QR of Hea (Z x A): Hea = Q [R; 0], A_basis = Q[:, A:], so that
+// "A^T v" is (Q^T v)[A:], i.e. A reflections applied to v and the first A entries dropped -- A is never formed.
+// u holds the A reflector vectors (entries below the pivot row are meaningful, the rest zero), beta[c] = 2 / (u_c.u_c).
+// Returns false when Hea is rank deficient (a pivot column vanishes against the largest one: the reference's numpy path
+// ignores such a measurement, ekf_sym.py:589-591); the reflectors are then the identity (beta = 0).
+template <int Z, int A>
+__device__ __forceinline__ bool householder_qr(double (&M)[Z * A], double (&u)[A * Z], double (&beta)[A]) {
+  bool full_rank = true;
+  double scale = 0.0;
+#pragma unroll
+  for (int c = 0; c < A; c++) {
+    double nrm2 = 0.0;
+#pragma unroll
+    for (int i = c; i < Z; i++) nrm2 += M[i * A + c] * M[i * A + c];
+    const double nrm = sqrt(nrm2);
+    if (c == 0) scale = nrm;
+    if (!(nrm > 2.220446049250313e-16 * Z * scale) || !(scale > 0.0)) full_rank = false;
+    const double alpha = M[c * A + c] > 0.0 ? -nrm : nrm;
+#pragma unroll
+    for (int i = 0; i < Z; i++) u[c * Z + i] = i < c ? 0.0 : M[i * A + c];
+    u[c * Z + c] -= alpha;
+    double uu = 0.0;
+#pragma unroll
+    for (int i = c; i < Z; i++) uu += u[c * Z + i] * u[c * Z + i];
+    beta[c] = uu > 0.0 ? 2.0 / uu : 0.0;
+#pragma unroll
+    for (int j = c + 1; j < A; j++) {
+      double dot = 0.0;
+#pragma unroll
+      for (int i = c; i < Z; i++) dot += u[c * Z + i] * M[i * A + j];
+      dot *= beta[c];
+#pragma unroll
+      for (int i = c; i < Z; i++) M[i * A + j] -= dot * u[c * Z + i];
+    }
+  }
+  if (!full_rank) {
+#pragma unroll
+    for (int c = 0; c < A; c++) beta[c] = 0.0;
+  }
+  return full_rank;
+}
+
+// v <- Q^T v for the reflectors above (u, beta may live in LDS: broadcast reads)
+template <int Z, int A>
+__device__ __forceinline__ void apply_reflectors(const double* u, const double* beta, double (&v)[Z]) {
+#pragma unroll
+  for (int c = 0; c < A; c++) {
+    double dot = 0.0;
+#pragma unroll
+    for (int i = c; i < Z; i++) dot += u[c * Z + i] * v[i];
+    dot *= beta[c];
+#pragma unroll
+    for (int i = c; i < Z; i++) v[i] -= dot * u[c * Z + i];
+  }
+}
+
+// R <- Q^T R Q (Z x Z, row-major, in registers); the projected noise A^T R A is its trailing (Z - A) x (Z - A) block
+template <int Z, int A>
+__device__ __forceinline__ void project_noise(const double (&u)[A * Z], const double (&beta)[A], double (&R)[Z * Z]) {
+  double v[Z];
+#pragma unroll
+  for (int j = 0; j < Z; j++) {          // columns
+#pragma unroll
+    for (int i = 0; i < Z; i++) v[i] = R[i * Z + j];
+    apply_reflectors<Z, A>(u, beta, v);
+#pragma unroll
+    for (int i = 0; i < Z; i++) R[i * Z + j] = v[i];
+  }
+#pragma unroll
+  for (int i = 0; i < Z; i++) {          // rows
+#pragma unroll
+    for (int j = 0; j < Z; j++) v[j] = R[i * Z + j];
+    apply_reflectors<Z, A>(u, beta, v);
+#pragma unroll
+    for (int j = 0; j < Z; j++) R[i * Z + j] = v[j];
+  }
+}
+
 // S = L D L^T with unit lower-triangular L (lower triangle of S is read); iD[j] = 1 / D[j].  Square-root-free on
 // purpose: Cholesky's sqrt + reciprocal per column are two long dependent chains (see fast_recip).  S is the SPD
 // innovation covariance; the reference solves with fullPivLu (ekf_c.c:89,101) -- same solution up to rounding.

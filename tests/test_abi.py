@@ -1,5 +1,5 @@
 """CPU test: every generated library loads without a GPU and exports every symbol its committed header declares
-(include/kinematic.h, include/kinematic6.h, include/live.h), plus the generic ABI of include/rednose_amd_filter.h.
+(include/kinematic.h, include/kinematic6.h, include/kinematic9.h, include/live.h, include/feature.h), plus the generic ABI of include/rednose_amd_filter.h.
 No compute call is made here; compute without a device must fail loudly, which is checked."""
 import ctypes
 import os
@@ -11,7 +11,7 @@ import pytest
 from conftest import REPO
 
 INCLUDE = os.path.join(REPO, "include")
-MODELS = ["kinematic", "kinematic6", "live"]
+MODELS = ["kinematic", "kinematic6", "kinematic9", "live", "feature"]
 
 
 @pytest.fixture(scope="module")
@@ -39,14 +39,22 @@ def test_library_exports_committed_header(gen_dir, name):
     assert protos[f"{name}_{sym}"][0] is None
   d = (ctypes.c_int * 3)()
   getattr(dll, f"{name}_dims")(d)
-  assert tuple(d) == {"kinematic": (2, 2, 2), "kinematic6": (6, 6, 6), "live": (23, 22, 22)}[name]
+  assert tuple(d) == {"kinematic": (2, 2, 2), "kinematic6": (6, 6, 6), "kinematic9": (9, 9, 9), "live": (23, 22, 22),
+                      "feature": (15, 15, 6)}[name]
+  md = (ctypes.c_int * 5)()
+  getattr(dll, f"{name}_msckf_dims")(md)
+  assert tuple(md) == ((6, 6, 3, 3, 3) if name == "feature" else (tuple(d)[0], tuple(d)[1], 0, 0, 0))
+  assert hasattr(dll, f"{name}_batch_augment") == (name == "feature")
+  if name == "feature":        # feature-track kind: extra-argument Jacobian exported, 3 extra arguments
+    assert hasattr(dll, "feature_He_2") and not hasattr(dll, "feature_He_1")
+    assert dll.feature_kind_eadim(2) == 3 and dll.feature_kind_eadim(1) == 0
 
 
 def test_generic_header_macros_cover_generated_symbols(gen_dir):
   """Every symbol family documented in rednose_amd_filter.h exists in a generated library, and vice versa."""
   with open(os.path.join(INCLUDE, "rednose_amd_filter.h"), encoding="utf-8") as f:
     text = f.read()
-  documented = set(re.findall(r"RN_FN\(name, (\w+?)(?:##k)?\)", text)) - {"sym"}
+  documented = set(re.findall(r"RN_FN\(name, (\w+?)(?:##k)?\)", text)) - {"sym", "batch_augment"}   # augment: MSCKF models only
   from rednose_amd.helpers import parse_prototypes
   with open(os.path.join(gen_dir, "kinematic6.h"), encoding="utf-8") as f:
     protos = parse_prototypes(f.read())

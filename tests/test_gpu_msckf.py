@@ -1,0 +1,134 @@
+"""GPU parity of the MSCKF path (windowed-camera example, examples/feature_kf.py): block-structured predict, null-space
+projected feature updates, window shift.  Goldens come from the reference's numpy path (tests/golden/feature_stream.npz,
+oracle/make_golden.py); random batches are checked against the oracle.  x and P do not depend on the null-space basis
+(tolerance as for every other kind); the projected residual does, so it is compared through its norm (the reference's
+numpy path and the HIP kernels both use orthonormal bases: equal up to a rotation)."""
+import numpy as np
+import pytest
+
+from conftest import assert_close, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+  import torch
+  assert torch.cuda.is_available()
+  from examples import ensure_generated
+  from examples.feature_kf import FeatureKalman
+  return torch, ensure_generated(["feature"]), FeatureKalman
+
+
+def _filter(env, n):
+  torch, gen, FK = env
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  return BatchedEKF(gen, "feature", FK.Q, FK.initial_x, np.diag(FK.initial_P_diag), 6, 6, batch=n, **FK.filter_kwargs())
+
+
+def test_feature_updates_vs_reference_numpy(env):
+  torch, gen, FK = env
+  g = golden("feature_stream.npz")
+  n = g["upd_x_in"].shape[0]
+  f = _filter(env, n)
+  f.init_state(g["upd_x_in"], g["upd_P_in"], 0.0)
+  y = f.update(2, g["upd_z"].copy(), FK.obs_noise[2], extra_args=g["upd_ea"])
+  torch.cuda.synchronize()
+  assert_close(f.state(), g["upd_x"], rtol=1e-9, floor=1e-11, what="feature update x")
+  assert_close(f.covs().reshape(n, -1), g["upd_P"].reshape(n, -1), rtol=1e-8, floor=1e-10, what="feature update P")
+  y = y.cpu().numpy()
+  assert_close(np.linalg.norm(y[:, :3], axis=1), np.linalg.norm(g["upd_y"], axis=1), rtol=1e-9, what="|projected residual|")
+  assert np.array_equal(y[:, 3:], g["upd_z"][:, 3:])          # y has Z - 3 rows; the tail of z is left alone (ekf_c.c:120)
+  assert not f.flags.cpu().numpy().any()
+
+
+@pytest.mark.parametrize("n", [1, 4, 5, 13, 200])
+def test_both_kinds_vs_oracle_strict(env, n):
+  """Random states; fused predict+update and split launches; tiles of 16 filters in groups of 4."""
+  torch, gen, FK = env
+  from oracle_lib import OracleLib
+  o = OracleLib("feature")
+  rng = np.random.default_rng(50 + n)
+  x0 = np.tile(FK.initial_x, (n, 1)) + rng.normal(size=(n, 15)) * 0.3
+  A = rng.normal(size=(n, 15, 15)) * 0.2
+  P0 = np.diag(FK.initial_P_diag)[None] + A @ A.transpose(0, 2, 1)
+  landmarks = np.array([2.0, 1.0, 8.0])[None] + rng.normal(size=(n, 3))
+  f = _filter(env, n)
+  for kind, Z in ((1, 3), (2, 6)):
+    R = FK.obs_noise[kind]
+    for fused in (True, False):
+      z = rng.normal(size=(n, Z)) * 0.3
+      f.init_state(x0, P0, 0.0)
+      xr, Pr, zr = x0.copy(), P0.copy(), z.copy()
+      o.batch_step(kind, xr, Pr, zr, R, FK.Q, 0.05, ea=landmarks)
+      if fused:
+        y = f.predict_and_update_batch(0.05, kind, z.copy(), R, extra_args=landmarks)
+      else:
+        f.predict(0.05)
+        y = f.update(kind, z.copy(), R, extra_args=landmarks)
+      torch.cuda.synchronize()
+      what = f"kind {kind} n={n} fused={fused}"
+      assert_close(f.state(), xr, rtol=1e-11, floor=1e-13, what=what + " x")
+      assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-10, floor=1e-12, what=what + " P")
+      if kind == 1:
+        assert_close(y.cpu().numpy(), zr, atol=1e-14 * np.abs(z).max(), what=what + " y")
+
+
+def test_stream_with_window_shifts_vs_reference_numpy(env):
+  """The golden stream: POSITION fixes followed by augment(), FEATURE tracks in between, every step against the
+  reference's numpy filter (including the state after each window shift)."""
+  torch, gen, FK = env
+  g = golden("feature_stream.npz")
+  n = 6
+  f = _filter(env, n)
+  for t in range(len(g["ts"])):
+    k = int(g["kinds"][t]); Z = 3 if k == 1 else 6
+    z = np.tile(g["zs"][t, :Z], (n, 1))
+    est = f.predict_and_update_batch(float(g["ts"][t]), k, z, FK.obs_noise[k], extra_args=np.tile(g["eas"][t], (n, 1)),
+                                     augment=bool(g["augment"][t]), keep_estimate=True)
+    torch.cuda.synchronize()
+    for j in (0, n - 1):
+      assert_close(est[0].cpu().numpy()[j], g["xk_km1"][t], rtol=1e-8, floor=1e-10, what=f"xk_km1 t={t}")
+      assert_close(est[2].cpu().numpy()[j].reshape(1, -1), g["Pk_km1"][t].reshape(1, -1), rtol=1e-8, floor=1e-10, what=f"Pk_km1 t={t}")
+      assert_close(est[1].cpu().numpy()[j], g["xk_k"][t], rtol=1e-8, floor=1e-10, what=f"xk_k t={t}")
+      assert_close(est[3].cpu().numpy()[j].reshape(1, -1), g["Pk_k"][t].reshape(1, -1), rtol=1e-7, floor=1e-9, what=f"Pk_k t={t}")
+      assert_close(f.state()[j], g["x_after"][t], rtol=1e-8, floor=1e-10, what=f"x after augment t={t}")
+      assert_close(f.covs()[j].reshape(1, -1), g["P_after"][t].reshape(1, -1), rtol=1e-7, floor=1e-9, what=f"P after augment t={t}")
+  assert f.get_augment_times()[-1] == pytest.approx(float(g["ts"][np.where(g["augment"])[0][-1]]))
+
+
+def test_rank_deficient_projection_is_flagged_and_ignored(env):
+  """A landmark on the optical axis of every window position (ray = (0, 0, z)) still gives a rank-3 Hea; a degenerate one
+  needs zero rows: scale the problem so that Hea vanishes -> the update must be skipped, flag bit 4 set (the reference's
+  numpy path ignores such measurements, ekf_sym.py:589-591)."""
+  torch, gen, FK = env
+  n = 3
+  f = _filter(env, n)
+  x0 = np.tile(FK.initial_x, (n, 1))
+  P0 = np.tile(np.diag(FK.initial_P_diag), (n, 1, 1))
+  f.init_state(x0, P0, 0.0)
+  far = np.array([[1.0, 1.0, 1e200]] * n)             # rays ~ (0, 0, 1e200): d h / d landmark underflows to zero
+  y = f.update(2, np.zeros((n, 6)), FK.obs_noise[2], extra_args=far)
+  torch.cuda.synchronize()
+  assert (f.flags.cpu().numpy() & 4).all()
+  assert np.array_equal(f.state(), x0) and np.array_equal(f.covs(), P0)
+  assert not np.abs(y.cpu().numpy()[:, :3]).any()
+
+
+def test_scalar_abi_feature_update(env):
+  """The drop-in host-pointer entry point {name}_update_{kind}(x, P, z, R, ea) of the reference, batch of one."""
+  torch, gen, FK = env
+  from rednose_amd.helpers.ekf_sym import EKF_sym
+  g = golden("feature_stream.npz")
+  f = EKF_sym(gen, "feature", FK.Q, FK.initial_x, np.diag(FK.initial_P_diag), 6, 6, **FK.filter_kwargs())
+  assert f.feature_track_kinds == [2]
+  for i in range(3):
+    x, P, z = g["upd_x_in"][i].copy(), g["upd_P_in"][i].copy(), g["upd_z"][i].copy()
+    f._updates[2](x, P, z, FK.obs_noise[2].copy(), g["upd_ea"][i].copy())       # pylint: disable=protected-access
+    assert_close(x, g["upd_x"][i], rtol=1e-9, floor=1e-11)
+    assert_close(P, g["upd_P"][i], rtol=1e-8, floor=1e-10)
+  He = np.zeros((6, 3))
+  f.Hes[2](g["upd_x_in"][0].copy(), g["upd_ea"][0].copy(), He)
+  from oracle_lib import OracleLib
+  want = np.zeros(18); OracleLib("feature").call("He_2", g["upd_x_in"][0].copy(), g["upd_ea"][0].copy(), want)
+  assert_close(He.reshape(-1), want)
