@@ -12,7 +12,7 @@ def model_table():
   from examples.kinematic_kf import KinematicKalman
   from examples.kinematic6_kf import Kinematic6Kalman
   from examples.kinematic9_kf import Kinematic9Kalman
-  from examples.feature_kf import FeatureKalman
+  from examples.feature_kf import FeatureKalman, WideFeatureKalman
   from examples.live_kf import LiveKalman, ObservationKind as LK
   return {
     "kinematic": lambda d: KinematicKalman.generate_code(d),
@@ -20,6 +20,7 @@ def model_table():
     "kinematic6_maha": lambda d: _renamed(Kinematic6Kalman, "kinematic6_maha", d, maha_test_kinds=[1]),
     "kinematic9": lambda d: Kinematic9Kalman.generate_code(d),
     "feature": lambda d: FeatureKalman.generate_code(d),
+    "feature36": lambda d: WideFeatureKalman.generate_code(d),
     "live": lambda d: LiveKalman.generate_code(d),
     "live_maha": lambda d: LiveKalman.generate_code(d, name="live_maha", maha_test_kinds=[LK.ECEF_POS]),
   }

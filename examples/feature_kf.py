@@ -38,6 +38,9 @@ DIM_MAIN, DIM_AUGMENT = 6, 3
 
 class FeatureKalman(KalmanFilter):
   name = 'feature'
+  n_window = N_WINDOW
+  dim_augment = DIM_AUGMENT          # window entries are copies of the first dim_augment main states (ekf_sym.py:366-367)
+  observed = tuple(range(N_WINDOW))  # window entries the camera model uses
 
   dim_state = DIM_MAIN + N_WINDOW * DIM_AUGMENT
   initial_x = np.concatenate([[0.0, 0.0, 0.0, 1.0, 0.5, 0.0], np.tile([0.0, 0.0, 0.0], N_WINDOW)])
@@ -60,12 +63,13 @@ class FeatureKalman(KalmanFilter):
     landmark_sym = sp.MatrixSymbol('landmark', 3, 1)
     landmark = sp.Matrix(landmark_sym)
     rows = []
-    for i in range(N_WINDOW):
-      ray = landmark - state[DIM_MAIN + 3 * i:DIM_MAIN + 3 * (i + 1), 0]
+    for i in cls.observed:
+      at = DIM_MAIN + cls.dim_augment * i
+      ray = landmark - state[at:at + 3, 0]
       rows += [ray[0] / ray[2], ray[1] / ray[2]]
     obs_eqs = [[sp.Matrix(state[0:3, 0]), ObservationKind.POSITION, None],
                [sp.Matrix(rows), ObservationKind.FEATURE, landmark_sym]]
-    msckf_params = [DIM_MAIN, DIM_AUGMENT, DIM_MAIN, DIM_AUGMENT, N_WINDOW, [ObservationKind.FEATURE]]
+    msckf_params = [DIM_MAIN, cls.dim_augment, DIM_MAIN, cls.dim_augment, cls.n_window, [ObservationKind.FEATURE]]
     return dict(name=cls.name, f_sym=f_sym, dt_sym=dt, x_sym=state_sym, obs_eqs=obs_eqs, dim_x=n, dim_err=n,
                 msckf_params=msckf_params)
 
@@ -75,7 +79,7 @@ class FeatureKalman(KalmanFilter):
 
   @classmethod
   def filter_kwargs(cls):
-    return dict(N=N_WINDOW, dim_augment=DIM_AUGMENT, dim_augment_err=DIM_AUGMENT)
+    return dict(N=cls.n_window, dim_augment=cls.dim_augment, dim_augment_err=cls.dim_augment)
 
   def __init__(self, generated_dir, batch=None, device=None):
     P0 = np.diag(self.initial_P_diag)
@@ -86,5 +90,19 @@ class FeatureKalman(KalmanFilter):
                                **self.filter_kwargs())
 
 
+class WideFeatureKalman(FeatureKalman):
+  """The same camera with a window of five [pos, vel] copies (36 error states: one filter per wavefront in the lane-group
+  kernels), landmarks observed from window entries 0, 2 and 4."""
+  name = 'feature36'
+  n_window = 5
+  dim_augment = 6
+  observed = (0, 2, 4)
+
+  dim_state = DIM_MAIN + 5 * 6
+  initial_x = np.concatenate([[0.0, 0.0, 0.0, 1.0, 0.5, 0.0], np.tile([0.0, 0.0, 0.0, 1.0, 0.5, 0.0], 5)])
+  initial_P_diag = np.concatenate([[0.5**2] * 3 + [1.0**2] * 3, np.tile([0.5**2] * 3 + [1.0**2] * 3, 5)])
+  Q = np.diag([0.05**2] * 3 + [0.5**2] * 3 + [0.0] * 30)
+
+
 if __name__ == "__main__":
-  FeatureKalman.generate_code(sys.argv[2])
+  {"feature": FeatureKalman, "feature36": WideFeatureKalman}[sys.argv[1] if sys.argv[1] in ("feature", "feature36") else "feature"].generate_code(sys.argv[2])

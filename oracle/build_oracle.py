@@ -43,6 +43,7 @@ MODELS = {
   "kinematic6": dict(model="examples.kinematic6_kf:Kinematic6Kalman"),
   "kinematic9": dict(model="examples.kinematic9_kf:Kinematic9Kalman"),
   "feature": dict(model="examples.feature_kf:FeatureKalman"),
+  "feature36": dict(model="examples.feature_kf:WideFeatureKalman"),
   "kinematic6_maha": dict(model="examples.kinematic6_kf:Kinematic6Kalman", rename="kinematic6_maha",
                           maha_test_kinds=[1]),
 }

@@ -250,20 +250,22 @@ def kinematic9_goldens(T=60):
                       xs_smooth=xs_s, Ps_smooth=Ps_s)
 
 
-def feature_goldens(T=45):
+def feature_goldens(T=45, cls_name="FeatureKalman", out_name="feature_stream.npz", n_upd=24):
   """MSCKF stream of the windowed-camera example (examples/feature_kf.py) through the reference's numpy path:
   block-structured predict (ekf_sym.py:541-556), null-space projected FEATURE updates (:576-591), POSITION updates
   and augment() window shifts (:365-391).  Also single feature updates from random states."""
   import importlib.util
   spec = importlib.util.spec_from_file_location("rn_amd_feature_kf", os.path.join(REPO, "examples", "feature_kf.py"))
   mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
-  FK = mod.FeatureKalman
+  FK = getattr(mod, cls_name)
   rng = np.random.default_rng(21)
-  kw = dict(N=mod.N_WINDOW, dim_augment=mod.DIM_AUGMENT, dim_augment_err=mod.DIM_AUGMENT)
-  f = ref_filter("feature", FK.Q, FK.initial_x, np.diag(FK.initial_P_diag), mod.DIM_MAIN, mod.DIM_MAIN, **kw)
+  kw = FK.filter_kwargs()
+  D = FK.dim_state
+  ZF = 2 * len(FK.observed)
+  f = ref_filter(FK.name, FK.Q, FK.initial_x, np.diag(FK.initial_P_diag), mod.DIM_MAIN, mod.DIM_MAIN, **kw)
   landmarks = np.array([[2.0, 1.0, 8.0], [-1.5, 0.5, 6.0], [0.5, -1.0, 10.0], [3.0, 2.0, 12.0]])
   truth_p, truth_v = np.zeros(3), np.array([1.0, 0.5, 0.0])
-  window = [np.zeros(3)] * mod.N_WINDOW
+  window = [np.zeros(3)] * FK.n_window
   recs = dict(kinds=[], ts=[], zs=[], eas=[], augment=[], xk_k=[], Pk_k=[], xk_km1=[], Pk_km1=[], ys=[])
   t = 0.0
   for i in range(T):
@@ -275,34 +277,34 @@ def feature_goldens(T=45):
     else:
       kind, aug = 2, False
       ea = landmarks[i % len(landmarks)] + rng.normal(size=3) * 0.05
-      rays = [landmarks[i % len(landmarks)] - w for w in window]
-      z = np.concatenate([[r[0] / r[2], r[1] / r[2]] for r in rays]) + rng.normal(size=6) * 0.01
-    R = FK.obs_noise[kind]
+      rays = [landmarks[i % len(landmarks)] - window[w] for w in FK.observed]
+      z = np.concatenate([[r[0] / r[2], r[1] / r[2]] for r in rays]) + rng.normal(size=ZF) * 0.01
+    R = FK.obs_noise[kind] if kind == 1 else np.eye(ZF) * 0.01**2
     est = f.predict_and_update_batch(t, kind, np.array([z]), np.array([R]), [list(ea)] if kind == 2 else [[]], augment=aug)
     if aug:
       window = window[1:] + [truth_p.copy()]
     y = np.ravel(est[6][0])
-    recs["kinds"].append(kind); recs["ts"].append(t); recs["zs"].append(np.concatenate([z, np.zeros(6 - len(z))]))
+    recs["kinds"].append(kind); recs["ts"].append(t); recs["zs"].append(np.concatenate([z, np.zeros(ZF - len(z))]))
     recs["eas"].append(ea); recs["augment"].append(aug)
     recs["xk_km1"].append(est[0]); recs["xk_k"].append(est[1]); recs["Pk_km1"].append(est[2]); recs["Pk_k"].append(est[3])
-    recs["ys"].append(np.concatenate([y, np.zeros(6 - len(y))]))
+    recs["ys"].append(np.concatenate([y, np.zeros(ZF - len(y))]))
     recs.setdefault("x_after", []).append(f.state().copy()); recs.setdefault("P_after", []).append(f.covs().copy())
   # single FEATURE updates from random states (reference numpy update, no predict)
-  n = 24
-  xs = np.tile(FK.initial_x, (n, 1)) + rng.normal(size=(n, 15)) * 0.3
+  n = n_upd
+  xs = np.tile(FK.initial_x, (n, 1)) + rng.normal(size=(n, D)) * 0.3
   Ps = []
   for _ in range(n):
-    A = rng.normal(size=(15, 15)) * 0.2
+    A = rng.normal(size=(D, D)) * 0.2
     Ps.append(np.diag(FK.initial_P_diag) + A @ A.T)
   Ps = np.array(Ps)
   eas = landmarks[rng.integers(0, 4, size=n)] + rng.normal(size=(n, 3)) * 0.2
-  zs = rng.normal(size=(n, 6)) * 0.3
+  zs = rng.normal(size=(n, ZF)) * 0.3
   ux, uP, uy = [], [], []
   for i in range(n):
-    x1, P1, y1 = f._update_python(xs[i].reshape(-1, 1).copy(), Ps[i].copy(), 2, zs[i].copy(), FK.obs_noise[2].copy(), extra_args=eas[i].copy())  # pylint: disable=protected-access
+    x1, P1, y1 = f._update_python(xs[i].reshape(-1, 1).copy(), Ps[i].copy(), 2, zs[i].copy(), np.eye(ZF) * 0.01**2, extra_args=eas[i].copy())  # pylint: disable=protected-access
     ux.append(np.ravel(x1)); uP.append(P1); uy.append(np.ravel(y1))
   out = {k: np.array(v) for k, v in recs.items()}
-  np.savez_compressed(os.path.join(GOLD, "feature_stream.npz"), **out, upd_x_in=xs, upd_P_in=Ps, upd_ea=eas, upd_z=zs,
+  np.savez_compressed(os.path.join(GOLD, out_name), **out, upd_x_in=xs, upd_P_in=Ps, upd_ea=eas, upd_z=zs,
                       upd_x=np.array(ux), upd_P=np.array(uP), upd_y=np.array(uy))
   print("feature stream: final x[:6]", out["x_after"][-1][:6], "y dims", {len(np.ravel(e)) for e in uy})
 
@@ -337,5 +339,6 @@ if __name__ == "__main__":
   maha_goldens()
   kinematic9_goldens()
   feature_goldens()
+  feature_goldens(T=15, cls_name="WideFeatureKalman", out_name="feature36_stream.npz", n_upd=6)
   for fn in sorted(os.listdir(GOLD)):
     print(fn, os.path.getsize(os.path.join(GOLD, fn)))

@@ -26,12 +26,17 @@ from rednose_amd.codegen.emit_common import SMat, term, sum_terms
 
 def group_lanes(spec):
   """Lanes per filter in the matrix phase: one lane per row/column of P, groups packed back to back."""
-  return 32 if filters_per_wave(spec) == 2 else spec.dim_err     # two groups: one per 32-lane half (fewest LDS conflicts)
+  fpw = filters_per_wave(spec)
+  if fpw == 1:
+    return 64              # 33 .. 64 error states: the whole wavefront works on one filter
+  return 32 if fpw == 2 else spec.dim_err     # two groups: one per 32-lane half (fewest LDS conflicts)
 
 
 def filters_per_wave(spec):
   """Filters whose covariance algebra one wavefront does at a time (64 // dim_err, e.g. 3 for 21 error states:
   63 of 64 lanes busy instead of 42 with two 32-lane groups)."""
+  if spec.dim_err > 32:
+    return 1
   fpw = tuning.current().wide_fpw
   return fpw if fpw else max(2, 64 // spec.dim_err)
 

@@ -29,6 +29,7 @@ enum Status : int {
   ERR_HIP = 1,         // a HIP runtime call failed (no device, launch failure, ...)
   ERR_ARG = 2,         // null / negative / unknown-kind argument
   ERR_ALIGN = 3,       // device pointer not 16-byte aligned
+  ERR_UNSUPPORTED = 4, // entry point not generated for this model (e.g. fused run above 32 error states)
 };
 
 struct ErrorState {

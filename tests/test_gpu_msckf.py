@@ -11,24 +11,30 @@ from conftest import assert_close, golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def env():
+@pytest.fixture(scope="module", params=["feature", "feature36"])
+def env(request):
+  """feature: 15 error states, 4 filters per wavefront; feature36: 36 error states, one filter per wavefront."""
   import torch
   assert torch.cuda.is_available()
   from examples import ensure_generated
-  from examples.feature_kf import FeatureKalman
-  return torch, ensure_generated(["feature"]), FeatureKalman
+  from examples.feature_kf import FeatureKalman, WideFeatureKalman
+  FK = {"feature": FeatureKalman, "feature36": WideFeatureKalman}[request.param]
+  return torch, ensure_generated([request.param]), FK
 
 
 def _filter(env, n):
   torch, gen, FK = env
   from rednose_amd.helpers.ekf_sym import BatchedEKF
-  return BatchedEKF(gen, "feature", FK.Q, FK.initial_x, np.diag(FK.initial_P_diag), 6, 6, batch=n, **FK.filter_kwargs())
+  return BatchedEKF(gen, FK.name, FK.Q, FK.initial_x, np.diag(FK.initial_P_diag), 6, 6, batch=n, **FK.filter_kwargs())
+
+
+def _gold(env):
+  return golden("feature_stream.npz" if env[2].name == "feature" else "feature36_stream.npz")
 
 
 def test_feature_updates_vs_reference_numpy(env):
   torch, gen, FK = env
-  g = golden("feature_stream.npz")
+  g = _gold(env)
   n = g["upd_x_in"].shape[0]
   f = _filter(env, n)
   f.init_state(g["upd_x_in"], g["upd_P_in"], 0.0)
@@ -47,10 +53,11 @@ def test_both_kinds_vs_oracle_strict(env, n):
   """Random states; fused predict+update and split launches; tiles of 16 filters in groups of 4."""
   torch, gen, FK = env
   from oracle_lib import OracleLib
-  o = OracleLib("feature")
+  o = OracleLib(FK.name)
+  D = FK.dim_state
   rng = np.random.default_rng(50 + n)
-  x0 = np.tile(FK.initial_x, (n, 1)) + rng.normal(size=(n, 15)) * 0.3
-  A = rng.normal(size=(n, 15, 15)) * 0.2
+  x0 = np.tile(FK.initial_x, (n, 1)) + rng.normal(size=(n, D)) * 0.3
+  A = rng.normal(size=(n, D, D)) * 0.2
   P0 = np.diag(FK.initial_P_diag)[None] + A @ A.transpose(0, 2, 1)
   landmarks = np.array([2.0, 1.0, 8.0])[None] + rng.normal(size=(n, 3))
   f = _filter(env, n)
@@ -78,7 +85,7 @@ def test_stream_with_window_shifts_vs_reference_numpy(env):
   """The golden stream: POSITION fixes followed by augment(), FEATURE tracks in between, every step against the
   reference's numpy filter (including the state after each window shift)."""
   torch, gen, FK = env
-  g = golden("feature_stream.npz")
+  g = _gold(env)
   n = 6
   f = _filter(env, n)
   for t in range(len(g["ts"])):
@@ -119,8 +126,8 @@ def test_scalar_abi_feature_update(env):
   """The drop-in host-pointer entry point {name}_update_{kind}(x, P, z, R, ea) of the reference, batch of one."""
   torch, gen, FK = env
   from rednose_amd.helpers.ekf_sym import EKF_sym
-  g = golden("feature_stream.npz")
-  f = EKF_sym(gen, "feature", FK.Q, FK.initial_x, np.diag(FK.initial_P_diag), 6, 6, **FK.filter_kwargs())
+  g = _gold(env)
+  f = EKF_sym(gen, FK.name, FK.Q, FK.initial_x, np.diag(FK.initial_P_diag), 6, 6, **FK.filter_kwargs())
   assert f.feature_track_kinds == [2]
   for i in range(3):
     x, P, z = g["upd_x_in"][i].copy(), g["upd_P_in"][i].copy(), g["upd_z"][i].copy()
@@ -130,5 +137,5 @@ def test_scalar_abi_feature_update(env):
   He = np.zeros((6, 3))
   f.Hes[2](g["upd_x_in"][0].copy(), g["upd_ea"][0].copy(), He)
   from oracle_lib import OracleLib
-  want = np.zeros(18); OracleLib("feature").call("He_2", g["upd_x_in"][0].copy(), g["upd_ea"][0].copy(), want)
+  want = np.zeros(18); OracleLib(FK.name).call("He_2", g["upd_x_in"][0].copy(), g["upd_ea"][0].copy(), want)
   assert_close(He.reshape(-1), want)
