@@ -47,6 +47,19 @@ def test_known_answer_scalar_abi_on_gpu(gen_dir, torch_cuda):
   assert_close(kf.P.reshape(-1), g["Ps"][-1].reshape(-1), rtol=1e-10, floor=1e-12)
 
 
+def test_pyx_named_class_is_the_same_orchestrator(gen_dir, torch_cuda):
+  """Models written for the reference construct `EKF_sym_pyx(gen_dir, name, Q, x0, P0, dim, dim_err, ...)`
+  (/root/reference/examples/kinematic_kf.py:69, ekf_sym_pyx.pyx:87-90)."""
+  from rednose_amd.helpers.ekf_sym_pyx import EKF_sym_pyx
+  g = golden("kinematic_stream.npz")
+  f = EKF_sym_pyx(gen_dir, "kinematic", np.diag([0.1**2, 2.0**2]), np.array([0.5, 0.0]), np.eye(2), 2, 2)
+  for t, meas in zip(g["ts"][:50], g["zs"][:50]):
+    est = f.predict_and_update_batch(t, 1, np.array([[meas]]), np.array([[[0.1**2]]]))
+  assert len(est) == 9
+  assert_close(f.state(), g["xs"][49], rtol=1e-10, floor=1e-12)
+  assert_close(f.covs().reshape(-1), g["Ps"][49].reshape(-1), rtol=1e-10, floor=1e-12)
+
+
 def test_scalar_sympy_routines_on_gpu(gen_dir, torch_cuda):
   from oracle_lib import OracleLib
   from rednose_amd.helpers.ekf_sym import EKF_sym
