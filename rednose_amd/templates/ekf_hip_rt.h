@@ -368,6 +368,16 @@ __device__ __forceinline__ double fast_recip(const double d) {
   return r;
 }
 
+// 1 / sqrt(a) for a > 0: v_rsq_f64 seed + two Newton steps (same reasoning as fast_recip: sqrt followed by an IEEE
+// division is ~100 dependent instructions per pivot of a Cholesky factorisation).
+__device__ __forceinline__ double fast_rsqrt(const double a) {
+  double y = __builtin_amdgcn_rsq(a);
+  const double h = 0.5 * a;
+  y = fma(y, fma(-h * y, y, 0.5), y);
+  y = fma(y, fma(-h * y, y, 0.5), y);
+  return y;
+}
+
 // ---- left null space of the extra-argument Jacobian (MSCKF, /root/reference/rednose/templates/ekf_c.c:66-76) --------
 // The reference projects the residual, H and R of a feature-track observation on A = kernel(Hea^T) (Eigen fullPivLu;
 // numpy twin: SVD null space, ekf_sym.py:20-26,583).  Any basis of that null space gives the same x and P; we use the

@@ -267,4 +267,235 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
   }
 }
 
+// Compiler-only fence between the iterations of the unrolled loops below: without it hipcc hoists the LDS reads of ALL
+// iterations to the top (hundreds of live values: 512 registers + 317 spills); with it the live set is one iteration's.
+#ifndef RN_RTS_FENCE
+#define RN_RTS_FENCE()
+#endif
+
+// ---- lane-group models with a generated sparse predict (Model::SPARSE): register-resident solves -----------------------
+// Same recursion and quirks as k_rts below; what differs is where the work lives.  Lane c keeps its row of the Cholesky
+// factor, its right-hand side / solution column and its rows of T = Ck (Pk1_n - Pk1_k) and Pk_n in REGISTERS; LDS holds
+// only what other lanes must see (the factor, Ck, the difference matrix, Pk1_n) and every LDS read is a broadcast or a
+// lane-private row, issued from fully unrolled code so that none of them sits on a dependent chain:
+//   * Cholesky, left-looking: at column j every lane reads pivot row j (final since step j-1) and forms BOTH its own
+//     entry and the pivot redundantly -> no publish / wait round trip per column (the rolled version paid two wave
+//     syncs + sqrt + division per column); reciprocal square root by v_rsq_f64 + Newton.
+//   * forward / back substitution, right-looking on the register column: as soon as y[m] is final, all later entries are
+//     updated by independent FMAs.
+//   * the filtered pair of step k-1 streams HBM -> LDS (global_load_lds) while step k computes; Pk_k's row is taken to
+//     registers first, so one buffer suffices.
+// LDS: 4 E x E matrices per filter (35 KB per wave for E = 22, 4 waves per CU) instead of 7 (51 KB, 3 waves).
+template <class Model>
+__global__ __launch_bounds__(64) void k_rts_wide(const double* __restrict__ xf, const double* __restrict__ Pf,
+                                                 const double* __restrict__ ts, const int64_t T,
+                                                 const double* __restrict__ gQ, const int64_t n, const int norm_quats,
+                                                 double* __restrict__ xs, double* __restrict__ Ps) {
+  constexpr int D = Model::D, E = Model::E, EE = E * E, GL = 32, FPW = 2;
+  constexpr int DP = D + (D & 1);
+  constexpr int ABUF = (FPW * EE + 3) / 2 * 2, XBUF = (FPW * D + 3) / 2 * 2;
+  __shared__ __attribute__((aligned(16))) double s_A[ABUF];       // Pk_k staging, prefetched one step ahead
+  __shared__ __attribute__((aligned(16))) double s_L[FPW * EE];   // Pk1_k -> its Cholesky factor -> Ck
+  __shared__ __attribute__((aligned(16))) double s_D[FPW * EE];   // Pk1_n - Pk1_k
+  __shared__ __attribute__((aligned(16))) double s_N[FPW * EE];   // Pk1_n; also the staging of the smoothed output
+  __shared__ __attribute__((aligned(16))) double s_Q[EE];
+  __shared__ __attribute__((aligned(16))) double s_xin[XBUF];     // xk_k staging, prefetched
+  __shared__ __attribute__((aligned(16))) double s_x[FPW * DP];   // smoothed state going out
+  __shared__ __attribute__((aligned(16))) double s_xk[2 * FPW * DP];  // xk_k and xk1_k parked during the factorisation
+  __shared__ __attribute__((aligned(16))) double s_xn[FPW * DP];      // xk1_n, the smoothed state of step k+1
+  __shared__ __attribute__((aligned(16))) double s_il[FPW * E];       // reciprocal pivots of the factor
+  __shared__ __attribute__((aligned(16))) double s_d[FPW * E];
+
+  const int lane = threadIdx.x;
+  const int g = lane / GL;
+  const int c = lane % GL;
+  const bool act = c < E;
+  const int cc = act ? c : 0;
+  copy_g2l<EE>(gQ, EE, s_Q, lane);
+  const int64_t tiles = (n + FPW - 1) / FPW;
+
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t base = tile * FPW;
+    const int cnt = (n - base) < FPW ? (int)(n - base) : FPW;
+    const int gg = g < cnt ? g : 0;
+    const bool on = act && g < cnt;
+    double* L = s_L + gg * EE;
+    double* Dm = s_D + gg * EE;
+    double* Nn = s_N + gg * EE;
+    double* sd = s_d + gg * E;
+    double* sxk = s_xk + gg * 2 * DP;
+    double* sxn = s_xn + gg * DP;
+    double* sil = s_il + gg * E;
+
+    if (T >= 2) {
+      async_copy_g2l_any<ABUF>(Pf + ((T - 2) * n + base) * EE, cnt * EE, s_A, lane);
+      async_copy_g2l_any<XBUF>(xf + ((T - 2) * n + base) * D, cnt * D, s_xin, lane);
+    }
+    for (int64_t k = T - 2; k >= 0; k--) {
+      // ---- the filtered pair of step k has landed: row c of Pk_k and xk_k to registers, then reuse the buffers ------
+      const int shA = odd_start(Pf + (k * n + base) * EE), shx = odd_start(xf + (k * n + base) * D);
+      const double dt = ts[k + 1] - ts[k];
+      async_wait();
+      wave_lds_sync();
+      double xk[D], x1k[D], prow[E];
+#pragma unroll
+      for (int i = 0; i < D; i++) xk[i] = s_xin[shx + gg * D + i];
+#pragma unroll
+      for (int j = 0; j < E; j++) prow[j] = s_A[shA + gg * EE + cc * E + j];
+      wave_lds_sync();
+      if (k >= 1) {
+        async_copy_g2l_any<ABUF>(Pf + ((k - 1) * n + base) * EE, cnt * EE, s_A, lane);
+        async_copy_g2l_any<XBUF>(xf + ((k - 1) * n + base) * D, cnt * D, s_xin, lane);
+      }
+
+      // ---- predicted pair of step k+1, recomputed with the forward kernels' generated sparse predict -------------------
+      const bool first = (k == T - 2);     // recursion start: smoothed(T-1) := predicted(T-1)  (estimates[-1][0], [2])
+      double y[E];
+      {
+        double p1col[E], pk[E], xn1[D];
+#pragma unroll
+        for (int j = 0; j < E; j++) pk[j] = prow[j];
+#pragma unroll
+        for (int i = 0; i < D; i++) x1k[i] = xk[i];
+        Model::predict_cov(x1k, prow, y, p1col, L, s_Q, dt, cc, on);        // L <- Pk1_k, y <- column c of M = Fk Pk_k^T
+        if (norm_quats) Model::normalize(x1k);
+        if (on) {
+#pragma unroll
+          for (int i = 0; i < E; i++) {
+            if (first) Nn[i * E + c] = p1col[i];
+            Dm[i * E + c] = Nn[i * E + c] - p1col[i];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < D; i++) xn1[i] = first ? x1k[i] : sxn[i];
+        if (norm_quats) Model::normalize(xn1);
+        wave_lds_sync();
+        // smoothed step k+1 is final now: write it out (state after the in-place renormalisation).  The replicated state
+        // vectors wait in LDS until the state update (in registers they would hold ~140 VGPRs through the factorisation)
+        if (c == 0 && g < cnt) {
+#pragma unroll
+          for (int i = 0; i < D; i++) { s_x[g * D + i] = xn1[i]; sxn[i] = xn1[i]; sxk[i] = xk[i]; sxk[DP + i] = x1k[i]; }
+        }
+        wave_lds_sync();
+        copy_l2g<FPW * D>(xs + ((k + 1) * n + base) * D, cnt * D, s_x, lane);
+        copy_l2g<FPW * EE>(Ps + ((k + 1) * n + base) * EE, cnt * EE, s_N, lane);
+        // Pk1_n has been consumed (difference formed, output issued): its row c now parks row c of Pk_k until the end of
+        // the step, where the smoothed Pk_n is accumulated on top of it
+        wave_lds_sync();
+        if (on) {
+#pragma unroll
+          for (int j = 0; j < E; j++) Nn[c * E + j] = pk[j];
+        }
+      }
+
+      // ---- Cholesky of Pk1_k: lane c owns row c in registers, pivot rows are broadcast from LDS ---------------------------
+      double lrow[E];
+#pragma unroll
+      for (int j = 0; j < E; j++) lrow[j] = L[cc * E + j];
+#pragma unroll
+      for (int j = 0; j < E; j++) {
+        double s = lrow[j], sj = L[j * E + j];
+#pragma unroll
+        for (int m = 0; m < j; m++) {
+          const double r = L[j * E + m];          // final: written by lane j at step m
+          s = fma(-lrow[m], r, s);
+          sj = fma(-r, r, sj);
+        }
+        const double ilj = fast_rsqrt(sj);
+        lrow[j] = (c == j) ? sj * ilj : s * ilj;
+        if (on && c >= j) L[c * E + j] = lrow[j];   // rows from the pivot down publish their entry; LDS is in-order within the wave
+        if (c == j && g < cnt) sil[j] = ilj;
+        RN_RTS_FENCE();
+      }
+      wave_lds_sync();
+      // ---- Ck^T = Pk1_k^-1 M: lane c solves for column c in registers (right-looking substitutions) -------------------
+#pragma unroll
+      for (int m = 0; m < E; m++) {
+        y[m] *= sil[m];
+#pragma unroll
+        for (int i = m + 1; i < E; i++) y[i] = fma(-L[i * E + m], y[m], y[i]);
+        RN_RTS_FENCE();
+      }
+#pragma unroll
+      for (int m = E - 1; m >= 0; m--) {
+        y[m] *= sil[m];
+#pragma unroll
+        for (int i = 0; i < m; i++) y[i] = fma(-L[m * E + i], y[m], y[i]);
+        RN_RTS_FENCE();
+      }
+      // y is column c of X = Ck^T, i.e. row c of Ck; the factor is dead: its buffer takes Ck^T (column c written by lane c)
+      wave_lds_sync();
+      if (on) {
+#pragma unroll
+        for (int j = 0; j < E; j++) L[j * E + c] = y[j];
+      }
+      // ---- state: delta = Ck inv_err(xk1_k, xk1_n); xk_n = err(xk_k, delta) -------------------------------
+      {
+        double delta[E], xa[D], xb[D], xn1[D];
+#pragma unroll
+        for (int i = 0; i < D; i++) { xa[i] = sxk[i]; xb[i] = sxk[DP + i]; xn1[i] = sxn[i]; }
+        Model::inv_err(xb, xn1, delta);
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int j = 0; j + 1 < E; j += 2) { s0 = fma(y[j], delta[j], s0); s1 = fma(y[j + 1], delta[j + 1], s1); }
+        if (E & 1) s0 = fma(y[E - 1], delta[E - 1], s0);
+        if (on) sd[c] = s0 + s1;
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < E; j++) delta[j] = sd[j];
+        Model::err(xa, delta, xn1);          // xk_n, becomes xk1_n of the next (older) step
+        if (c == 0 && g < cnt) {
+#pragma unroll
+          for (int i = 0; i < D; i++) sxn[i] = xn1[i];
+        }
+      }
+      // ---- covariance: Pk_n = Pk_k + (Ck Dm) Ck^T, row c in registers ---------------------------------------
+      double trow[E];
+#pragma unroll
+      for (int m = 0; m < E; m++) trow[m] = 0.0;
+#pragma unroll
+      for (int j = 0; j < E; j++) {
+#pragma unroll
+        for (int m = 0; m < E; m++) trow[m] = fma(y[j], Dm[j * E + m], trow[m]);     // row j of Dm: contiguous broadcast
+        RN_RTS_FENCE();
+      }
+      double nn[E];
+#pragma unroll
+      for (int m = 0; m < E; m++) nn[m] = Nn[cc * E + m];       // row c of Pk_k, parked there at the top of the step
+#pragma unroll
+      for (int j = 0; j < E; j++) {
+#pragma unroll
+        for (int m = 0; m < E; m++) nn[m] = fma(trow[j], L[j * E + m], nn[m]);      // row j of Ck^T: contiguous broadcast
+        RN_RTS_FENCE();
+      }
+      if (on) {
+#pragma unroll
+        for (int m = 0; m < E; m++) Nn[c * E + m] = nn[m];   // Pk1_n of the next (older) step
+      }
+      wave_lds_sync();
+    }
+    // the oldest smoothed state goes out un-normalised (ekf_sym.py:665-667 never reaches it)
+    if (T >= 2) {
+      wave_lds_sync();
+      if (c == 0 && g < cnt) {
+#pragma unroll
+        for (int i = 0; i < D; i++) s_x[g * D + i] = sxn[i];
+      }
+      wave_lds_sync();
+      copy_l2g<FPW * D>(xs + base * D, cnt * D, s_x, lane);
+      copy_l2g<FPW * EE>(Ps + base * EE, cnt * EE, s_N, lane);
+      wave_lds_sync();
+    }
+    // T == 1: nothing to smooth, the single estimate's predicted pair is not available -> copy filtered through
+    if (T == 1) {
+      copy_g2l<FPW * EE>(Pf + base * EE, cnt * EE, s_L, lane);
+      copy_g2l<FPW * D>(xf + base * D, cnt * D, s_x, lane);
+      wave_lds_sync();
+      copy_l2g<FPW * EE>(Ps + base * EE, cnt * EE, s_L, lane);
+      copy_l2g<FPW * D>(xs + base * D, cnt * D, s_x, lane);
+      wave_lds_sync();
+    }
+  }
+}
+
 }  // namespace rn
