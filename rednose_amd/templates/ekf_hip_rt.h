@@ -13,6 +13,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <utility>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -366,6 +367,18 @@ __device__ __forceinline__ double fast_recip(const double d) {
   r = fma(fma(-d, r, 1.0), r, r);
   r = fma(fma(-d, r, 1.0), r, r);
   return r;
+}
+
+// Compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}).  Unlike
+// `#pragma unroll`, the body may contain scheduling barriers (hipcc does not duplicate those when unrolling, which turns
+// register arrays indexed by the loop variable into scratch).
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 // 1 / sqrt(a) for a > 0: v_rsq_f64 seed + two Newton steps (same reasoning as fast_recip: sqrt followed by an IEEE

@@ -267,12 +267,6 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
   }
 }
 
-// Compiler-only fence between the iterations of the unrolled loops below: without it hipcc hoists the LDS reads of ALL
-// iterations to the top (hundreds of live values: 512 registers + 317 spills); with it the live set is one iteration's.
-#ifndef RN_RTS_FENCE
-#define RN_RTS_FENCE()
-#endif
-
 // ---- lane-group models with a generated sparse predict (Model::SPARSE): register-resident solves -----------------------
 // Same recursion and quirks as k_rts below; what differs is where the work lives.  Lane c keeps its row of the Cholesky
 // factor, its right-hand side / solution column and its rows of T = Ck (Pk1_n - Pk1_k) and Pk_n in REGISTERS; LDS holds
@@ -285,7 +279,15 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
 //     updated by independent FMAs.
 //   * the filtered pair of step k-1 streams HBM -> LDS (global_load_lds) while step k computes; Pk_k's row is taken to
 //     registers first, so one buffer suffices.
-// LDS: 4 E x E matrices per filter (35 KB per wave for E = 22, 4 waves per CU) instead of 7 (51 KB, 3 waves).
+// LDS: 4 E x E matrices per filter (36 KB per wave for E = 22, 4 waves per CU) instead of 7 (51 KB, 3 waves).
+// Measured (live, 16 384 filters): 26.5 us per step and wavefront against ~42 us for k_rts; timing with phases removed
+// puts ~20 us of that in the factorisation -- a serial chain of (j + 10) DEPENDENT fp64 operations per column j
+// (dot product, v_rsq_f64 + two Newton steps, scaling) plus an LDS write -> broadcast-read turnaround, on a wavefront
+// that is alone on its SIMD (LDS holds 8 filters per CU).  Things that did NOT help, measured: 4 partial sums per dot
+// product (+12 %: more instructions, same chain through the pivot), __builtin_amdgcn_sched_barrier / asm memory fences /
+// never-taken aliasing stores between unrolled iterations (each sends the register allocator to 6 KB of scratch per lane),
+// per-column predicates (one exec mask per column is hoisted out of the step loop: 190 SGPR spills; a single predicate
+// and harmless stores above the pivot brought that to 61).
 template <class Model>
 __global__ __launch_bounds__(64) void k_rts_wide(const double* __restrict__ xf, const double* __restrict__ Pf,
                                                  const double* __restrict__ ts, const int64_t T,
@@ -403,9 +405,10 @@ __global__ __launch_bounds__(64) void k_rts_wide(const double* __restrict__ xf, 
         }
         const double ilj = fast_rsqrt(sj);
         lrow[j] = (c == j) ? sj * ilj : s * ilj;
-        if (on && c >= j) L[c * E + j] = lrow[j];   // rows from the pivot down publish their entry; LDS is in-order within the wave
-        if (c == j && g < cnt) sil[j] = ilj;
-        RN_RTS_FENCE();
+        // every row publishes its entry (rows above the pivot write a value nobody reads: one predicate for the whole
+        // factorisation instead of one exec mask per column) and the pivot reciprocal, identical in all lanes of the group;
+        // LDS is in-order within the wave, so the next column's broadcast reads see these stores
+        if (on) { L[c * E + j] = lrow[j]; sil[j] = ilj; }
       }
       wave_lds_sync();
       // ---- Ck^T = Pk1_k^-1 M: lane c solves for column c in registers (right-looking substitutions) -------------------
@@ -414,14 +417,12 @@ __global__ __launch_bounds__(64) void k_rts_wide(const double* __restrict__ xf, 
         y[m] *= sil[m];
 #pragma unroll
         for (int i = m + 1; i < E; i++) y[i] = fma(-L[i * E + m], y[m], y[i]);
-        RN_RTS_FENCE();
       }
 #pragma unroll
       for (int m = E - 1; m >= 0; m--) {
         y[m] *= sil[m];
 #pragma unroll
         for (int i = 0; i < m; i++) y[i] = fma(-L[m * E + i], y[m], y[i]);
-        RN_RTS_FENCE();
       }
       // y is column c of X = Ck^T, i.e. row c of Ck; the factor is dead: its buffer takes Ck^T (column c written by lane c)
       wave_lds_sync();
@@ -457,16 +458,14 @@ __global__ __launch_bounds__(64) void k_rts_wide(const double* __restrict__ xf, 
       for (int j = 0; j < E; j++) {
 #pragma unroll
         for (int m = 0; m < E; m++) trow[m] = fma(y[j], Dm[j * E + m], trow[m]);     // row j of Dm: contiguous broadcast
-        RN_RTS_FENCE();
       }
       double nn[E];
 #pragma unroll
-      for (int m = 0; m < E; m++) nn[m] = Nn[cc * E + m];       // row c of Pk_k, parked there at the top of the step
+      for (int m = 0; m < E; m++) nn[m] = Nn[cc * E + m];
 #pragma unroll
       for (int j = 0; j < E; j++) {
 #pragma unroll
         for (int m = 0; m < E; m++) nn[m] = fma(trow[j], L[j * E + m], nn[m]);      // row j of Ck^T: contiguous broadcast
-        RN_RTS_FENCE();
       }
       if (on) {
 #pragma unroll
