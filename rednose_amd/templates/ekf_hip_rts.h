@@ -287,7 +287,10 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
 // product (+12 %: more instructions, same chain through the pivot), __builtin_amdgcn_sched_barrier / asm memory fences /
 // never-taken aliasing stores between unrolled iterations (each sends the register allocator to 6 KB of scratch per lane),
 // per-column predicates (one exec mask per column is hoisted out of the step loop: 190 SGPR spills; a single predicate
-// and harmless stores above the pivot brought that to 61).
+// and harmless stores above the pivot brought that to 61).  A variant with only two LDS matrices per filter (rows of
+// Pk1_n carried in registers, the prefetch landing in the dead difference matrix: 18 KB per wave, enough for two waves
+// per SIMD) needs <= 256 registers for that, and the generated predict alone keeps ~270 live: 1 264 spilled VGPRs under
+// every -amdgpu-sched-strategy, so it was dropped.
 template <class Model>
 __global__ __launch_bounds__(64) void k_rts_wide(const double* __restrict__ xf, const double* __restrict__ Pf,
                                                  const double* __restrict__ ts, const int64_t T,
