@@ -118,6 +118,8 @@ def run_model(torch, dist, args, model, n, K, W, dev, rank, world):
     from examples.kinematic6_kf import Kinematic6Kalman as M
   elif model == "kinematic":
     from examples.kinematic_kf import KinematicKalman as M
+  elif model == "kinematic9":
+    from examples.kinematic9_kf import Kinematic9Kalman as M
   else:
     from examples.live_kf import LiveKalman as M
   if rank == 0:
@@ -216,7 +218,8 @@ def main():
 
   extra = {}
   if not args.no_extras and world == 1:
-    others = {"kinematic6": [("live", 16384, 420, 42), ("kinematic", 65536, 500, 50), ("kinematic6", 1 << 20, 200, 20)],
+    others = {"kinematic6": [("live", 16384, 420, 42), ("kinematic", 65536, 500, 50), ("kinematic6", 1 << 20, 200, 20),
+                             ("kinematic9", 65536, 300, 30)],
               "live": [], "kinematic": []}[args.model]
     for om, on, oK, oW in others:
       o = run_model(torch, dist, args, om, on, oK, oW, dev, rank, world)
@@ -251,6 +254,34 @@ def main():
                           "note": "state resident in VGPRs for T steps; bound by fp64 VALU issue, not HBM"}
 
   if not args.no_extras and world == 1 and args.model == "kinematic6":
+    # MSCKF: null-space projected feature-track updates of the windowed-camera example, 36 error
+    # states, per-filter landmarks; timed through the generic Python method (no pre-bound variant takes extra arguments)
+    from examples import ensure_generated
+    from examples.feature_kf import WideFeatureKalman as FK
+    from rednose_amd.helpers.ekf_sym import BatchedEKF
+    genf = ensure_generated(["feature36"])
+    nf, Kf = 16384, 100
+    ff = BatchedEKF(genf, FK.name, FK.Q, FK.initial_x, np.diag(FK.initial_P_diag), 6, 6, batch=nf, device=dev, **FK.filter_kwargs())
+    lm = torch.tensor([2.0, 1.0, 8.0], dtype=torch.float64, device=dev) + torch.randn((nf, 3), dtype=torch.float64, device=dev)
+    zf = [0.05 * torch.randn((nf, 6), dtype=torch.float64, device=dev) for _ in range(8)]
+    for i in range(10):
+      ff.predict_and_update_batch(0.01 * (i + 1), 2, zf[i % 8].clone(), FK.obs_noise[2], extra_args=lm)
+    zc = [zf[i % 8].clone() for i in range(Kf)]
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(Kf):
+      ff.predict_and_update_batch(0.01 * (i + 11), 2, zc[i], FK.obs_noise[2], extra_args=lm)
+    e1.record()
+    torch.cuda.synchronize()
+    assert torch.isfinite(ff.x).all() and torch.isfinite(ff.P).all()
+    msf = e0.elapsed_time(e1) / Kf
+    bf = 8.0 * (2 * (36 + 36 * 36) + 6 + 3 + 3)
+    extra["feature36_msckf"] = {"batch": nf, "steps": Kf, "value": nf / (msf * 1e-3), "unit": "steps/s", "launch_us": msf * 1e3,
+                                "algorithmic_bytes_per_filter_step": bf, "frac_of_8TBs": bf * nf / (msf * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "note": "fused predict + feature-track update (Z = 6 projected to 3), one filter per wavefront"}
+    del ff, zf, zc
+
     # BASELINE config 4: live with the Mahalanobis gate on ECEF_POS, forward pass keeping the filtered trace, then the
     # batched RTS backward pass.  T = 210 steps (1 s of IMU@100Hz + GNSS@10Hz), batch 16384, 2 % GNSS outliers.
     from examples import ensure_generated
