@@ -185,7 +185,7 @@ def main():
   ap.add_argument("--steps", type=int, default=2000)
   ap.add_argument("--warmup", type=int, default=100)
   ap.add_argument("--batch", type=int, default=None, help="filters per GPU (default 65536; 16384 for --model live)")
-  ap.add_argument("--model", default="kinematic6", choices=["kinematic6", "kinematic", "live"])
+  ap.add_argument("--model", default="kinematic6", choices=["kinematic6", "kinematic", "kinematic9", "live"])
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-extras", action="store_true", help="skip the additional configs reported under 'extra'")
   args = ap.parse_args()
@@ -220,7 +220,7 @@ def main():
   if not args.no_extras and world == 1:
     others = {"kinematic6": [("live", 16384, 420, 42), ("kinematic", 65536, 500, 50), ("kinematic6", 1 << 20, 200, 20),
                              ("kinematic9", 65536, 300, 30)],
-              "live": [], "kinematic": []}[args.model]
+              "live": [], "kinematic": [], "kinematic9": []}[args.model]
     for om, on, oK, oW in others:
       o = run_model(torch, dist, args, om, on, oK, oW, dev, rank, world)
       ls = o["dev_ms"] * 1e-3 / oK

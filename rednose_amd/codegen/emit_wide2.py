@@ -60,7 +60,18 @@ def _odd(n):
 def tile_filters(spec):
   """Filters per wavefront tile: the tuning value rounded up to whole groups."""
   fpw = filters_per_wave(spec)
-  return -(-tuning.current().wide_ft // fpw) * fpw
+  ft = tuning.current().wide_ft
+  if ft == 0:      # auto: small records (<= 16 error states) -> two groups per tile, several wavefronts per SIMD; else 16
+    ft = 2 * fpw if spec.dim_err <= 16 else 16
+  return -(-ft // fpw) * fpw
+
+
+def double_buffered(spec):
+  """Asynchronous double-buffered prefetch of the next group's covariance records, or a single buffer.  With small records
+  several wavefronts fit per SIMD and hide each other's HBM latency, and the second buffer only costs occupancy
+  (kinematic9: 25.5-26.3 us per launch with a single buffer and tiles of 14 filters, 30.5 us with the live-tuned 16 / double)."""
+  db = tuning.current().wide_db
+  return bool(db) if db >= 0 else spec.dim_err > 16
 
 
 class Layout:
@@ -419,7 +430,7 @@ def kernels(spec):
     A(f"{tmpl}__global__ {lbs} void {kname}(double* __restrict__ gx, double* __restrict__ gP,")
     A(f"    {sig_obs}const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,")
     A(f"    const int norm_quats{flags_arg}) {{")
-    DB = 1 if tune.wide_db else 0
+    DB = 1 if double_buffered(spec) else 0
     ODD = (FPW * EE) % 2 == 1 or (FT * EE) % 2 == 1       # can a group's record start on an odd double?
     PBUF = (FPW * EE + (3 if ODD else 1)) // 2 * 2      # one slack double for the shifted image, whole 16-byte vectors
     CPIN = "rn::async_copy_g2l_any" if ODD else "rn::async_copy_g2l"

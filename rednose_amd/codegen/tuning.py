@@ -6,13 +6,17 @@ environment variable RN_TUNE, e.g.  RN_TUNE="wide_ft=8,wide_lb=2" python bench.p
 
   knob          default  measured alternatives (live = 23/22-state ESKF, batch 16 384; k6 = kinematic6, batch 65 536)
   wide_struct   2        1 = scalars evaluated redundantly in all 32 lanes of a group: live 122 us/launch vs 47 us
-  wide_ft       16       filters per wavefront tile: 8 -> 52.8 us, 32 -> LDS allows only 3 waves per CU
+  wide_ft       0 (auto) filters per wavefront tile; auto = 16 above 16 error states (live: 8 -> 52.8 us, 32 -> LDS allows only
+                         3 waves per CU), two groups below (kinematic9, 7 filters per group: 14 -> 25.5-26.3 us with a single
+                         buffer, 7 -> 31.2, 21 -> 28.6, 28 -> 28.3; with the double buffer 16 -> 30.5, 42 -> 36.4, 63 -> 47.7)
   wide_lb       0        second argument of __launch_bounds__ (waves per SIMD): 2 forces <= 256 registers, hipcc then
                          spills 64-172 VGPRs to scratch: 87-138 us (0 = unconstrained, 1 wave per SIMD, 47 us)
-  wide_db       1        double-buffered asynchronous P prefetch; 0 = single buffer (only sensible with wide_lb=2)
+  wide_db       -1 (auto) double-buffered asynchronous P prefetch (1) or single buffer (0); auto = double above 16 error states
+                         (one wavefront per SIMD there: nothing else hides the HBM latency), single below
   wide_inline   1        0 = phase functions __noinline__: each fits 256 registers but pays scratch frames: 237 us
   wide_fpw      0        filters per wavefront in the matrix phase: 0 = 64 // dim_err (dim_err-lane groups when that is > 2, e.g. 7 filters
-                         for 9 error states; live's 22 error states fit twice: two 32-lane groups); 2 = always two groups
+                         for 9 error states: kinematic9 30.2 us vs 45.8 us with two groups; live's 22 error states fit twice: two
+                         32-lane groups); 2 = always two groups
   wide_lean     0        1 = covariance rows stay in LDS (in-place rank-Z pass, only the columns He touches are read, Q from
                          LDS): 199-229 VGPRs instead of 256 + 84..234 AGPRs, two waves per SIMD without spills -- but live
                          46.4 us/launch at 1 wave/SIMD and 44.4 us at 2 waves/SIMD (ft=4, lb=2, db=0; smaller tiles repeat the
@@ -34,9 +38,9 @@ from dataclasses import dataclass, fields
 @dataclass(frozen=True)
 class Tuning:
   wide_struct: int = 2
-  wide_ft: int = 16
+  wide_ft: int = 0
   wide_lb: int = 0
-  wide_db: int = 1
+  wide_db: int = -1
   wide_inline: int = 1
   wide_fpw: int = 0
   wide_lean: int = 0
