@@ -24,6 +24,8 @@ environment variable RN_TUNE, e.g.  RN_TUNE="wide_ft=8,wide_lb=2" python bench.p
                          2 = rows in registers, lean algebra (no column array, one fused rank-Z pass): 41.3 us.  Parity-green.
   wide_unroll   2        unroll factor of the lean in-place pass (1: 65.9 us, 4: same as 2)
   small_waves   0        amdgpu_waves_per_eu(n, n) on the lane-per-filter step kernels: 1 -> k6 35 us/launch vs 9.5 us
+  small_max_e   8        largest error-state count served lane-per-filter; below it the lane-group family also works (k6 with
+                         small_max_e=4: 13.9-15.7 us/launch, parity-green, against 9.1 us lane-per-filter)
   small_lpf     1        lanes per filter in the family-S step kernels: 2 = lane PAIR per filter (emit_small2.py: half the
                          rows per lane, DPP exchanges, 2 waves per SIMD): k6 9.8-10.0 us/launch vs 9.4 us -- parity-green but
                          not faster, the two waves of a SIMD still move in lockstep through load / compute / store
@@ -46,6 +48,7 @@ class Tuning:
   wide_lean: int = 0
   wide_unroll: int = 2
   small_waves: int = 0
+  small_max_e: int = 8
   small_lpf: int = 1
 
 
