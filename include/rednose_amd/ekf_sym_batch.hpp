@@ -108,15 +108,34 @@ class EKFSymBatch {
   // One fused predict(t - filter_time) + update(kind) launch over the batch.  z_dev: (N, Z) device, in: z, out: y.
   // R_host: Z x Z row-major, shared.  flags_dev: N bytes or nullptr.  Returns false (and does nothing) when the
   // observation is older than the filter time (the reference would rewind; this class does not keep a ring).
-  bool predict_and_update_batch(double t, int kind, double* z_dev, const double* R_host, uint8_t* flags_dev = nullptr) {
+  // ea_dev: (N, kind_eadim) extra arguments of the observations (MSCKF feature tracks: the landmark), or nullptr for kinds
+  // that take none; augment = true shifts the MSCKF window afterwards (EKFSym asserts !augment, ekf_sym.cc:186; the
+  // Python class implements it, ekf_sym.py:365-391,527-528).
+  bool predict_and_update_batch(double t, int kind, double* z_dev, const double* R_host, uint8_t* flags_dev = nullptr,
+                                const double* ea_dev = nullptr, bool augment = false) {
     const int Z = zdim_.at(kind);
     if (!std::isnan(filter_time_) && t < filter_time_) return false;
     const double dt = advance(t);
     hip(hipMemcpyAsync(R_, R_host, sizeof(double) * Z * Z, hipMemcpyHostToDevice, stream_), "copy R");
     auto fn = sym<step_fn>("batch_predict_update_" + std::to_string(kind));
-    check(fn(x_, P_, Q_, nullptr, dt, z_dev, R_, 0, nullptr, n_, norm_quats_, flags_dev, stream_), "batch_predict_update");
+    check(fn(x_, P_, Q_, nullptr, dt, z_dev, R_, 0, ea_dev, n_, norm_quats_, flags_dev, stream_), "batch_predict_update");
     filter_time_ = t;
+    if (augment) this->augment();
     return true;
+  }
+
+  // MSCKF window shift on every filter (libraries generated with msckf_params only)
+  void augment() {
+    check(sym<int (*)(double*, double*, int64_t, void*)>("batch_augment")(x_, P_, n_, stream_), "batch_augment");
+  }
+
+  // Mahalanobis distance of an observation per filter into d2_dev (N), state untouched (EKF_sym.maha_test, ekf_sym.py:626-649)
+  void maha_distance(int kind, const double* z_dev, const double* R_host, double* d2_dev, const double* ea_dev = nullptr) {
+    const int Z = zdim_.at(kind);
+    hip(hipMemcpyAsync(R_, R_host, sizeof(double) * Z * Z, hipMemcpyHostToDevice, stream_), "copy R");
+    auto fn = sym<int (*)(const double*, const double*, const double*, const double*, int, const double*, int64_t, double*, void*)>(
+        "batch_maha_" + std::to_string(kind));
+    check(fn(x_, P_, z_dev, R_, 0, ea_dev, n_, d2_dev, stream_), "batch_maha");
   }
 
   void synchronize() const { hip(hipStreamSynchronize(stream_), "synchronize"); }

@@ -35,9 +35,21 @@ int main(int argc, char** argv) {
     try { kf.predict_and_update_batch(1e9, 7, z_dev, R); } catch (const std::out_of_range&) { threw = true; }
     kf.synchronize();
     const std::vector<double> x = kf.state(), P = kf.covs();
+    // Mahalanobis distance of an observation 0.3 above every filter's position estimate (state must stay untouched)
+    for (int64_t i = 0; i < n; i++) zs[i] = x[i * 2] + 0.3;
+    double* d2_dev = nullptr;
+    if (hipMalloc((void**)&d2_dev, sizeof(double) * n) != hipSuccess) return 3;
+    if (hipMemcpy(z_dev, zs.data(), sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) return 3;
+    kf.maha_distance(1, z_dev, R, d2_dev);
+    kf.synchronize();
+    std::vector<double> d2(n);
+    if (hipMemcpy(d2.data(), d2_dev, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) return 3;
+    const bool untouched = kf.state() == x && kf.covs() == P;
+    (void)hipFree(d2_dev);
     std::printf("steps %ld late_rejected %d unknown_kind_threw %d filter_time %.17g\n", steps, late ? 0 : 1, threw ? 1 : 0, kf.get_filter_time());
     for (int64_t i : {(int64_t)0, n - 1})
       std::printf("x %.17g %.17g std %.17g %.17g\n", x[i * 2], x[i * 2 + 1], std::sqrt(P[i * 4]), std::sqrt(P[i * 4 + 3]));
+    std::printf("maha %.17g %.17g untouched %d\n", d2[0], 0.3 * 0.3 / (P[0] + R[0]), untouched ? 1 : 0);
     (void)hipFree(z_dev);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "exception: %s\n", e.what());

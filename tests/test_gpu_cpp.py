@@ -34,7 +34,9 @@ def test_cpp_orchestrator_known_answers(tmp_path):
   head = out[0].split()
   assert head[1] == "500" and head[3] == "1" and head[5] == "1"          # 500 steps, late observation rejected, unknown kind threw
   lit = g["literals"]
-  for line in out[1:]:
+  maha = out[-1].split()
+  assert maha[0] == "maha" and abs(float(maha[1]) - float(maha[2])) < 1e-12 * float(maha[2]) and maha[4] == "1"
+  for line in out[1:-1]:
     v = [float(t) for t in line.replace("x ", "").replace("std ", "").split()]
     for got, want in zip((v[0], v[2], v[1], v[3]), lit):
       assert round(abs(got - want), 7) == 0                                # the reference's assertAlmostEqual
