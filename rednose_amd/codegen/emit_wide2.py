@@ -7,10 +7,13 @@ the HBM roofline on live (round-1 profile).  Here a wavefront owns a tile of FT 
 
   phase 1  lane l = filter l of the tile (FT lanes active): x, z -> f, F non-zeros, normalise, h, He = H.H_mod
            non-zeros, y = z - h; results go to the filter's scalar SLOT in LDS.  One evaluation per filter.
-  phase 2  for each pair of filters: the 32-lane-group-per-filter covariance algebra of emit_wide.py, but every
-           x-dependent coefficient is an LDS broadcast read from the slot; the next pair's P record streams
-           HBM -> LDS asynchronously (global_load_lds_dwordx4, double buffer) while the current pair computes.
-           dx goes back to the slot.
+  phase 2  for each GROUP of filters (as many as fit a wavefront with one lane per row of P: 64 // dim_err, see
+           filters_per_wave): the lane-group-per-filter covariance algebra of emit_wide.py, but every x-dependent
+           coefficient is an LDS broadcast read from the slot; the next group's P records stream HBM -> LDS
+           asynchronously (global_load_lds_dwordx4, double buffer) while the current group computes -- or, for small
+           records, a single buffer and several wavefronts per SIMD (double_buffered).  dx goes back to the slot.
+           Feature-track kinds of MSCKF models project G, Gt and He P He^T on the left null space of the
+           extra-argument Jacobian with the reflectors phase 1 left in the slot (_lean_update).
   phase 3  lane l = filter l again: x' = err_fun(x, dx), renormalise, x / y / flags leave through LDS, coalesced.
 
 The algebra and its order are unchanged (see emit_wide.py / emit_small.py docstrings); only who evaluates the
@@ -246,8 +249,9 @@ def device_functions(spec):
   out = []
 
   # ---- phase 1: scalars of predict ---------------------------------------------------------------
-  # All phase functions are __noinline__ with pointer-only interfaces (state lives in LDS between them): inlined into
-  # the pair loop hipcc keeps ~460 registers live (1 wave/SIMD); as separate functions each stays under 256.
+  # Phase functions have pointer-only interfaces (state lives in LDS between them) and are inlined by default: inlined
+  # into the group loop hipcc keeps ~460 registers live (1 wave/SIMD); __noinline__ (tuning knob wide_inline=0) keeps each
+  # under 256 but pays scratch frames and is 5x slower.
   quat = "".join(f" rn::normalize_quat<{D}>(x, {q});" for q in spec.quaternion_idxs)
   normq = f"if (norm_quats) {{{quat} }}" if spec.quaternion_idxs else "(void)norm_quats;"
   b = [f"double x[{D}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = xin[i];"]

@@ -139,3 +139,16 @@ def test_scalar_abi_feature_update(env):
   from oracle_lib import OracleLib
   want = np.zeros(18); OracleLib(FK.name).call("He_2", g["upd_x_in"][0].copy(), g["upd_ea"][0].copy(), want)
   assert_close(He.reshape(-1), want)
+
+
+def test_unsupported_entry_points_fail_loudly(env):
+  """Feature-track kinds are step-granular only and MSCKF models have no smoother: both must raise, not mis-compute."""
+  torch, gen, FK = env
+  from rednose_amd.helpers import KalmanError
+  f = _filter(env, 4)
+  with pytest.raises(KalmanError):
+    f.run(np.array([0.1]), np.array([2], dtype=np.int32), np.zeros((1, 4, 6)), {2: FK.obs_noise[2]})
+  with pytest.raises(KalmanError):
+    f.rts_smooth(np.zeros((2, 4, FK.dim_state)), np.tile(np.eye(FK.dim_state), (2, 4, 1, 1)), np.array([0.0, 0.1]))
+  with pytest.raises(KalmanError):
+    f.update(2, np.zeros((4, 6)), FK.obs_noise[2])              # extra arguments missing
