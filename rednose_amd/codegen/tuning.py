@@ -29,6 +29,10 @@ environment variable RN_TUNE, e.g.  RN_TUNE="wide_ft=8,wide_lb=2" python bench.p
   small_lpf     1        lanes per filter in the family-S step kernels: 2 = lane PAIR per filter (emit_small2.py: half the
                          rows per lane, DPP exchanges, 2 waves per SIMD): k6 9.8-10.0 us/launch vs 9.4 us -- parity-green but
                          not faster, the two waves of a SIMD still move in lockstep through load / compute / store
+Also measured, not kept: TWO WAVEFRONTS per 64-filter tile, lane l of both = filter l, both run predict / gains / state
+redundantly from the shared LDS image and each finishes half of the covariance rows (no exchange, code specialised per
+wavefront, ~65 % of the fp64 work per wavefront, 2 wavefronts per SIMD at 256 VGPRs with 14 spills): k6 11.1 us per launch
+against 9.2 us -- the extra LDS reads, workgroup barriers and spills cost more than the second wavefront hides.
 Also measured, not kept as a knob: delaying every other group of 8 wavefronts with s_sleep so that load / compute / store
 phases of the two halves interleave (k6: 1.0 us delay -> 9.4 us, 2.9 us -> 10.8 us, none 9.1 us): the phases are latency-,
 not bandwidth-bound, so staggering only adds the delay.
