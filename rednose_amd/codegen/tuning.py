@@ -29,6 +29,12 @@ environment variable RN_TUNE, e.g.  RN_TUNE="wide_ft=8,wide_lb=2" python bench.p
   small_lpf     1        lanes per filter in the family-S step kernels: 2 = lane PAIR per filter (emit_small2.py: half the
                          rows per lane, DPP exchanges, 2 waves per SIMD): k6 9.8-10.0 us/launch vs 9.4 us -- parity-green but
                          not faster, the two waves of a SIMD still move in lockstep through load / compute / store
+Also measured, not kept: SOFTWARE PIPELINING over the tiles of a wavefront (double-buffered LDS image, the next tile's
+global_load_lds issued before the current tile is computed, counted s_waitcnt vmcnt(23) so that the previous tile's stores stay
+in flight, two tiles per wavefront): k6 at 65 536 filters 10.7 us per launch against 9.2 us (half as many wavefronts, 53 KB of
+LDS each), no difference from 196 608 filters up (1 M filters: 134.5 vs 134.0 us on the same box).  The same kernel with the
+arithmetic removed takes 7.3 of the 9.2 us: the load -> store skeleton dominates.  Box-to-box spread of identical builds is up
+to 9 % (1 M filters: 134 us on one MI355X, 147 us on another), so only same-call comparisons are quoted here.
 Also measured, not kept: TWO WAVEFRONTS per 64-filter tile, lane l of both = filter l, both run predict / gains / state
 redundantly from the shared LDS image and each finishes half of the covariance rows (no exchange, code specialised per
 wavefront, ~65 % of the fp64 work per wavefront, 2 wavefronts per SIMD at 256 VGPRs with 14 spills): k6 11.1 us per launch
