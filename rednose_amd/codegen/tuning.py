@@ -35,6 +35,9 @@ in flight, two tiles per wavefront): k6 at 65 536 filters 10.7 us per launch aga
 LDS each), no difference from 196 608 filters up (1 M filters: 134.5 vs 134.0 us on the same box).  The same kernel with the
 arithmetic removed takes 7.3 of the 9.2 us: the load -> store skeleton dominates.  Box-to-box spread of identical builds is up
 to 9 % (1 M filters: 134 us on one MI355X, 147 us on another), so only same-call comparisons are quoted here.
+Also measured, not kept: records straight between HBM and registers (per-lane 16-byte loads / stores, no LDS staging): k6
+12.5 us per launch against 9.2 us (1 M filters: 173 vs 134 us) -- a lane's record is 288 bytes, so every wave-instruction
+touches 64 different cache lines.
 Also measured, not kept: TWO WAVEFRONTS per 64-filter tile, lane l of both = filter l, both run predict / gains / state
 redundantly from the shared LDS image and each finishes half of the covariance rows (no exchange, code specialised per
 wavefront, ~65 % of the fp64 work per wavefront, 2 wavefronts per SIMD at 256 VGPRs with 14 spills): k6 11.1 us per launch
