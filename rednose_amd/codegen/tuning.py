@@ -35,6 +35,14 @@ in flight, two tiles per wavefront): k6 at 65 536 filters 10.7 us per launch aga
 LDS each), no difference from 196 608 filters up (1 M filters: 134.5 vs 134.0 us on the same box).  The same kernel with the
 arithmetic removed takes 7.3 of the 9.2 us: the load -> store skeleton dominates.  Box-to-box spread of identical builds is up
 to 9 % (1 M filters: 134 us on one MI355X, 147 us on another), so only same-call comparisons are quoted here.
+Also measured, not kept (family W, live): the double-buffered P prefetch is drained early in the compute phase -- hipcc inserts
+s_waitcnt vmcnt(0) where the per-filter R (an ordinary global load issued AFTER the global_load_lds prefetch) is first used,
+because vmcnt retires in order.  With R copied into the LDS slot in phase 1, two distinct LDS objects ping-ponged by an
+unrolled group loop and a counted vmcnt(8) that leaves the previous group's write-back in flight, the ISA shows no wait between
+prefetch and write-back any more -- and the kernel time does not move (same-call A/B: 41.0 vs 41.1 us).  With the arithmetic
+removed the live kernel takes 19.8 us (8 dependent HBM round trips per wavefront), the matrix part of predict adds 5, of the
+update 13, the scalar phases 2.7: the step is bound by the dependent-instruction latency of a wavefront that is alone on its
+SIMD (LDS turnarounds, the in-lane 3 x 3 factorisation), not by HBM latency or bandwidth.
 Also measured, not kept: records straight between HBM and registers (per-lane 16-byte loads / stores, no LDS staging): k6
 12.5 us per launch against 9.2 us (1 M filters: 173 vs 134 us) -- a lane's record is 288 bytes, so every wave-instruction
 touches 64 different cache lines.
