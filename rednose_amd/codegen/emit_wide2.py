@@ -342,7 +342,8 @@ def device_functions(spec):
       b.append(f"  sP[cc * {E} + {i}] = {sum_terms(term(cf, f'v[{kk}]') for kk, cf in Fs.row_nz(i))};")
     b += ["}", "rn::wave_lds_sync();", "if (act) {", "#pragma unroll", f"  for (int k = 0; k < {E}; k++) v[k] = sP[k * {E} + cc];"]
     for i in range(E):
-      b.append(f"  sP[{i} * {E} + cc] = {sum_terms(term(cf, f'v[{kk}]') for kk, cf in Fs.row_nz(i))} + dt*sQ[{i} * {E} + cc];")
+      qv = f"qcol[{i}]" if tuning.current().wide_lean_q else f"sQ[{i} * {E} + cc]"
+      b.append(f"  sP[{i} * {E} + cc] = {sum_terms(term(cf, f'v[{kk}]') for kk, cf in Fs.row_nz(i))} + dt*{qv};")
     b += ["}", "rn::wave_lds_sync();"]
   else:
     b = [f"const double dt = sl[{lay.OFF_DT}];", f"double row[{E}], a[{E}], col[{E}];", "#pragma unroll",
@@ -355,7 +356,7 @@ def device_functions(spec):
       b.append(f"col[{i}] = {sum_terms(term(cf, f'a[{kk}]') for kk, cf in Fs.row_nz(i))} + dt*qcol[{i}];")
     b += ["rn::wave_lds_sync();", "if (act) {", "#pragma unroll", f"  for (int k = 0; k < {E}; k++) sP[k * {E} + cc] = col[k];", "}",
           "rn::wave_lds_sync();"]
-  qarg = "const double* sQ" if lean_p else f"const double (&qcol)[{E}]"
+  qarg = "const double* sQ" if (lean_p and not tuning.current().wide_lean_q) else f"const double (&qcol)[{E}]"
   out.append("\n".join([f"__device__ {INL} void mat_predict(double* sP, {qarg}, const double* sl, const int cc, const bool act) {{"]
                         + _ind(b) + ["}"]))
 
@@ -450,7 +451,7 @@ def kernels(spec):
     A(f"  const int c = lane % {GL};")
     A(f"  const bool act = c < {E} && g < {FPW};")
     A("  const int cc = act ? c : 0;")
-    if tune.wide_lean == 1:
+    if tune.wide_lean == 1 and not tune.wide_lean_q:
       A(f"  __shared__ __attribute__((aligned(16))) double s_Q[{EE}];      // process noise, staged once per wavefront")
       A(f"  for (int i = lane; i < {EE}; i += 64) s_Q[i] = ({dop} && gQ != nullptr) ? gQ[i] : 0.0;")
       A("  const double* qcol = s_Q;")

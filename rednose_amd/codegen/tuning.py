@@ -23,6 +23,10 @@ environment variable RN_TUNE, e.g.  RN_TUNE="wide_ft=8,wide_lb=2" python bench.p
                          16-lane scalar phase more often: 7.9 M VALU instructions vs 5.4 M) against 40.0 us for the default;
                          2 = rows in registers, lean algebra (no column array, one fused rank-Z pass): 41.3 us.  Parity-green.
   wide_unroll   2        unroll factor of the lean in-place pass (1: 65.9 us, 4: same as 2)
+  wide_lean_q   0        1 = the lean predict takes its column of Q from registers instead of an LDS copy: with wide_lean=1,
+                         wide_ft=8, wide_lb=2, wide_db=0 the block needs 19 KB of LDS and <= 256 VGPRs, so all 2 048 tiles of
+                         16 384 filters are resident at two wavefronts per SIMD: live 38.0 us per launch against 40.0 us for the
+                         default in the same call (-5 %; not the default: the budget does not hold for larger models)
   small_waves   0        amdgpu_waves_per_eu(n, n) on the lane-per-filter step kernels: 1 -> k6 35 us/launch vs 9.5 us
   small_max_e   8        largest error-state count served lane-per-filter; below it the lane-group family also works (k6 with
                          small_max_e=4: 13.9-15.7 us/launch, parity-green, against 9.1 us lane-per-filter)
@@ -68,6 +72,7 @@ class Tuning:
   wide_fpw: int = 0
   wide_lean: int = 0
   wide_unroll: int = 2
+  wide_lean_q: int = 0
   small_waves: int = 0
   small_max_e: int = 8
   small_lpf: int = 1
