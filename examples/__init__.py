@@ -22,8 +22,19 @@ def model_table():
     "feature": lambda d: FeatureKalman.generate_code(d),
     "feature36": lambda d: WideFeatureKalman.generate_code(d),
     "live": lambda d: LiveKalman.generate_code(d),
+    **{f"rand{n}": (lambda d, n=n: _random(n).generate_code(d)) for n in _random_sizes()},
     "live_maha": lambda d: LiveKalman.generate_code(d, name="live_maha", maha_test_kinds=[LK.ECEF_POS]),
   }
+
+
+def _random_sizes():
+  from examples.random_kf import SIZES
+  return SIZES
+
+
+def _random(n):
+  import examples.random_kf as R
+  return getattr(R, f"Random{n}Kalman")
 
 
 def _renamed(cls, name, folder, **kw):

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Seeded random filters: a family of small nonlinear models of assorted sizes, written through the gen_code API.
+
+Not part of the reference; they exist to exercise the emitter where the hand-written examples do not reach -- every
+lane layout of the kernels (lane per filter up to 8 error states; 7, 5, 4, 3 and 2 filters per wavefront above),
+odd and even covariance record sizes, random sparsity in F and H, state-dependent Jacobians, 1- to 3-dimensional
+observations.  f = x + dt * (A x + bilinear + sine terms), h_k = H_k x + a product term, all coefficients drawn from
+numpy's default_rng(seed) at model-construction time (so the reference's gen_code and ours see the same expressions).
+"""
+import os
+import sys
+
+if __name__ == "__main__":  # allow running as a script from anywhere (generator CLI contract)
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+import numpy as np
+import sympy as sp
+
+from rednose_amd.helpers.kalmanfilter import KalmanFilter
+from rednose_amd.helpers.ekf_sym import EKF_sym, BatchedEKF, gen_code
+
+SIZES = (3, 5, 8, 11, 13, 17, 24)
+
+
+def make(n, seed=None):
+  """-> a KalmanFilter subclass for an n-state random model (seed defaults to 1000 + n)."""
+  seed = 1000 + n if seed is None else seed
+  rng = np.random.default_rng(seed)
+  A = np.where(rng.random((n, n)) < min(0.5, 3.0 / n), np.round(rng.normal(size=(n, n)), 3), 0.0)
+  kinds = {}
+  for k, z in ((1, 3), (2, 1), (3, 2)):
+    H = np.where(rng.random((z, n)) < min(0.6, 4.0 / n), np.round(rng.normal(size=(z, n)), 3), 0.0)
+    H[np.arange(z), rng.choice(n, size=z, replace=False)] = 1.0          # every row observes something
+    kinds[k] = (H, int(rng.integers(0, n)), int(rng.integers(0, n)))
+  bil = [(int(rng.integers(0, n)), int(rng.integers(0, n)), int(rng.integers(0, n)), round(float(rng.normal()) * 0.3, 3)) for _ in range(3)]
+  sines = [(int(rng.integers(0, n)), int(rng.integers(0, n)), round(float(rng.normal()) * 0.5, 3)) for _ in range(2)]
+
+  class RandomKalman(KalmanFilter):
+    name = f"rand{n}"
+    dim = n
+    initial_x = np.round(rng.normal(size=n) * 0.5, 3)
+    initial_P_diag = np.round(rng.uniform(0.5, 2.0, size=n), 3)
+    Q = np.diag(np.round(rng.uniform(0.01, 0.5, size=n) ** 2, 6))
+    obs_noise = {1: np.eye(3) * 0.1**2, 2: np.eye(1) * 0.2**2, 3: np.diag([0.05**2, 0.3**2])}
+
+    @classmethod
+    def model(cls):
+      state_sym = sp.MatrixSymbol('state', n, 1)
+      state = sp.Matrix(state_sym)
+      dt = sp.Symbol('dt')
+      rate = sp.Matrix(A) * state
+      for i, a, b, c in bil:
+        rate[i] += c * state[a] * state[b]
+      for i, a, c in sines:
+        rate[i] += c * sp.sin(state[a])
+      f_sym = state + dt * rate
+      obs_eqs = []
+      for k, (H, a, b) in kinds.items():
+        h = sp.Matrix(H) * state
+        h[0] += 0.25 * state[a] * state[b]
+        obs_eqs.append([h, k, None])
+      return dict(name=cls.name, f_sym=f_sym, dt_sym=dt, x_sym=state_sym, obs_eqs=obs_eqs, dim_x=n, dim_err=n)
+
+    @classmethod
+    def generate_code(cls, generated_dir, **gen_kwargs):
+      gen_code(generated_dir, **cls.model(), **gen_kwargs)
+
+    def __init__(self, generated_dir, batch=None, device=None):
+      P0 = np.diag(self.initial_P_diag)
+      if batch is None:
+        self.filter = EKF_sym(generated_dir, self.name, self.Q, self.initial_x, P0, n, n)
+      else:
+        self.filter = BatchedEKF(generated_dir, self.name, self.Q, self.initial_x, P0, n, n, batch=batch, device=device)
+
+  RandomKalman.__name__ = f"Random{n}Kalman"
+  return RandomKalman
+
+
+# module-level classes so that "module:Class" references (oracle/build_oracle.py) resolve
+for _n in SIZES:
+  globals()[f"Random{_n}Kalman"] = make(_n)
+
+
+if __name__ == "__main__":
+  globals()[f"Random{int(sys.argv[1].replace('rand', ''))}Kalman"].generate_code(sys.argv[2])

@@ -1,0 +1,121 @@
+"""GPU parity on a family of seeded random nonlinear filters (examples/random_kf.py) of 3 ... 24 states: every lane layout
+of the generated kernels (lane per filter; 7, 5, 4, 3, 2 filters per wavefront), odd and even record sizes, random sparsity,
+three kinds of 3-, 1- and 2-dimensional observations.  Checked against the oracle (reference-generated sympy C + C
+restatement of ekf_c.c) on identical inputs: single calls strictly, fused multi-step runs to stream tolerance."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+SIZES = (3, 5, 8, 11, 13, 17, 24)
+
+
+@pytest.fixture(scope="module", params=SIZES)
+def env(request):
+  import torch
+  assert torch.cuda.is_available()
+  from examples import ensure_generated
+  import examples.random_kf as R
+  n = request.param
+  return torch, ensure_generated([f"rand{n}"]), getattr(R, f"Random{n}Kalman")
+
+
+def _filter(env, batch):
+  torch, gen, M = env
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  return BatchedEKF(gen, M.name, M.Q, M.initial_x, np.diag(M.initial_P_diag), M.dim, M.dim, batch=batch)
+
+
+def _states(M, rng, n):
+  D = M.dim
+  x0 = M.initial_x[None] + rng.normal(size=(n, D)) * 0.3
+  A = rng.normal(size=(n, D, D)) * 0.2
+  return x0, np.diag(M.initial_P_diag)[None] + A @ A.transpose(0, 2, 1)
+
+
+@pytest.mark.parametrize("n", [1, 70, 333])
+def test_single_calls_vs_oracle_strict(env, n):
+  torch, gen, M = env
+  from oracle_lib import OracleLib
+  o = OracleLib(M.name)
+  rng = np.random.default_rng(7 * M.dim + n)
+  x0, P0 = _states(M, rng, n)
+  f = _filter(env, n)
+  for k in (1, 2, 3):
+    Z = o.zdim(k)
+    R = M.obs_noise[k]
+    for fused in (True, False):
+      z = rng.normal(size=(n, Z))
+      f.init_state(x0, P0, 0.0)
+      xr, Pr, zr = x0.copy(), P0.copy(), z.copy()
+      o.batch_step(k, xr, Pr, zr, R, M.Q, 0.02)
+      if fused:
+        y = f.predict_and_update_batch(0.02, k, z.copy(), R)
+      else:
+        f.predict(0.02)
+        y = f.update(k, z.copy(), R)
+      torch.cuda.synchronize()
+      what = f"{M.name} kind {k} n={n} fused={fused}"
+      assert_close(f.state(), xr, rtol=1e-11, floor=1e-13, what=what + " x")
+      assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-11, floor=1e-13, what=what + " P")
+      assert_close(y.cpu().numpy(), zr, rtol=1e-11, atol=1e-13 * max(1.0, np.abs(z).max()), what=what + " y")
+
+
+def test_fused_run_and_step_path_vs_oracle(env):
+  torch, gen, M = env
+  from oracle_lib import OracleLib
+  o = OracleLib(M.name)
+  n, T = 41, 18
+  rng = np.random.default_rng(M.dim)
+  x0, P0 = _states(M, rng, n)
+  kinds = np.array([(1, 2, 3)[t % 3] for t in range(T)], dtype=np.int32)
+  ts = np.cumsum(rng.uniform(0.005, 0.03, size=T))
+  zs = rng.normal(size=(T, n, 3)) * 0.5
+  Rs = {k: M.obs_noise[k] for k in (1, 2, 3)}
+  f = _filter(env, n); f.init_state(x0, P0, 0.0)
+  ys, tx, tP, _ = f.run(ts, kinds, zs.copy(), Rs, trace=True)
+  s = _filter(env, n); s.init_state(x0, P0, 0.0)
+  for t in range(T):
+    Z = Rs[int(kinds[t])].shape[0]
+    s.predict_and_update_batch(float(ts[t]), int(kinds[t]), zs[t, :, :Z].copy(), Rs[int(kinds[t])])
+  torch.cuda.synchronize()
+  xr, Pr, zr = x0.copy(), P0.copy(), zs.copy()
+  Rt = np.zeros((T, 9))
+  for t, k in enumerate(kinds):
+    Rk = Rs[int(k)]
+    Rt[t, :Rk.size] = Rk.reshape(-1)
+  xf = np.zeros((T, n, M.dim)); Pf = np.zeros((T, n, M.dim, M.dim))
+  o.batch_run(kinds, np.diff(np.concatenate([[0.0], ts])), xr, Pr, zr, Rt, M.Q, xf=xf, Pf=Pf)
+  for name, got in (("fused run", f), ("step path", s)):
+    assert_close(got.state(), xr, rtol=1e-8, floor=1e-10, what=f"{M.name} {name} x")
+    assert_close(got.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-8, floor=1e-10, what=f"{M.name} {name} P")
+  assert_close(tx.cpu().numpy().reshape(T * n, -1), xf.reshape(T * n, -1), rtol=1e-8, floor=1e-10, what=f"{M.name} trace x")
+  assert_close(tP.cpu().numpy().reshape(T * n, -1), Pf.reshape(T * n, -1), rtol=1e-8, floor=1e-10, what=f"{M.name} trace P")
+  # smoother vs a numpy restatement of ekf_sym.py:651-690 on the oracle's f / F (additive error state, no quaternions):
+  # the recursion starts from the PREDICTED pair of the last step
+  xs, Ps = f.rts_smooth(tx, tP, ts)
+  torch.cuda.synchronize()
+  xs, Ps = xs.cpu().numpy(), Ps.cpu().numpy()
+  X, P = tx.cpu().numpy(), tP.cpu().numpy()
+  D = M.dim
+  for j in (0, n - 1):
+    x1n = P1n = None
+    for k in range(T - 2, -1, -1):
+      dt = ts[k + 1] - ts[k]
+      x1k = np.zeros(D); Fk = np.zeros(D * D)
+      o.call("f_fun", X[k, j].copy(), float(dt), x1k)
+      o.call("F_fun", X[k, j].copy(), float(dt), Fk)
+      Fk = Fk.reshape(D, D)
+      P1k = Fk @ P[k, j] @ Fk.T + dt * M.Q
+      if k == T - 2:
+        x1n, P1n = x1k.copy(), P1k.copy()
+        assert_close(xs[T - 1, j], x1n, rtol=1e-9, floor=1e-11, what=f"{M.name} smoothed x[T-1]")
+        assert_close(Ps[T - 1, j].reshape(1, -1), P1n.reshape(1, -1), rtol=1e-9, floor=1e-11, what=f"{M.name} smoothed P[T-1]")
+      Ck = np.linalg.solve(P1k, Fk @ P[k, j].T).T
+      xkn = X[k, j] + Ck @ (x1n - x1k)
+      Pkn = P[k, j] + Ck @ (P1n - P1k) @ Ck.T
+      assert_close(xs[k, j], xkn, rtol=1e-7, floor=1e-9, what=f"{M.name} smoothed x[{k}]")
+      assert_close(Ps[k, j].reshape(1, -1), Pkn.reshape(1, -1), rtol=1e-6, floor=1e-8, what=f"{M.name} smoothed P[{k}]")
+      x1n, P1n = xs[k, j].copy(), Ps[k, j].copy()       # continue from the GPU values: every step is checked on its own

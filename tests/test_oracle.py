@@ -173,7 +173,7 @@ def test_thresholds_match_reference_table():
 
 
 @pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref not built (needs /root/reference)")
-@pytest.mark.parametrize("name", ["kinematic", "live", "kinematic6", "kinematic9", "feature"])
+@pytest.mark.parametrize("name", ["kinematic", "live", "kinematic6", "kinematic9", "feature", "rand5", "rand17"])
 def test_port_flavour_equals_ref_flavour(name):
   """Our model front end (examples/ + rednose_amd.codegen.spec) must generate the same functions as the reference."""
   a, b = OracleLib(name, "ref"), OracleLib(name, "port")
@@ -185,7 +185,7 @@ def test_port_flavour_equals_ref_flavour(name):
     kinds = [3, 4, 9, 10, 12, 13, 14, 19]
   else:
     x = rng.normal(size=a.D)
-    kinds = {"kinematic9": [1, 2, 3], "feature": [1, 2]}.get(name, [1])
+    kinds = {"kinematic9": [1, 2, 3], "feature": [1, 2], "rand5": [1, 2, 3], "rand17": [1, 2, 3]}.get(name, [1])
   dt = 0.037
   def both(sym, *args, shape):
     oa, ob = np.zeros(shape), np.zeros(shape)
