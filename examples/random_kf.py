@@ -2,7 +2,7 @@
 """Seeded random filters: a family of small nonlinear models of assorted sizes, written through the gen_code API.
 
 Not part of the reference; they exist to exercise the emitter where the hand-written examples do not reach -- every
-lane layout of the kernels (lane per filter up to 8 error states; 7, 5, 4, 3 and 2 filters per wavefront above),
+lane layout of the kernels (lane per filter up to 8 error states; 7, 5, 4, 3, 2 and 1 filters per wavefront above),
 odd and even covariance record sizes, random sparsity in F and H, state-dependent Jacobians, 1- to 3-dimensional
 observations.  f = x + dt * (A x + bilinear + sine terms), h_k = H_k x + a product term, all coefficients drawn from
 numpy's default_rng(seed) at model-construction time (so the reference's gen_code and ours see the same expressions).
@@ -19,7 +19,7 @@ import sympy as sp
 from rednose_amd.helpers.kalmanfilter import KalmanFilter
 from rednose_amd.helpers.ekf_sym import EKF_sym, BatchedEKF, gen_code
 
-SIZES = (3, 5, 8, 11, 13, 17, 24)
+SIZES = (3, 5, 8, 11, 13, 17, 24, 32, 40)
 
 
 def make(n, seed=None):

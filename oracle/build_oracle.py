@@ -44,7 +44,7 @@ MODELS = {
   "kinematic9": dict(model="examples.kinematic9_kf:Kinematic9Kalman"),
   "feature": dict(model="examples.feature_kf:FeatureKalman"),
   "feature36": dict(model="examples.feature_kf:WideFeatureKalman"),
-  **{f"rand{n}": dict(model=f"examples.random_kf:Random{n}Kalman") for n in (3, 5, 8, 11, 13, 17, 24)},
+  **{f"rand{n}": dict(model=f"examples.random_kf:Random{n}Kalman") for n in (3, 5, 8, 11, 13, 17, 24, 32, 40)},
   "kinematic6_maha": dict(model="examples.kinematic6_kf:Kinematic6Kalman", rename="kinematic6_maha",
                           maha_test_kinds=[1]),
 }
