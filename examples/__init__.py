@@ -12,6 +12,7 @@ def model_table():
   from examples.kinematic_kf import KinematicKalman
   from examples.kinematic6_kf import Kinematic6Kalman
   from examples.kinematic9_kf import Kinematic9Kalman
+  from examples.attitude_kf import AttitudeKalman
   from examples.feature_kf import FeatureKalman, WideFeatureKalman
   from examples.live_kf import LiveKalman, ObservationKind as LK
   return {
@@ -19,6 +20,7 @@ def model_table():
     "kinematic6": lambda d: Kinematic6Kalman.generate_code(d),
     "kinematic6_maha": lambda d: _renamed(Kinematic6Kalman, "kinematic6_maha", d, maha_test_kinds=[1]),
     "kinematic9": lambda d: Kinematic9Kalman.generate_code(d),
+    "attitude": lambda d: AttitudeKalman.generate_code(d),
     "feature": lambda d: FeatureKalman.generate_code(d),
     "feature36": lambda d: WideFeatureKalman.generate_code(d),
     "live": lambda d: LiveKalman.generate_code(d),

@@ -89,7 +89,8 @@ extern "C" {
                              int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags,    \
                              double *trace_x, double *trace_P, void *stream);                                     \
   /* Rauch-Tung-Striebel backward pass over a filtered trace; replaces the Python-only EKF_sym.rts_smooth        \
-   * (/root/reference/rednose/helpers/ekf_sym.py:651-690).  xs/Ps may alias xf/Pf. */                             \
+   * (/root/reference/rednose/helpers/ekf_sym.py:651-690).  xs/Ps may alias xf/Pf.  norm_quats: bit 0 = renormalise the   \
+   * recomputed predicted states (as the forward pass did), bit 1 = the reference's norm_quats (smoothed states). */                             \
   int RN_FN(name, batch_rts)(const double *xf, const double *Pf, const double *ts, int64_t T, const double *Q,     \
                              int64_t n, int norm_quats, double *xs, double *Ps, void *stream);
 

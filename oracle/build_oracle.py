@@ -42,6 +42,7 @@ MODELS = {
                     maha_test_kinds=[12]),
   "kinematic6": dict(model="examples.kinematic6_kf:Kinematic6Kalman"),
   "kinematic9": dict(model="examples.kinematic9_kf:Kinematic9Kalman"),
+  "attitude": dict(model="examples.attitude_kf:AttitudeKalman"),
   "feature": dict(model="examples.feature_kf:FeatureKalman"),
   "feature36": dict(model="examples.feature_kf:WideFeatureKalman"),
   **{f"rand{n}": dict(model=f"examples.random_kf:Random{n}Kalman") for n in (3, 5, 8, 11, 13, 17, 24, 32, 40)},

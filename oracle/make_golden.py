@@ -309,6 +309,58 @@ def feature_goldens(T=45, cls_name="FeatureKalman", out_name="feature_stream.npz
   print("feature stream: final x[:6]", out["x_after"][-1][:6], "y dims", {len(np.ravel(e)) for e in uy})
 
 
+def attitude_goldens(T=60):
+  """7/6-state attitude ESKF (examples/attitude_kf.py): gyro every step, gravity direction every third, a rotating body;
+  reference numpy path with quaternion_idxs=[0], C++ orchestration order obtained as in live_stream (predict(t), then
+  predict_and_update_batch at the same t), then rts_smooth with norm_quats (it normalises x[3:7] whatever the model,
+  ekf_sym.py:666-667 -- for this state layout that slice is NOT the quaternion, which the golden therefore also pins)."""
+  import copy
+  import importlib.util
+  spec = importlib.util.spec_from_file_location("rn_amd_attitude_kf", os.path.join(REPO, "examples", "attitude_kf.py"))
+  mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+  AK = mod.AttitudeKalman
+  rng = np.random.default_rng(77)
+  f = ref_filter("attitude", AK.Q, AK.initial_x, np.diag(AK.initial_P_diag), 7, 6, quaternion_idxs=[0])
+  x0 = AK.initial_x.copy()
+  e = rng.uniform(-0.1, 0.1, size=3)
+  q = np.array([1.0, e[0] / 2, e[1] / 2, e[2] / 2]); x0[0:4] = q / np.linalg.norm(q)
+  P0 = np.diag(AK.initial_P_diag)
+  f.init_state(x0, P0, None)
+  w_true = np.array([0.3, -0.2, 0.5])
+  q_true = np.array([1.0, 0.0, 0.0, 0.0])
+  g_w = np.array(AK.gravity_world)
+
+  def rot(qq):
+    a, b, c, d = qq
+    return np.array([[a*a + b*b - c*c - d*d, 2*(b*c - a*d), 2*(b*d + a*c)],
+                     [2*(b*c + a*d), a*a - b*b + c*c - d*d, 2*(c*d - a*b)],
+                     [2*(b*d - a*c), 2*(c*d + a*b), a*a - b*b - c*c + d*d]])
+
+  kinds, ts, zs, est, xs, Ps, ys = [], [], [], [], [], [], []
+  t = 0.0
+  for i in range(T):
+    t += 0.02
+    wq = np.array([0.0, *w_true])
+    dq = 0.5 * np.array([-q_true[1]*wq[1] - q_true[2]*wq[2] - q_true[3]*wq[3],
+                          q_true[0]*wq[1] + q_true[2]*wq[3] - q_true[3]*wq[2],
+                          q_true[0]*wq[2] - q_true[1]*wq[3] + q_true[3]*wq[1],
+                          q_true[0]*wq[3] + q_true[1]*wq[2] - q_true[2]*wq[1]])
+    q_true = q_true + 0.02 * dq; q_true /= np.linalg.norm(q_true)
+    if i % 3 == 2:
+      k, z = 2, rot(q_true).T @ g_w + rng.normal(size=3) * 0.3
+    else:
+      k, z = 1, w_true + rng.normal(size=3) * 0.02
+    f.predict(t)
+    r = f.predict_and_update_batch(t, k, np.array([z]), np.array([AK.obs_noise[k]]))
+    est.append(r); kinds.append(k); ts.append(t); zs.append(z)
+    xs.append(f.state().copy()); Ps.append(f.covs().copy()); ys.append(np.asarray(r[6][0]).flatten())
+  xs_s, Ps_s = f.rts_smooth(copy.deepcopy(est), norm_quats=False)
+  np.savez_compressed(os.path.join(GOLD, "attitude_stream.npz"), x0=x0, P0=P0, kinds=np.array(kinds), ts=np.array(ts), zs=np.array(zs),
+                      ys=np.array(ys), xs=np.array(xs), Ps=np.array(Ps), xk_km1=np.array([e_[0] for e_ in est]),
+                      Pk_km1=np.array([e_[2] for e_ in est]), xs_smooth=xs_s, Ps_smooth=Ps_s)
+  print("attitude: final quat", xs[-1][:4], "truth", q_true, "rate", xs[-1][4:])
+
+
 def maha_goldens():
   """Gate DECISIONS of the reference's maha_test (ekf_sym.py:626-649; threshold = chi2_ppf(0.95, Z) from the
   reference's lookup table) on live ECEF_POS observations with and without gross outliers."""
@@ -338,6 +390,7 @@ if __name__ == "__main__":
   rts_goldens()
   maha_goldens()
   kinematic9_goldens()
+  attitude_goldens()
   feature_goldens()
   feature_goldens(T=15, cls_name="WideFeatureKalman", out_name="feature36_stream.npz", n_upd=6)
   for fn in sorted(os.listdir(GOLD)):

@@ -8,7 +8,10 @@
 //     Pk_n    = Pk_k + Ck (Pk1_n - Pk1_k) Ck^T                                      (:686)
 // including its quirks: the recursion starts from the PREDICTED state/covariance of the last step
 // (estimates[-1][0], [2], :658-659), and with norm_quats every xk1_n is renormalised in place, so all returned
-// states except the oldest are normalised (:665-667).
+// states except the oldest are normalised (:665-667).  norm_quats is a bit mask here: bit 0 renormalises the RECOMPUTED
+// predicted state (what the forward pass did when the filter has quaternion_idxs: the reference reads those pairs from
+// the stored estimates), bit 1 is the reference's norm_quats argument (the smoothed states; the reference normalises
+// the hard-coded slice 3:7, :666-667 -- here the model's quaternion slices).
 // Memory plan (SURVEY.md section 7 "smoother trace capacity"): only the FILTERED trace (xk_k, Pk_k, t) is stored by
 // the forward pass; the predicted pair (xk1_k, Pk1_k) is recomputed here from the filtered pair of step k with the
 // same f/F code -- half the trace (140 GB instead of 279 GB at 2100 x 16384 live steps).  Outputs may alias inputs.
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
 #pragma unroll
         for (int i = 0; i < D; i++) x1k[i] = xk[i];
         Model::predict_cov(x1k, prow, mcol, p1col, L, s_Q, dt, cc, on);        // L <- Pk1_k (full matrix), x1k <- f(xk)
-        if (norm_quats) Model::normalize(x1k);
+        if (norm_quats & 1) Model::normalize(x1k);
         if (on) {
 #pragma unroll
           for (int i = 0; i < E; i++) {
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
         for (int j = 0; j < E; j++) prow[j] = A[cc * E + j];                 // predict_cov consumed the row registers
       } else {
         Model::f(xk, dt, x1k);
-        if (norm_quats) Model::normalize(x1k);
+        if (norm_quats & 1) Model::normalize(x1k);
         if (c == 0 && g < cnt) Model::F(xk, dt, Fm);
         wave_lds_sync();
         // M = Fk Pk_k^T : lane c forms column c, M[i][c] = sum_m F[i][m] Pk[c][m]; i loops stay rolled (operands in LDS)
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
 #pragma unroll
         for (int i = 0; i < D; i++) xn1[i] = x1k[i];
       }
-      if (norm_quats) Model::normalize(xn1);
+      if (norm_quats & 2) Model::normalize(xn1);
       // smoothed step k+1 is final now: write it out (state after the in-place renormalisation)
       if (c == 0 && g < cnt) {
 #pragma unroll
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(64) void k_rts_wide(const double* __restrict__ xf, 
 #pragma unroll
         for (int i = 0; i < D; i++) x1k[i] = xk[i];
         Model::predict_cov(x1k, prow, y, p1col, L, s_Q, dt, cc, on);        // L <- Pk1_k, y <- column c of M = Fk Pk_k^T
-        if (norm_quats) Model::normalize(x1k);
+        if (norm_quats & 1) Model::normalize(x1k);
         if (on) {
 #pragma unroll
           for (int i = 0; i < E; i++) {
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(64) void k_rts_wide(const double* __restrict__ xf, 
         }
 #pragma unroll
         for (int i = 0; i < D; i++) xn1[i] = first ? x1k[i] : sxn[i];
-        if (norm_quats) Model::normalize(xn1);
+        if (norm_quats & 2) Model::normalize(xn1);
         wave_lds_sync();
         // smoothed step k+1 is final now: write it out (state after the in-place renormalisation).  The replicated state
         // vectors wait in LDS until the state update (in registers they would hold ~140 VGPRs through the factorisation)
