@@ -10,13 +10,18 @@ import sympy as sp
 from conftest import REPO
 
 
-def _model(gain):
-  state_sym = sp.MatrixSymbol('state', 2, 1)
+def _model(gain, n=2):
+  """Chain of n integrators whose coupling is `gain` (n = 2: lane-per-filter kernels; n = 10: lane-group kernels, where the
+  gain is evaluated in the scalar phase and reaches the covariance phase through the LDS slot); the observation uses it too."""
+  state_sym = sp.MatrixSymbol('state', n, 1)
   state = sp.Matrix(state_sym)
   dt = sp.Symbol('dt')
-  f_sym = state + dt * sp.Matrix([gain * state[1, 0], 0])
-  obs = [[sp.Matrix([state[0, 0]]), 1, None]]
-  return dict(f_sym=f_sym, dt_sym=dt, x_sym=state_sym, obs_eqs=obs, dim_x=2, dim_err=2)
+  rate = sp.zeros(n, 1)
+  for i in range(n - 1):
+    rate[i] = gain * state[i + 1, 0]
+  f_sym = state + dt * rate
+  obs = [[sp.Matrix([state[0, 0] + (gain * state[n - 1, 0] if n > 2 else 0)]), 1, None]]
+  return dict(f_sym=f_sym, dt_sym=dt, x_sym=state_sym, obs_eqs=obs, dim_x=n, dim_err=n)
 
 
 @pytest.fixture(scope="module")
@@ -26,6 +31,8 @@ def libs():
   g = sp.Symbol('gain')
   gen_code(folder, "gv_runtime", global_vars=[g], **_model(g))
   gen_code(folder, "gv_literal", **_model(sp.Float(2.5)))
+  gen_code(folder, "gv_runtime10", global_vars=[g], **_model(g, 10))
+  gen_code(folder, "gv_literal10", **_model(sp.Float(2.5), 10))
   return folder
 
 
@@ -39,23 +46,25 @@ def test_setter_is_generated_and_exported(libs):
 
 
 @pytest.mark.gpu
-def test_runtime_global_equals_literal(libs):
+@pytest.mark.parametrize("dim,suffix", [(2, ""), (10, "10")])
+def test_runtime_global_equals_literal(libs, dim, suffix):
   import torch
   from rednose_amd.helpers.ekf_sym import EKF_sym, BatchedEKF
-  Q = np.diag([0.01, 4.0]); x0 = np.array([0.5, 0.3]); P0 = np.eye(2)
-  a = EKF_sym(libs, "gv_runtime", Q, x0, P0, 2, 2, global_vars=["gain"])
+  Q = np.diag(np.linspace(0.01, 4.0, dim)); x0 = np.linspace(0.5, 0.3, dim); P0 = np.eye(dim)
+  a = EKF_sym(libs, "gv_runtime" + suffix, Q, x0, P0, dim, dim, global_vars=["gain"])
   a.set_global("gain", 2.5)
   n = 100
   rng = np.random.default_rng(0)
-  X0 = rng.normal(size=(n, 2))
-  fa = BatchedEKF(libs, "gv_runtime", Q, x0, P0, 2, 2, batch=n); fa.init_state(X0, P0, 0.0)
-  fb = BatchedEKF(libs, "gv_literal", Q, x0, P0, 2, 2, batch=n); fb.init_state(X0, P0, 0.0)
+  X0 = rng.normal(size=(n, dim))
+  fa = BatchedEKF(libs, "gv_runtime" + suffix, Q, x0, P0, dim, dim, batch=n); fa.init_state(X0, P0, 0.0)
+  fb = BatchedEKF(libs, "gv_literal" + suffix, Q, x0, P0, dim, dim, batch=n); fb.init_state(X0, P0, 0.0)
   for i in range(1, 6):
     z = rng.normal(size=(n, 1))
     fa.predict_and_update_batch(0.01 * i, 1, z.copy(), np.array([[0.01]]))
     fb.predict_and_update_batch(0.01 * i, 1, z.copy(), np.array([[0.01]]))
   torch.cuda.synchronize()
-  assert torch.equal(fa.x, fb.x) and torch.equal(fa.P, fb.P)
+  # a literal gain lets the compiler fold constants that the run-time gain multiplies at run time: equal to rounding
+  assert torch.allclose(fa.x, fb.x, rtol=1e-12, atol=1e-14) and torch.allclose(fa.P, fb.P, rtol=1e-12, atol=1e-14)
   a.set_global("gain", 0.0)          # with a zero gain the position no longer integrates the velocity
   fa.init_state(X0, P0, 0.0)
   fa.predict(1.0)
