@@ -25,6 +25,7 @@ def model_table():
     "feature36": lambda d: WideFeatureKalman.generate_code(d),
     "live": lambda d: LiveKalman.generate_code(d),
     **{f"rand{n}": (lambda d, n=n: _random(n).generate_code(d)) for n in _random_sizes()},
+    "rand13_maha": lambda d: _renamed(_random(13), "rand13_maha", d, maha_test_kinds=[1, 3]),
     "live_maha": lambda d: LiveKalman.generate_code(d, name="live_maha", maha_test_kinds=[LK.ECEF_POS]),
   }
 

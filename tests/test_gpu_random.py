@@ -125,3 +125,45 @@ def test_fused_run_and_step_path_vs_oracle(env):
       assert_close(xs[k, j], xkn, rtol=1e-7, floor=1e-9, what=f"{M.name} smoothed x[{k}]")
       assert_close(Ps[k, j].reshape(1, -1), Pkn.reshape(1, -1), rtol=1e-6, floor=1e-8, what=f"{M.name} smoothed P[{k}]")
       x1n, P1n = xs[k, j].copy(), Ps[k, j].copy()       # continue from the GPU values: every step is checked on its own
+
+
+def test_mahalanobis_gate_in_lane_groups_vs_oracle():
+  """The gate inside the E-lane-group update (13 error states, 4 filters per wavefront): 3- and 2-dimensional gated kinds,
+  a third of the observations gross outliers; decisions (flag bit 0), states and covariances against the oracle, and the
+  standalone distance against its definition."""
+  import torch
+  from examples import ensure_generated
+  import examples.random_kf as R
+  from oracle_lib import OracleLib
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  from rednose_amd.helpers.chi2_lookup import chi2_ppf
+  M = R.Random13Kalman
+  gen = ensure_generated(["rand13_maha"])
+  o = OracleLib("rand13_maha")
+  n = 257
+  rng = np.random.default_rng(13)
+  x0 = M.initial_x[None] + rng.normal(size=(n, 13)) * 0.3
+  A = rng.normal(size=(n, 13, 13)) * 0.2
+  P0 = np.diag(M.initial_P_diag)[None] + A @ A.transpose(0, 2, 1)
+  f = BatchedEKF(gen, "rand13_maha", M.Q, M.initial_x, np.diag(M.initial_P_diag), 13, 13, batch=n, maha_test_kinds=[1, 3])
+  for k in (1, 3):
+    Z = o.zdim(k)
+    hx = np.zeros((n, Z))
+    for i in range(n):
+      out = np.zeros(Z); o.call(f"h_{k}", x0[i].copy(), np.zeros(1), out); hx[i] = out
+    z = hx + rng.normal(size=(n, Z)) * 0.5
+    bad = rng.random(n) < 0.33
+    z[bad] += rng.normal(size=(bad.sum(), Z)) * 40.0
+    f.init_state(x0, P0, 0.0)
+    d2 = f.maha_dist(k, z.copy(), M.obs_noise[k]).cpu().numpy()
+    want_gate = d2 > chi2_ppf(0.95, Z)
+    xr, Pr, zr = x0.copy(), P0.copy(), z.copy()
+    fl = np.zeros(n, dtype=np.uint8)
+    o.batch_step(k, xr, Pr, zr, M.obs_noise[k], M.Q, 0.0, flags=fl, do_predict=False)
+    f.update(k, z.copy(), M.obs_noise[k])
+    torch.cuda.synchronize()
+    got = f.flags.cpu().numpy() & 1
+    assert np.array_equal(got, fl), f"kind {k}: {np.sum(got != fl)} gate decisions differ"
+    assert np.array_equal(got.astype(bool), want_gate) and bad[got.astype(bool)].mean() > 0.9
+    assert_close(f.state(), xr, rtol=1e-10, floor=1e-12, what=f"gated kind {k} x")
+    assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-10, floor=1e-12, what=f"gated kind {k} P")
