@@ -423,8 +423,10 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       rn::lds_to_regs<{zmax}>(s_z, lane, z);
       rn::wave_lds_sync();
       // software prefetch: next step's observations travel while this step computes
+      // (issued unconditionally, the last step re-reads its own row: a predicated issue demotes the staging registers to
+      // scratch memory, 48 bytes per lane that every step then travels through)
       rn::TilePrefetch<{zmax}> nxt;
-      if (t + 1 < T) nxt.issue(gz + ((t + 1) * n + base) * {zmax}, cnt, lane);
+      nxt.issue(gz + ((t + 1 < T ? t + 1 : t) * n + base) * {zmax}, cnt, lane);
       const int kind = kinds[t];
       const double dt = dts[t];
       predict_regs(x, P, s_Q, dt);

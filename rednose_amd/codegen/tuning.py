@@ -28,7 +28,7 @@ environment variable RN_TUNE, e.g.  RN_TUNE="wide_ft=8,wide_lb=2" python bench.p
                          16 384 filters are resident at two wavefronts per SIMD: live 38.0 us per launch against 40.0 us for the
                          default in the same call (-5 %; not the default: the budget does not hold for larger models)
   small_waves   0        amdgpu_waves_per_eu(n, n) on the lane-per-filter step kernels: 1 -> k6 35 us/launch vs 9.5 us
-  small_max_e   8        largest error-state count served lane-per-filter; below it the lane-group family also works (k6 with
+  small_max_e   7        largest error-state count served lane-per-filter (8 spills, see emit.py); below it the lane-group family also works (k6 with
                          small_max_e=4: 13.9-15.7 us/launch, parity-green, against 9.1 us lane-per-filter)
   small_lpf     1        lanes per filter in the family-S step kernels: 2 = lane PAIR per filter (emit_small2.py: half the
                          rows per lane, DPP exchanges, 2 waves per SIMD): k6 9.8-10.0 us/launch vs 9.4 us -- parity-green but
@@ -74,7 +74,7 @@ class Tuning:
   wide_unroll: int = 2
   wide_lean_q: int = 0
   small_waves: int = 0
-  small_max_e: int = 8
+  small_max_e: int = 7
   small_lpf: int = 1
 
 

@@ -170,56 +170,30 @@ __device__ __forceinline__ void tile_l2g(double* __restrict__ g, int cnt, const 
   }
 }
 
-// Register-staged prefetch of one tile (cnt <= 64 filters x EPF doubles): issue() starts the coalesced global
-// loads, commit() later drops them into the wave's LDS image -- the loads fly while the caller computes.
+// Register-staged prefetch of one tile (cnt <= 64 filters x EPF doubles): issue() starts the coalesced global loads (lane l
+// takes doubles l, l + 64, ...), commit() puts them into the LDS image later.  ONE representation and unconditional, clamped
+// loads on purpose: with a 16-byte path for full tiles next to an 8-byte path for ragged ones the staging arrays were
+// assigned under different conditions, hipcc kept the struct in scratch memory, and every step of the fused run then went
+// through 48 bytes of scratch per lane (a scratch access costs a wavefront that is alone on its SIMD about a microsecond).
 template <int EPF>
 struct TilePrefetch {
-  static constexpr int NV = 32 * EPF;
-  static constexpr int IT = (NV + WAVE - 1) / WAVE;
   static constexpr int STR = RN_LDS_PAD ? (EPF | 1) : EPF;
-  double2 v[IT];
   double s[EPF];
   __device__ __forceinline__ void issue(const double* __restrict__ g, int cnt, int lane) {
-    if (cnt == WAVE) {
-      const double2* __restrict__ g2 = reinterpret_cast<const double2*>(g);
+    const int last = cnt * EPF - 1;
 #pragma unroll
-      for (int i = 0; i < IT; i++) {
-        const int idx = lane + i * WAVE;
-        v[i] = g2[((NV % WAVE == 0) || idx < NV) ? idx : NV - 1];     // unconditional, clamped (see copy_g2l)
-      }
-    } else {
-      const int last = cnt * EPF - 1;
-#pragma unroll
-      for (int i = 0; i < EPF; i++) {
-        const int idx = lane + i * WAVE;
-        s[i] = g[idx <= last ? idx : last];
-      }
+    for (int i = 0; i < EPF; i++) {
+      const int idx = lane + i * WAVE;
+      s[i] = g[idx <= last ? idx : last];
     }
   }
   __device__ __forceinline__ void commit(double* lds, int cnt, int lane) const {
-    if (cnt == WAVE) {
 #pragma unroll
-      for (int i = 0; i < IT; i++) {
-        const int idx = lane + i * WAVE;
-        if ((NV % WAVE == 0) || idx < NV) {
-#if RN_LDS_PAD
-          const int e = 2 * idx;
-          const int f = e / EPF, k = e - f * EPF;
-          lds[f * STR + k] = v[i].x;
-          if (k + 1 < EPF) lds[f * STR + k + 1] = v[i].y; else lds[(f + 1) * STR] = v[i].y;
-#else
-          reinterpret_cast<double2*>(lds)[idx] = v[i];
-#endif
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < EPF; i++) {
-        const int e = lane + i * WAVE;
-        if (e < cnt * EPF) {
-          const int f = e / EPF, k = e - f * EPF;
-          lds[f * STR + k] = s[i];
-        }
+    for (int i = 0; i < EPF; i++) {
+      const int e = lane + i * WAVE;
+      if (e < cnt * EPF) {
+        const int f = e / EPF, k = e - f * EPF;
+        lds[f * STR + k] = s[i];
       }
     }
   }

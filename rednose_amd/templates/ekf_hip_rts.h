@@ -293,7 +293,12 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
 // and harmless stores above the pivot brought that to 61).  A variant with only two LDS matrices per filter (rows of
 // Pk1_n carried in registers, the prefetch landing in the dead difference matrix: 18 KB per wave, enough for two waves
 // per SIMD) needs <= 256 registers for that, and the generated predict alone keeps ~270 live: 1 264 spilled VGPRs under
-// every -amdgpu-sched-strategy, so it was dropped.
+// every -amdgpu-sched-strategy, so it was dropped.  A later variant -- right-looking factorisation with redundantly tracked
+// diagonals, the two products as rolled loops with LDS-resident multipliers, and the factor read through an LDS pointer
+// "redefined" by an empty asm once per column (which stops hipcc from hoisting the substitution loads: 0 spills, 256 + 156
+// registers) -- ran at 21.2 us per step and wavefront (96 M steps/s) but returned wrong states for SOME inputs of the
+// 24-error-state random model (tools/lds_poison.hip + a numpy restatement found it; 11, 13, 17 and 22 states were fine;
+// cause not found), so this version stays.
 template <class Model>
 __global__ __launch_bounds__(64) void k_rts_wide(const double* __restrict__ xf, const double* __restrict__ Pf,
                                                  const double* __restrict__ ts, const int64_t T,

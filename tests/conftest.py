@@ -39,3 +39,20 @@ def assert_close(got, want, rtol=1e-12, floor=1e-14, what="", atol=0.0):
 @pytest.fixture(scope="session")
 def repo_root():
   return REPO
+
+
+@pytest.fixture(autouse=True)
+def _poison_lds(request):
+  """Before every GPU test, fill the LDS of all CUs with NaN patterns (tools/lds_poison.hip): a kernel that reads LDS it never
+  wrote then produces NaNs deterministically instead of depending on what the previous kernel left there."""
+  if request.node.get_closest_marker("gpu") is None:
+    yield
+    return
+  import ctypes
+  lib = os.path.join(REPO, "tools", "liblds_poison.so")
+  if os.path.exists(lib):
+    import torch
+    if torch.cuda.is_available():
+      ctypes.CDLL(lib).lds_poison(None)
+      torch.cuda.synchronize()
+  yield

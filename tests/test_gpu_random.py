@@ -99,6 +99,11 @@ def test_fused_run_and_step_path_vs_oracle(env):
     assert_close(got.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-8, floor=1e-10, what=f"{M.name} {name} P")
   assert_close(tx.cpu().numpy().reshape(T * n, -1), xf.reshape(T * n, -1), rtol=1e-8, floor=1e-10, what=f"{M.name} trace x")
   assert_close(tP.cpu().numpy().reshape(T * n, -1), Pf.reshape(T * n, -1), rtol=1e-8, floor=1e-10, what=f"{M.name} trace P")
+  if M.dim > 24:
+    from rednose_amd.helpers import KalmanError
+    with pytest.raises(KalmanError):         # no smoother above 24 error states
+      f.rts_smooth(tx, tP, ts)
+    return
   # smoother vs a numpy restatement of ekf_sym.py:651-690 on the oracle's f / F (additive error state, no quaternions):
   # the recursion starts from the PREDICTED pair of the last step
   xs, Ps = f.rts_smooth(tx, tP, ts)
@@ -167,3 +172,78 @@ def test_mahalanobis_gate_in_lane_groups_vs_oracle():
     assert np.array_equal(got.astype(bool), want_gate) and bad[got.astype(bool)].mean() > 0.9
     assert_close(f.state(), xr, rtol=1e-10, floor=1e-12, what=f"gated kind {k} x")
     assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-10, floor=1e-12, what=f"gated kind {k} P")
+
+
+@pytest.mark.parametrize("dim", [5, 8, 17])
+def test_trace_vs_step_path_many_shapes(dim):
+  """Fused-run trace against the step-granular path (GPU vs GPU, states to 1e-9) over a dozen random batch sizes / schedule
+  lengths in ONE process -- the configuration that exposed a wrong trace for 8 error states when those still ran on the
+  lane-per-filter kernels with spilled registers (tools/stress_run_trace.py is the stand-alone version)."""
+  import torch
+  from examples import ensure_generated
+  import examples.random_kf as R
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  M = getattr(R, f"Random{dim}Kalman")
+  gen = ensure_generated([M.name])
+  rng = np.random.default_rng(100 + dim)
+  Rs = {k: M.obs_noise[k] for k in (1, 2, 3)}
+  for rep in range(12):
+    n = int(rng.integers(1, 400)); T = int(rng.integers(2, 24))
+    x0 = M.initial_x[None] + rng.normal(size=(n, dim)) * 0.3
+    A = rng.normal(size=(n, dim, dim)) * 0.2
+    P0 = np.diag(M.initial_P_diag)[None] + A @ A.transpose(0, 2, 1)
+    kinds = rng.integers(1, 4, size=T).astype(np.int32)
+    ts = np.cumsum(rng.uniform(0.005, 0.03, size=T))
+    zs = rng.normal(size=(T, n, 3)) * 0.5
+    f = BatchedEKF(gen, M.name, M.Q, M.initial_x, np.diag(M.initial_P_diag), dim, dim, batch=n); f.init_state(x0, P0, 0.0)
+    _, tx, tP, _ = f.run(ts, kinds, zs.copy(), Rs, trace=True)
+    s = BatchedEKF(gen, M.name, M.Q, M.initial_x, np.diag(M.initial_P_diag), dim, dim, batch=n); s.init_state(x0, P0, 0.0)
+    for t in range(T):
+      Z = Rs[int(kinds[t])].shape[0]
+      s.predict_and_update_batch(float(ts[t]), int(kinds[t]), zs[t, :, :Z].copy(), Rs[int(kinds[t])])
+      dx = (s.x - tx[t]).abs().max().item(); dP = (s.P - tP[t]).abs().max().item()
+      assert dx < 1e-9 and dP < 1e-9, f"{M.name} rep {rep} n={n} T={T} t={t}: |dx|={dx:.3e} |dP|={dP:.3e}"
+
+
+@pytest.mark.parametrize("dim", [13, 24])
+def test_smoother_many_shapes(dim):
+  """The smoother against the numpy restatement over several random batch sizes / trace lengths (every filter, every step)."""
+  import torch
+  from examples import ensure_generated
+  import examples.random_kf as R
+  from oracle_lib import OracleLib
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  M = getattr(R, f"Random{dim}Kalman")
+  gen = ensure_generated([M.name]); o = OracleLib(M.name)
+  rng = np.random.default_rng(5)
+  Rs = {k: M.obs_noise[k] for k in (1, 2, 3)}
+  for rep in range(6):
+    n = int(rng.integers(1, 90)); T = int(rng.integers(3, 22))
+    x0 = M.initial_x[None] + rng.normal(size=(n, dim)) * 0.3
+    A = rng.normal(size=(n, dim, dim)) * 0.2
+    P0 = np.diag(M.initial_P_diag)[None] + A @ A.transpose(0, 2, 1)
+    kinds = rng.integers(1, 4, size=T).astype(np.int32)
+    ts = np.cumsum(rng.uniform(0.005, 0.03, size=T))
+    zs = rng.normal(size=(T, n, 3)) * 0.5
+    f = BatchedEKF(gen, M.name, M.Q, M.initial_x, np.diag(M.initial_P_diag), dim, dim, batch=n); f.init_state(x0, P0, 0.0)
+    _, tx, tP, _ = f.run(ts, kinds, zs.copy(), Rs, trace=True)
+    xs, Ps = f.rts_smooth(tx, tP, ts)
+    torch.cuda.synchronize()
+    xs, Ps = xs.cpu().numpy(), Ps.cpu().numpy(); X, P = tx.cpu().numpy(), tP.cpu().numpy()
+    assert np.isfinite(xs).all() and np.isfinite(Ps).all()
+    worst = 0.0
+    for j in range(n):
+      x1n = None
+      for k in range(T - 2, -1, -1):
+        dt = ts[k + 1] - ts[k]
+        x1k = np.zeros(dim); Fk = np.zeros(dim * dim)
+        o.call("f_fun", X[k, j].copy(), float(dt), x1k); o.call("F_fun", X[k, j].copy(), float(dt), Fk)
+        Fk = Fk.reshape(dim, dim)
+        P1k = Fk @ P[k, j] @ Fk.T + dt * M.Q
+        if k == T - 2:
+          x1n = x1k.copy()
+        Ck = np.linalg.solve(P1k, Fk @ P[k, j].T).T
+        xkn = X[k, j] + Ck @ (x1n - x1k)
+        worst = max(worst, np.abs(xs[k, j] - xkn).max() / max(1.0, np.abs(xkn).max()))
+        x1n = xs[k, j].copy()
+    assert worst < 1e-7, f"{M.name} rep {rep} n={n} T={T}: smoothed states off by {worst:.2e} (relative)"
