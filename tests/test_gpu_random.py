@@ -174,7 +174,7 @@ def test_mahalanobis_gate_in_lane_groups_vs_oracle():
     assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-10, floor=1e-12, what=f"gated kind {k} P")
 
 
-@pytest.mark.parametrize("dim", [5, 8, 17])
+@pytest.mark.parametrize("dim", [5, 8, 17, 24, 32])
 def test_trace_vs_step_path_many_shapes(dim):
   """Fused-run trace against the step-granular path (GPU vs GPU, states to 1e-9) over a dozen random batch sizes / schedule
   lengths in ONE process -- the configuration that exposed a wrong trace for 8 error states when those still ran on the
