@@ -297,8 +297,10 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
 // diagonals, the two products as rolled loops with LDS-resident multipliers, and the factor read through an LDS pointer
 // "redefined" by an empty asm once per column (which stops hipcc from hoisting the substitution loads: 0 spills, 256 + 156
 // registers) -- ran at 21.2 us per step and wavefront (96 M steps/s) but returned wrong states for SOME inputs of the
-// 24-error-state random model (tools/lds_poison.hip + a numpy restatement found it; 11, 13, 17 and 22 states were fine;
-// cause not found), so this version stays.
+// 24-error-state random model (tools/lds_poison.hip + a numpy restatement found it; 11, 13, 17 and 22 states were fine).
+// The pinned LDS pointer alone, on this otherwise unchanged kernel (0 spills, 23.4 us per step and wavefront, 87 M steps/s),
+// reproduces exactly that failure -- wrong for 24 states, right for the others -- so it is the asm-pinned address-space-3
+// pointer that miscompiles there (cause not found), and this version, spills and all, stays.
 template <class Model>
 __global__ __launch_bounds__(64) void k_rts_wide(const double* __restrict__ xf, const double* __restrict__ Pf,
                                                  const double* __restrict__ ts, const int64_t T,
