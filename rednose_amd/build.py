@@ -6,6 +6,7 @@ lib{name}.so beside the header.  SCons is not available here and the target is a
 """
 import hashlib
 import os
+import re
 import shutil
 import subprocess
 
@@ -37,10 +38,48 @@ def compile_filter(folder, name, extra_flags=(), verbose=False):
   src = os.path.join(folder, f"{name}.hip")
   lib = os.path.join(folder, f"lib{name}.so")
   extra_flags = list(extra_flags) + os.environ.get("RN_HIPCC_FLAGS", "").split()     # A/B experiments only
-  cmd = [find_hipcc()] + HIPCC_FLAGS + extra_flags + ["-I", TEMPLATE_DIR, "-x", "hip", src, "-o", lib]
+  cmd = [find_hipcc()] + HIPCC_FLAGS + extra_flags + ["-Rpass-analysis=kernel-resource-usage", "-I", TEMPLATE_DIR, "-x", "hip", src, "-o", lib]
   if verbose:
     print(" ".join(cmd))
   res = subprocess.run(cmd, capture_output=True, text=True)
   if res.returncode != 0:
     raise RuntimeError(f"hipcc failed for {src}:\n{res.stderr[-6000:]}")
+  usage = kernel_resources(res.stderr)
+  with open(os.path.join(folder, f"{name}.kernels.txt"), "w", encoding="utf-8") as f:
+    f.write("# per-kernel resources reported by hipcc (-Rpass-analysis=kernel-resource-usage) for lib%s.so\n" % name)
+    f.write("%-60s %6s %6s %8s %8s %7s %6s\n" % ("kernel", "vgprs", "agprs", "scratch", "lds", "spills", "occ"))
+    for k, u in usage.items():
+      f.write("%-60s %6d %6d %8d %8d %7d %6d\n" % (k[:60], u["vgprs"], u["agprs"], u["scratch"], u["lds"], u["vgpr_spill"], u["occupancy"]))
+  if verbose:
+    for k, u in usage.items():
+      if u["scratch"] or u["vgpr_spill"]:
+        print(f"note: {k} uses {u['scratch']} B of scratch per lane ({u['vgpr_spill']} spilled VGPRs)")
   return lib
+
+
+def kernel_resources(remarks):
+  """Parse hipcc's kernel-resource-usage remarks: {demangled-ish kernel name: dict(vgprs, agprs, scratch, lds, vgpr_spill,
+  occupancy)}.  Written next to every library as {name}.kernels.txt: register spills cost a lone wavefront microseconds per
+  access, and the one build that spilled in a lane-per-filter kernel also produced wrong results."""
+  out, cur = {}, None
+  keys = (("vgprs", r" VGPRs: (\d+)"), ("agprs", r"AGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+          ("lds", r"LDS Size \[bytes/block\]: (\d+)"), ("vgpr_spill", r"VGPRs Spill: (\d+)"), ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)"))
+  for line in remarks.split("\n"):
+    m = re.search(r"Function Name: (\S+)", line)
+    if m:
+      mangled = m.group(1)
+      cur = mangled
+      mm = re.search(r"(?:N_1|2rn)(\d+)(k_\w+)", mangled)        # Itanium mangling: <length><identifier>
+      if mm:
+        ident = mm.group(2)[:int(mm.group(1))]
+        rest = mm.group(2)[int(mm.group(1)):]
+        cur = ident + ("<true>" if rest.startswith("ILb1E") else "<false>" if rest.startswith("ILb0E") else "")
+      out[cur] = dict(vgprs=0, agprs=0, scratch=0, lds=0, vgpr_spill=0, occupancy=0)
+      continue
+    if cur is None:
+      continue
+    for key, pat in keys:
+      m = re.search(pat, line)
+      if m:
+        out[cur][key] = int(m.group(1))
+  return out

@@ -76,3 +76,24 @@ def test_compute_without_device_fails_loudly(gen_dir):
     f.predict_and_update_batch(0.0, 1, np.zeros((1, 1)), np.ones((1, 1, 1)))
   with pytest.raises(KalmanError):
     BatchedEKF(gen_dir, "kinematic", np.eye(2), np.zeros(2), np.eye(2), 2, 2, batch=8)
+
+
+@pytest.mark.parametrize("name", ["kinematic", "kinematic6", "kinematic9", "live", "feature"])
+def test_step_kernels_do_not_spill(gen_dir, name):
+  """Every library is built with hipcc's per-kernel resource report next to it ({name}.kernels.txt).  The step kernels of the
+  shipped models must not touch scratch memory: a spill costs a lone wavefront microseconds per access, and the one
+  lane-per-filter build that spilled (8 error states) also produced wrong results."""
+  fn = os.path.join(gen_dir, f"{name}.kernels.txt")
+  assert os.path.exists(fn)
+  rows = {}
+  with open(fn, encoding="utf-8") as f:
+    for line in f:
+      if line.startswith("#") or line.startswith("kernel"):
+        continue
+      parts = line.split()
+      rows[parts[0]] = dict(zip(("vgprs", "agprs", "scratch", "lds", "spills", "occ"), map(int, parts[1:7])))
+  steps = {k: v for k, v in rows.items() if k.startswith("k_step_") or k == "k_predict"}
+  assert steps, rows.keys()
+  for k, v in steps.items():
+    assert v["scratch"] == 0 and v["spills"] == 0, f"{name}: {k} spills ({v})"
+    assert v["lds"] <= 65536
