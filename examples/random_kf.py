@@ -19,7 +19,7 @@ import sympy as sp
 from rednose_amd.helpers.kalmanfilter import KalmanFilter
 from rednose_amd.helpers.ekf_sym import EKF_sym, BatchedEKF, gen_code
 
-SIZES = (3, 5, 8, 11, 13, 17, 24, 32, 40)
+SIZES = (3, 5, 8, 11, 13, 17, 24, 32, 40, 56)
 
 
 def make(n, seed=None):

@@ -45,7 +45,7 @@ MODELS = {
   "attitude": dict(model="examples.attitude_kf:AttitudeKalman"),
   "feature": dict(model="examples.feature_kf:FeatureKalman"),
   "feature36": dict(model="examples.feature_kf:WideFeatureKalman"),
-  **{f"rand{n}": dict(model=f"examples.random_kf:Random{n}Kalman") for n in (3, 5, 8, 11, 13, 17, 24, 32, 40)},
+  **{f"rand{n}": dict(model=f"examples.random_kf:Random{n}Kalman") for n in (3, 5, 8, 11, 13, 17, 24, 32, 40, 56)},
   "rand13_maha": dict(model="examples.random_kf:Random13Kalman", rename="rand13_maha", maha_test_kinds=[1, 3]),
   "kinematic6_maha": dict(model="examples.kinematic6_kf:Kinematic6Kalman", rename="kinematic6_maha",
                           maha_test_kinds=[1]),

@@ -64,8 +64,9 @@ def tile_filters(spec):
   """Filters per wavefront tile: the tuning value rounded up to whole groups."""
   fpw = filters_per_wave(spec)
   ft = tuning.current().wide_ft
-  if ft == 0:      # auto: small records (<= 16 error states) -> two groups per tile, several wavefronts per SIMD; else 16
-    ft = 2 * fpw if spec.dim_err <= 16 else 16
+  if ft == 0:      # auto: small records (<= 16 error states) -> two groups per tile, several wavefronts per SIMD; else 16;
+    #                above 40 error states 8, to keep the block's LDS (P buffer + per-filter slots) under 64 KB
+    ft = 2 * fpw if spec.dim_err <= 16 else (16 if spec.dim_err <= 40 else 8)
   return -(-ft // fpw) * fpw
 
 
@@ -74,7 +75,7 @@ def double_buffered(spec):
   several wavefronts fit per SIMD and hide each other's HBM latency, and the second buffer only costs occupancy
   (kinematic9: 25.5-26.3 us per launch with a single buffer and tiles of 14 filters, 30.5 us with the live-tuned 16 / double)."""
   db = tuning.current().wide_db
-  return bool(db) if db >= 0 else spec.dim_err > 16
+  return bool(db) if db >= 0 else 16 < spec.dim_err <= 40       # above 40 error states a second E x E buffer does not fit 64 KB
 
 
 class Layout:

@@ -6,12 +6,12 @@ environment variable RN_TUNE, e.g.  RN_TUNE="wide_ft=8,wide_lb=2" python bench.p
 
   knob          default  measured alternatives (live = 23/22-state ESKF, batch 16 384; k6 = kinematic6, batch 65 536)
   wide_struct   2        1 = scalars evaluated redundantly in all 32 lanes of a group: live 122 us/launch vs 47 us
-  wide_ft       0 (auto) filters per wavefront tile; auto = 16 above 16 error states (live: 8 -> 52.8 us, 32 -> LDS allows only
+  wide_ft       0 (auto) filters per wavefront tile; auto = 8 above 40 error states (LDS budget), 16 above 16 error states (live: 8 -> 52.8 us, 32 -> LDS allows only
                          3 waves per CU), two groups below (kinematic9, 7 filters per group: 14 -> 25.5-26.3 us with a single
                          buffer, 7 -> 31.2, 21 -> 28.6, 28 -> 28.3; with the double buffer 16 -> 30.5, 42 -> 36.4, 63 -> 47.7)
   wide_lb       0        second argument of __launch_bounds__ (waves per SIMD): 2 forces <= 256 registers, hipcc then
                          spills 64-172 VGPRs to scratch: 87-138 us (0 = unconstrained, 1 wave per SIMD, 47 us)
-  wide_db       -1 (auto) double-buffered asynchronous P prefetch (1) or single buffer (0); auto = double above 16 error states
+  wide_db       -1 (auto) double-buffered asynchronous P prefetch (1) or single buffer (0); auto = double from 17 to 40 error states
                          (one wavefront per SIMD there: nothing else hides the HBM latency), single below
   wide_inline   1        0 = phase functions __noinline__: each fits 256 registers but pays scratch frames: 237 us
   wide_fpw      0        filters per wavefront in the matrix phase: 0 = 64 // dim_err (dim_err-lane groups when that is > 2, e.g. 7 filters

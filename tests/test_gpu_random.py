@@ -9,7 +9,7 @@ from conftest import assert_close
 
 pytestmark = pytest.mark.gpu
 
-SIZES = (3, 5, 8, 11, 13, 17, 24, 32, 40)
+SIZES = (3, 5, 8, 11, 13, 17, 24, 32, 40, 56)
 
 
 @pytest.fixture(scope="module", params=SIZES)
