@@ -104,3 +104,24 @@ def test_maha_test_matches_reference_decisions():
   f = EKF_sym(oracle_folder("live"), "live", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22)
   got = np.array([f.maha_test(g["x"][i], g["P"][i], 12, g["z"][i], g["R"]) for i in range(len(g["x"]))])
   assert np.array_equal(got, g["accepted"])
+
+
+def test_kernel_resource_report_parser():
+  """rednose_amd.build.kernel_resources: hipcc remarks -> per-kernel numbers written next to every library."""
+  from rednose_amd.build import kernel_resources
+  remarks = """x.hip:1:1: remark: Function Name: _ZN12_GLOBAL__N_112k_fn_err_funEPKdS1_Pd [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     VGPRs: 13 [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     AGPRs: 0 [-Rpass-analysis=kernel-resource-usage]
+x.hip:2:1: remark: Function Name: _ZN12_GLOBAL__N_18k_step_1ILb1EEEvPdS1_S1_PKdiS3_S3_S3_dliPh [-Rpass-analysis=kernel-resource-usage]
+x.hip:2:1: remark:     VGPRs: 242 [-Rpass-analysis=kernel-resource-usage]
+x.hip:2:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]
+x.hip:2:1: remark:     Occupancy [waves/SIMD]: 2 [-Rpass-analysis=kernel-resource-usage]
+x.hip:2:1: remark:     LDS Size [bytes/block]: 28960 [-Rpass-analysis=kernel-resource-usage]
+x.hip:3:1: remark: Function Name: _ZN2rn10k_rts_wideIN12_GLOBAL__N_18RtsModelEEEvPKdS4_S4_lS4_liPdS5_ [-Rpass-analysis=kernel-resource-usage]
+x.hip:3:1: remark:     ScratchSize [bytes/lane]: 464 [-Rpass-analysis=kernel-resource-usage]
+x.hip:3:1: remark:     VGPRs Spill: 129 [-Rpass-analysis=kernel-resource-usage]
+"""
+  u = kernel_resources(remarks)
+  assert list(u) == ["k_fn_err_fun", "k_step_1<true>", "k_rts_wide"]
+  assert u["k_step_1<true>"] == dict(vgprs=242, agprs=0, scratch=0, lds=28960, vgpr_spill=0, occupancy=2)
+  assert u["k_rts_wide"]["scratch"] == 464 and u["k_rts_wide"]["vgpr_spill"] == 129
