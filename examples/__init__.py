@@ -25,6 +25,7 @@ def model_table():
     "feature36": lambda d: WideFeatureKalman.generate_code(d),
     "live": lambda d: LiveKalman.generate_code(d),
     **{f"rand{n}": (lambda d, n=n: _random(n).generate_code(d)) for n in _random_sizes()},
+    **{f"randaff{n}": (lambda d, n=n: _random(n, affine=True).generate_code(d)) for n in _affine_sizes()},
     "rand13_maha": lambda d: _renamed(_random(13), "rand13_maha", d, maha_test_kinds=[1, 3]),
     "live_maha": lambda d: LiveKalman.generate_code(d, name="live_maha", maha_test_kinds=[LK.ECEF_POS]),
   }
@@ -35,9 +36,14 @@ def _random_sizes():
   return SIZES
 
 
-def _random(n):
+def _affine_sizes():
+  from examples.random_kf import AFFINE_SIZES
+  return AFFINE_SIZES
+
+
+def _random(n, affine=False):
   import examples.random_kf as R
-  return getattr(R, f"Random{n}Kalman")
+  return getattr(R, f"RandomAffine{n}Kalman" if affine else f"Random{n}Kalman")
 
 
 def _renamed(cls, name, folder, **kw):

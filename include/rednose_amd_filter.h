@@ -90,9 +90,14 @@ extern "C" {
                              double *trace_x, double *trace_P, void *stream);                                     \
   /* Rauch-Tung-Striebel backward pass over a filtered trace; replaces the Python-only EKF_sym.rts_smooth        \
    * (/root/reference/rednose/helpers/ekf_sym.py:651-690).  xs/Ps may alias xf/Pf.  norm_quats: bit 0 = renormalise the   \
-   * recomputed predicted states (as the forward pass did), bit 1 = the reference's norm_quats (smoothed states). */                             \
+   * recomputed predicted states (as the forward pass did), bit 1 = the reference's norm_quats (smoothed states).       \
+   * x_last (n, D) / P_last (n, E, E), both optional (NULL): the PREDICTED pair of the last step, which the reference     \
+   * returns verbatim as the newest smoothed estimate (estimates[-1][0], [2], ekf_sym.py:658-659); NULL = recomputed from  \
+   * the filtered pair of step T-2 (exact unless an MSCKF window shift happened in between).  MSCKF models: only the     \
+   * main block / main states are smoothed, the rest of each filtered estimate passes through (ekf_sym.py:675-686). */    \
   int RN_FN(name, batch_rts)(const double *xf, const double *Pf, const double *ts, int64_t T, const double *Q,     \
-                             int64_t n, int norm_quats, double *xs, double *Ps, void *stream);
+                             int64_t n, int norm_quats, double *xs, double *Ps, const double *x_last,             \
+                             const double *P_last, void *stream);
 
 /* MSCKF models only (gen_code msckf_params): window shift of EKF_sym.augment (ekf_sym.py:365-391) on n filters, in place */
 #define RN_DECLARE_BATCH_MSCKF(name)                                                                             \

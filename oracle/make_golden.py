@@ -267,6 +267,7 @@ def feature_goldens(T=45, cls_name="FeatureKalman", out_name="feature_stream.npz
   truth_p, truth_v = np.zeros(3), np.array([1.0, 0.5, 0.0])
   window = [np.zeros(3)] * FK.n_window
   recs = dict(kinds=[], ts=[], zs=[], eas=[], augment=[], xk_k=[], Pk_k=[], xk_km1=[], Pk_km1=[], ys=[])
+  ests = []
   t = 0.0
   for i in range(T):
     t += 0.05
@@ -283,6 +284,7 @@ def feature_goldens(T=45, cls_name="FeatureKalman", out_name="feature_stream.npz
     est = f.predict_and_update_batch(t, kind, np.array([z]), np.array([R]), [list(ea)] if kind == 2 else [[]], augment=aug)
     if aug:
       window = window[1:] + [truth_p.copy()]
+    ests.append(est)
     y = np.ravel(est[6][0])
     recs["kinds"].append(kind); recs["ts"].append(t); recs["zs"].append(np.concatenate([z, np.zeros(ZF - len(z))]))
     recs["eas"].append(ea); recs["augment"].append(aug)
@@ -304,8 +306,12 @@ def feature_goldens(T=45, cls_name="FeatureKalman", out_name="feature_stream.npz
     x1, P1, y1 = f._update_python(xs[i].reshape(-1, 1).copy(), Ps[i].copy(), 2, zs[i].copy(), np.eye(ZF) * 0.01**2, extra_args=eas[i].copy())  # pylint: disable=protected-access
     ux.append(np.ravel(x1)); uP.append(P1); uy.append(np.ravel(y1))
   out = {k: np.array(v) for k, v in recs.items()}
+  # the reference's smoother on this MSCKF trajectory: only the main block / main states are smoothed (ekf_sym.py:675-686).
+  # It aliases and mutates its input -- a deep copy goes in.
+  import copy
+  xs_smooth, Ps_smooth = f.rts_smooth(copy.deepcopy(ests), norm_quats=False)
   np.savez_compressed(os.path.join(GOLD, out_name), **out, upd_x_in=xs, upd_P_in=Ps, upd_ea=eas, upd_z=zs,
-                      upd_x=np.array(ux), upd_P=np.array(uP), upd_y=np.array(uy))
+                      upd_x=np.array(ux), upd_P=np.array(uP), upd_y=np.array(uy), xs_smooth=xs_smooth, Ps_smooth=Ps_smooth)
   print("feature stream: final x[:6]", out["x_after"][-1][:6], "y dims", {len(np.ravel(e)) for e in uy})
 
 

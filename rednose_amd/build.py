@@ -54,7 +54,13 @@ def compile_filter(folder, name, extra_flags=(), verbose=False):
     for k, u in usage.items():
       if u["scratch"] or u["vgpr_spill"]:
         print(f"note: {k} uses {u['scratch']} B of scratch per lane ({u['vgpr_spill']} spilled VGPRs)")
+  compile_filter.last_usage = usage
   return lib
+
+
+def spilled_kernels(usage, prefixes=("k_step", "k_run", "k_predict", "k_rts", "k_maha")):
+  """Names of shipped kernels that use scratch memory or spilled registers."""
+  return [k for k, u in usage.items() if k.startswith(prefixes) and (u["scratch"] > 0 or u["vgpr_spill"] > 0)]
 
 
 def kernel_resources(remarks):

@@ -384,7 +384,9 @@ def run_kernel(spec, norm):
   cases = []
   for k in spec.kinds:
     Z = k.zdim
-    ea = ", nullptr" if k.ea_sym is not None else ""
+    if k.ea_sym is not None:
+      continue       # kinds with per-observation extra arguments are not served by the fused run: `default` reports flag 8
+    ea = ""
     cases.append(f"""        case {k.kind}: {{
           double zk[{Z}], Rk[{Z * Z}];
 #pragma unroll

@@ -37,7 +37,7 @@ def _even(n):
   return n + (n & 1)
 
 
-def predict_fn(spec, rts=False):
+def predict_fn(spec):
   D, E, M = spec.dim_x, spec.dim_err, spec.dim_main_err
   names = {**vector_names(spec.x_sym, 'x'), spec.dt_sym: 'dt'}
   blk = Block(names, tmp_prefix="pt")
@@ -54,9 +54,6 @@ def predict_fn(spec, rts=False):
   b.append(f"double a[{E}];")
   for i in range(E):
     b.append(f"a[{i}] = {sum_terms(term(cf, f'row[{k}]') for k, cf in F.row_nz(i))};")
-  if rts:
-    b.append("#pragma unroll")
-    b.append(f"for (int i = 0; i < {E}; i++) arow[i] = a[i];       // column c of M = F P^T, the smoother's right-hand side")
   b.append("if (act) {")
   b.append("#pragma unroll")
   b.append(f"  for (int i = 0; i < {E}; i++) sP[cc * {E} + i] = a[i];")
@@ -79,12 +76,8 @@ def predict_fn(spec, rts=False):
   for i in range(D):
     kind, val = st[f"xn_{i}"]
     b.append(f"x[{i}] = xn_{i};" if kind == 'expr' else f"x[{i}] = {float(val)!r};")
-  if rts:
-    head = (f"__device__ __forceinline__ void predict_wide_rts(double (&x)[{D}], double (&row)[{E}], double (&arow)[{E}], double (&col)[{E}], "
-            "double* sP, const double* sQ, const double dt, const int cc, const bool act) {\n  constexpr bool WANT_ROW = false;")
-  else:
-    head = (f"template <bool WANT_ROW>\n__device__ __forceinline__ void predict_wide(double (&x)[{D}], double (&row)[{E}], double (&col)[{E}], "
-            "double* sP, const double* sQ, const double dt, const int cc, const bool act) {")
+  head = (f"template <bool WANT_ROW>\n__device__ __forceinline__ void predict_wide(double (&x)[{D}], double (&row)[{E}], double (&col)[{E}], "
+          "double* sP, const double* sQ, const double dt, const int cc, const bool act) {")
   return "\n".join([head] + _ind(b) + ["}"])
 
 
@@ -183,7 +176,6 @@ def kernels(spec, step_kernels=True):
   zmax = max(k.zdim for k in spec.kinds)
   out = [f"constexpr int GL = {G_LANES};    // lanes per filter", f"constexpr int FPW = {FPW};   // filters per wavefront", ""]
   out.append(predict_fn(spec))
-  out.append(predict_fn(spec, rts=True))
   for k in run_kinds(spec):
     utxt, _ = update_fn(spec, k)
     out.append(utxt)
@@ -329,6 +321,8 @@ def run_kernel(spec, norm):
           for (int i = 0; i < {Z}; i++) z[i] = zk[i];
           break;
         }}""")
+  # the dt == 0 shortcut below is only emitted for models whose predict(dt = 0) is symbolically the identity
+  id0_guard = "" if spec.identity_at_dt0() else "true || "
   return f"""
 // ---- fused multi-step run: kinds[t], dts[t] shared by all filters; z is (T, n, {zmax}) in: z, out: y -----------
 __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __restrict__ gP, const double* __restrict__ gQ,
@@ -371,7 +365,7 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       if (t + 1 < T && lane < cnt * {zmax}) zn = gz[((t + 1) * n + base) * {zmax} + lane];
       const int kind = kinds[t];
       const double dt = dts[t];
-      if (dt != 0.0) {{
+      if ({id0_guard}dt != 0.0) {{
         predict_wide<true>(x, row, col, s_P + gg * {EE}, s_Q, dt, cc, on);
       }} else {{
         // predict(dt = 0) is the identity on (x, P) for finite states (F = I, dt Q = 0): only the column view of P

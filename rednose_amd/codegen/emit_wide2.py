@@ -361,6 +361,22 @@ def device_functions(spec):
   out.append("\n".join([f"__device__ {INL} void mat_predict(double* sP, {qarg}, const double* sl, const int cc, const bool act) {{"]
                         + _ind(b) + ["}"]))
 
+  # ---- smoother (templates/ekf_hip_rts.h, k_rts_group): main block of the predicted pair from a row held in registers -----
+  # row = row c of Pk_k[:M, :M]; y <- column c of F Pk_k^T; sB (M x M, stride M) <- F Pk_k F^T + dt Q[:M, :M].
+  # Only two register vectors are live at a time (y + the column of P F^T): each entry of the result goes to LDS as soon as
+  # it is formed -- the lane rewrites its OWN column of sB, which no other lane reads in this function.
+  M = spec.dim_main_err
+  b = [f"const double dt = sl[{lay.OFF_DT}];"]
+  for i in range(M):
+    b.append(f"y[{i}] = {sum_terms(term(cf, f'row[{kk}]') for kk, cf in Fs.row_nz(i) if kk < M)};")
+  b += ["if (act) {", "#pragma unroll", f"  for (int i = 0; i < {M}; i++) sB[cc * {M} + i] = y[i];", "}", "rn::wave_lds_sync();",
+        f"double a[{M}];", "#pragma unroll", f"for (int k = 0; k < {M}; k++) a[k] = sB[k * {M} + cc];", "rn::wave_lds_sync();"]
+  for i in range(M):
+    b.append(f"{{ const double v = {sum_terms(term(cf, f'a[{kk}]') for kk, cf in Fs.row_nz(i) if kk < M)} + dt*gQ[{i * E} + cc]; if (act) sB[{i * M} + cc] = v; }}")
+  b += ["rn::wave_lds_sync();"]
+  out.append("\n".join([f"__device__ __forceinline__ void mat_predict_rts(const double (&row)[{M}], double* sB, const double* __restrict__ gQ, "
+                        f"const double* sl, const int cc, const bool act, double (&y)[{M}]) {{"] + _ind(b) + ["}"]))
+
   # ---- phase 2: update, matrix part ----------------------------------------------------------------------
   for k in spec.kinds:
     _, _, He, he_vars = obs[k.kind]
@@ -418,9 +434,12 @@ def kernels(spec):
   GL = group_lanes(spec)
   fn_text, lay = device_functions(spec)
   out = [f"// ---- family W, three-phase step kernels (tile of {FT} filters per wavefront, slot = {lay.SLOT} doubles) ----",
-         f"constexpr int FT2 = {FT};", f"constexpr int SLOT = {lay.SLOT};", fn_text]
+         f"constexpr int FT2 = {FT};", f"constexpr int SLOT = {lay.SLOT};", f"constexpr int SLOT_OFF_X = {lay.OFF_X};",
+         f"constexpr int SLOT_OFF_DT = {lay.OFF_DT};", fn_text]
   tune = tuning.current()
   lbs = f"__launch_bounds__(64, {tune.wide_lb})" if tune.wide_lb else "__launch_bounds__(64)"
+  if tune.wide_timeline:
+    out.append("__device__ unsigned long long g_tl[256 * 64 * 2];      // debug timeline (tuning knob wide_timeline)")
 
   def kernel(kname, k=None):
     upd = k is not None
@@ -433,6 +452,11 @@ def kernels(spec):
     flags_arg = ", uint8_t* __restrict__ flags" if upd else ""
     L = []
     A = L.append
+    TLK = tune.wide_timeline
+
+    def TL(idx):      # debug stamps (tuning knob wide_timeline): [block][slot][0] = shader cycles, [1] = 100 MHz wall clock
+      if TLK:
+        A(f"    if (lane == 0 && blockIdx.x < 256) {{ const int ti_ = {idx}; if (ti_ < 64) {{ g_tl[(blockIdx.x * 64 + ti_) * 2] = __builtin_readcyclecounter(); g_tl[(blockIdx.x * 64 + ti_) * 2 + 1] = wall_clock64(); }} }}")
     A(f"{tmpl}__global__ {lbs} void {kname}(double* __restrict__ gx, double* __restrict__ gP,")
     A(f"    {sig_obs}const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,")
     A(f"    const int norm_quats{flags_arg}) {{")
@@ -460,13 +484,19 @@ def kernels(spec):
       A(f"  double qcol[{E}];                          // column cc of Q, resident for the whole launch")
       A("#pragma unroll")
       A(f"  for (int i = 0; i < {E}; i++) qcol[i] = ({dop} && gQ != nullptr) ? gQ[i * {E} + cc] : 0.0;")
-    A("  // predict with a uniform dt == 0 (a second observation at the same timestamp) is the identity on (x, P) for finite")
-    A("  // states: F = I + dt A = I and dt Q = 0 exactly, so the covariance phase is skipped; results are unchanged.")
-    A(f"  const bool do_pred = {dop} && !(gdt == nullptr && dt_scalar == 0.0);")
+    if spec.identity_at_dt0():
+      A("  // predict with a uniform dt == 0 (a second observation at the same timestamp) is the identity on (x, P) for finite")
+      A("  // states: f(x, 0) == x and F(x, 0) == I were checked SYMBOLICALLY for this model at generation time")
+      A("  // (FilterSpec.identity_at_dt0) and dt Q = 0, so the covariance phase is skipped; results are unchanged.")
+      A(f"  const bool do_pred = {dop} && !(gdt == nullptr && dt_scalar == 0.0);")
+    else:
+      A("  // this model's f(x, 0) != x or F(x, 0) != I: predict runs on every call, dt == 0 included (ekf_c.c:15-28)")
+      A(f"  const bool do_pred = {dop};")
     A("  const int64_t tiles = (n + FT2 - 1) / FT2;")
     A("  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {")
     A("    const int64_t base = tile * FT2;")
     A("    const int cnt = (n - base) < FT2 ? (int)(n - base) : FT2;")
+    TL(0)
     A("    // ---------------- phase 1: lane l = filter l, x-dependent scalars -> LDS slot ----------------")
     A(f"    rn::copy_g2l<FT2 * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);")
     if upd:
@@ -474,6 +504,7 @@ def kernels(spec):
     if DB:
       A(f"    {CPIN}<{PBUF}>(gP + base * {EE}, (cnt < {FPW} ? cnt : {FPW}) * {EE}, s_P[0], lane);")
     A("    rn::wave_lds_sync();")
+    TL(1)
     A("    if (lane < cnt) {")
     A("      double* sl = s_sl + lane * SLOT;")
     A("      if (do_pred) {")
@@ -486,6 +517,7 @@ def kernels(spec):
       A(f"      {_obs_call(k, 'true')};")
     A("    }")
     A("    rn::wave_lds_sync();")
+    TL(2)
     A(f"    // ---------------- phase 2: {GL}-lane group per filter, {FPW} filters at a time, covariance algebra ----------")
     A(f"    const int ngroups = (cnt + {FPW - 1}) / {FPW};")
     A("    for (int p = 0; p < ngroups; p++) {")
@@ -504,16 +536,21 @@ def kernels(spec):
       A(f"      {CPIN}<{PBUF}>(gPp, pcnt * {EE}, sPb, lane);")
       A("      rn::async_wait();")
       A("      rn::wave_lds_sync();")
+    TL("4 + 4 * p")
     A("      double* sPc = sPb + sh;")
     A("      const int gg = g < pcnt ? g : 0;")
     A("      const bool on = act && g < pcnt;")
     A(f"      double* sl = s_sl + ({FPW} * p + gg) * SLOT;")
     A(f"      if (do_pred) mat_predict(sPc + gg * {EE}, qcol, sl, cc, on);")
+    TL("5 + 4 * p")
     if upd:
       A(f"      mat_update_{k.kind}(sPc + gg * {EE}, r_per_filter ? gR + (base + {FPW} * p + gg) * {ZZ} : gR, sl, sl, s_G + gg * {Z * E}, s_K + gg * {Z * E}, cc, on);")
+    TL("6 + 4 * p")
     A(f"      rn::copy_l2g_any<{PBUF}>(gPp, pcnt * {EE}, sPb, sh, lane);" if ODD else f"      rn::copy_l2g<{PBUF}>(gPp, pcnt * {EE}, sPb, lane);")
+    TL("7 + 4 * p")
     A("      rn::wave_lds_sync();")
     A("    }")
+    TL(3)
     A("    // ---------------- phase 3: lane l = filter l, inject the error state, write x / y / flags ---------")
     A("    if (lane < cnt) {")
     A("      const double* sl = s_sl + lane * SLOT;")
@@ -531,6 +568,7 @@ def kernels(spec):
     if upd:
       A(f"    rn::copy_l2g<FT2 * {Z}>(gz + base * {Z}, cnt * {Z}, s_z, lane);")
     A("    rn::wave_lds_sync();")
+    TL(63)
     A("  }")
     A("}")
     return "\n".join(L) + "\n"

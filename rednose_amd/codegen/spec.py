@@ -76,6 +76,22 @@ class FilterSpec:
         out.append(Routine(f'He_{k.kind}', k.He_sym, [self.x_sym, k.ea_sym]))
     return out
 
+  def identity_at_dt0(self):
+    """True when predict(dt = 0) is the identity on (x, P) for every finite state and finite Q: f(x, 0) == x and
+    F(x, 0)[:M, :M] == I symbolically.  The reference makes no such assumption -- it evaluates f and F on every call,
+    including the first one of a filter, whose dt is always 0 (ekf_c.c:15-28, ekf_sym.cc:198-206) -- so the kernel
+    emitters may skip the covariance phase of a dt == 0 predict ONLY when this holds (e.g. not for f = A x + dt g(x)
+    with A != I, a clamp, or a reset term)."""
+    if getattr(self, "_id0", None) is None:
+      x = sp.Matrix(self.x_sym)
+      f0 = sp.Matrix(self.f_sym).subs(self.dt_sym, 0)
+      M = self.dim_main_err
+      F0 = sp.Matrix(self.F_sym)[:M, :M].subs(self.dt_sym, 0)
+      ok = all(sp.simplify(f0[i] - x[i]) == 0 for i in range(self.dim_x))
+      ok = ok and all(sp.simplify(F0[i, j] - (1 if i == j else 0)) == 0 for i in range(M) for j in range(M))
+      object.__setattr__(self, "_id0", bool(ok))
+    return self._id0
+
   def kind(self, kind):
     for k in self.kinds:
       if k.kind == kind:

@@ -76,6 +76,8 @@ class Tuning:
   small_waves: int = 0
   small_max_e: int = 7
   small_lpf: int = 1
+  wide_timeline: int = 0     # debug: lane 0 of the first 256 workgroups stamps s_memtime / the 100 MHz wall clock at every phase boundary of
+                             # the three-phase step kernels into a device buffer read back by {name}_debug_timeline (tools/timeline.py)
 
 
 def current():

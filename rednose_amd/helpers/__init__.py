@@ -66,6 +66,11 @@ class CtypesFFI:
       return int(value)
     raise NotImplementedError(ctype)
 
+  @staticmethod
+  def string(value):
+    """cffi's ffi.string for a `const char *` return value (ctypes already hands back bytes)."""
+    return value if isinstance(value, bytes) else bytes(value or b"")
+
 
 class CtypesLib:
   def __init__(self, shared_fn, protos):
@@ -90,13 +95,22 @@ def lib_paths(folder, name):
   return os.path.join(folder, f"lib{name}.{shared_ext}"), os.path.join(folder, f"{name}.h")
 
 
-def load_code(folder, name):
-  """Returns (ffi, lib) exactly like the reference's load_code."""
+def load_code(folder, name, backend=None):
+  """Returns (ffi, lib) exactly like the reference's load_code.
+
+  backend: None = cffi when importable, else ctypes (what the reference-style EKF_sym uses); "ctypes" = always the ctypes
+  binding.  BatchedEKF asks for "ctypes": it marshals device pointers, streams and NULLs as ctypes values, which a cffi
+  library object rejects (cdata pointers / ffi.NULL required) -- cffi is a hard dependency of every real rednose
+  environment, so the batched path must not depend on which of the two is installed."""
   shared_fn, header_fn = lib_paths(folder, name)
   if not os.path.exists(shared_fn):
     raise KalmanError(f"generated filter library missing: {shared_fn} (run the model's generate_code / rednose_amd.build first)")
   with open(header_fn, encoding='utf-8') as f:
     header = f.read()
+  if backend not in (None, "cffi", "ctypes"):
+    raise ValueError(backend)
+  if backend == "ctypes" or os.environ.get("RN_LOADER") == "ctypes":
+    return CtypesFFI(), CtypesLib(shared_fn, parse_prototypes(header))
 
   try:
     from cffi import FFI  # type: ignore  # pylint: disable=import-outside-toplevel
@@ -108,4 +122,6 @@ def load_code(folder, name):
     ffi.cdef(keep)
     return ffi, ffi.dlopen(shared_fn)
   except ImportError:
+    if backend == "cffi":
+      raise
     return CtypesFFI(), CtypesLib(shared_fn, parse_prototypes(header))

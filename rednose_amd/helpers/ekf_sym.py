@@ -3,7 +3,7 @@ import ctypes
 import logging
 import os
 from bisect import bisect_right
-from collections import deque
+from collections import OrderedDict, deque
 
 import numpy as np
 
@@ -44,6 +44,28 @@ def gen_code(folder, name, f_sym, dt_sym, x_sym, obs_eqs, dim_x, dim_err, eskf_p
     f.write(source)
   if compile and not fresh:
     rn_build.compile_filter(folder, name, verbose=verbose)
+    # Register spills are not tolerated where they were seen to matter: a lane-per-filter build that spilled (8 error states
+    # in round 1) also produced a wrong fused-run trace on some runs, and whether hipcc spills depends on the user's f / h
+    # expressions, not only on the state count.  Such a model is regenerated in the lane-group family; a smoother kernel that
+    # spills is an error (RN_ALLOW_SPILLS=1 overrides, for experiments).
+    from rednose_amd.codegen import emit as rn_emit
+    bad = rn_build.spilled_kernels(rn_build.compile_filter.last_usage)
+    if bad and rn_emit.family(spec) == "small" and not os.environ.get("RN_ALLOW_SPILLS"):
+      if verbose:
+        print(f"{name}: lane-per-filter kernels {bad} spill registers -> regenerating in the lane-group family")
+      rn_emit.FORCE_WIDE.add(name)
+      header, source = emit(spec)         # the stamp keeps the digest of the FIRST emission: a later gen_code call of this
+      #                                     model emits the lane-per-filter text again, finds it stamped and reuses the library
+      with open(os.path.join(folder, f"{name}.h"), "w", encoding="utf-8") as f:
+        f.write(header)
+      with open(os.path.join(folder, f"{name}.hip"), "w", encoding="utf-8") as f:
+        f.write(source)
+      rn_build.compile_filter(folder, name, verbose=verbose)
+      bad = rn_build.spilled_kernels(rn_build.compile_filter.last_usage)
+    bad_rts = [k for k in bad if k.startswith("k_rts")]
+    if bad_rts and not os.environ.get("RN_ALLOW_SPILLS"):
+      raise RuntimeError(f"{name}: smoother kernel {bad_rts} spills registers (see {folder}/{name}.kernels.txt); "
+                         "set RN_ALLOW_SPILLS=1 to build it anyway")
     with open(stamp_fn, "w", encoding="utf-8") as f:
       f.write(digest)
   return spec
@@ -129,7 +151,7 @@ class EKF_sym:
   # -- library plumbing ---------------------------------------------------------------------------
   def _raise_if_failed(self, sym):
     if self._check is not None and self._check() != 0:
-      msg = self._errstr().decode() if self._errstr is not None else "library error"
+      msg = self._ffi.string(self._errstr()).decode() if self._errstr is not None else "library error"
       if self._clear is not None:
         self._clear()
       raise KalmanError(f"{self.name}_{sym}: {msg}")
@@ -356,6 +378,7 @@ class BatchedEKF:
   Compute goes through the generated library's `{name}_batch_*` entry points on the current torch HIP
   stream; torch is used only for device memory and streams.  No GPU / no library => KalmanError.
   """
+  R_CACHE_ENTRIES = 16
 
   def __init__(self, folder, name, Q, x_initial, P_initial, dim_main, dim_main_err,  # pylint: disable=dangerous-default-value
                N=0, dim_augment=0, dim_augment_err=0, maha_test_kinds=[], quaternion_idxs=[], global_vars=None,
@@ -381,7 +404,9 @@ class BatchedEKF:
     self.dim_main, self.dim_augment, self.dim_augment_err = dim_main, dim_augment, dim_augment_err
     self.augment_times = [0] * N
 
-    self._ffi, self._lib = load_code(folder, name)
+    # always the ctypes binding: every argument below is a ctypes value (device pointers, stream handles, None), which a
+    # cffi-dlopen'ed library would reject; EKF_sym keeps the reference's cffi-first loader for its host-pointer calls
+    self._ffi, self._lib = load_code(folder, name, backend="ctypes")
     dims = (ctypes.c_int * 3)()
     getattr(self._lib, f"{name}_dims")(ctypes.cast(dims, ctypes.c_void_p))
     self.dim_x, self.dim_err, self.dim_main_err = int(dims[0]), int(dims[1]), int(dims[2])
@@ -404,7 +429,7 @@ class BatchedEKF:
       raise KalmanError(f"library {name} was generated with maha_test_kinds={lib_maha}, constructor got {self.maha_test_kinds}")
 
     self.Q = torch.as_tensor(np.ascontiguousarray(Q, dtype=np.float64), device=self.device)
-    self._R_cache = {}
+    self._R_cache = OrderedDict()          # small LRU of shared (Z, Z) noise matrices already on the device
     self.flags = torch.zeros(self.batch, dtype=torch.uint8, device=self.device)
     self.init_state(x_initial, P_initial, None)
 
@@ -415,7 +440,7 @@ class BatchedEKF:
   def _call(self, sym, *args):
     rc = getattr(self._lib, f"{self.name}_{sym}")(*args)
     if rc != 0:
-      msg = getattr(self._lib, f"{self.name}_last_error_string")().decode()
+      msg = self._ffi.string(getattr(self._lib, f"{self.name}_last_error_string")()).decode()
       getattr(self._lib, f"{self.name}_clear_error")()
       raise KalmanError(f"{self.name}_{sym} -> {rc}: {msg}")
 
@@ -464,7 +489,7 @@ class BatchedEKF:
     """Run-time model scalar (gen_code's global_vars); like the reference it is per LIBRARY, shared by every filter."""
     getattr(self._lib, f"{self.name}_set_{global_var}")(float(val))
     if getattr(self._lib, f"{self.name}_last_error")() != 0:
-      raise KalmanError(getattr(self._lib, f"{self.name}_last_error_string")().decode())
+      raise KalmanError(self._ffi.string(getattr(self._lib, f"{self.name}_last_error_string")()).decode())
 
   # -- hot path -------------------------------------------------------------------------------------
   def _dt(self, t):
@@ -516,6 +541,10 @@ class BatchedEKF:
         Rd = self._dev(R, (Z, Z))
         if key is not None:
           self._R_cache[key] = Rd
+          while len(self._R_cache) > self.R_CACHE_ENTRIES:       # time-varying noise: bounded, oldest entry goes
+            self._R_cache.popitem(last=False)
+      elif key is not None:
+        self._R_cache.move_to_end(key)
       return z, Rd, 0
     return z, self._dev(R, (self.batch, Z, Z)), 1
 
@@ -676,6 +705,8 @@ class BatchedEKF:
     T = len(ts)
     assert kinds.shape == (T,)
     zmax = getattr(self._lib, f"{self.name}_zmax")()
+    if T == 0:         # empty schedule: a no-op, like the C ABI
+      return self._dev(zs, (0, self.batch, zmax)), None, None, None
     for k in set(kinds.tolist()):
       if k not in self.zdims:
         raise KeyError(k)
@@ -707,28 +738,36 @@ class BatchedEKF:
     return zs, tx, tP, fl
 
   # -- offline smoothing ----------------------------------------------------------------------------
-  def rts_smooth(self, trace_x, trace_P, ts, norm_quats=None, inplace=False):
+  def rts_smooth(self, trace_x, trace_P, ts, norm_quats=None, inplace=False, last_predicted=None):
     """Batched Rauch-Tung-Striebel backward pass over the filtered trace returned by run(trace=True).
 
     trace_x (T, N, D), trace_P (T, N, E, E) filtered states/covariances, ts (T,) their times.  Semantics are the
     reference's rts_smooth (ekf_sym.py:651-690) applied to every filter -- the recursion starts from the predicted
     pair of the last step and, with norm_quats, all returned states but the oldest are renormalised; the
-    predicted pairs are recomputed on the GPU from the filtered ones (templates/ekf_hip_rts.h).
+    predicted pairs are recomputed on the GPU from the filtered ones (templates/ekf_hip_rts.h).  MSCKF models: only
+    the main block of the covariance and the main states are smoothed, the rest passes through (:675-686).
+    last_predicted = (x (N, D), P (N, E, E)): the predicted pair of the last step (xk_km1, Pk_km1 of its estimate), which
+    the reference returns verbatim as the newest smoothed estimate; default: recomputed from the filtered pair of step
+    T - 2 (exact unless an MSCKF window shift happened between the last two steps).
     Returns (states (T, N, D), covs (T, N, E, E)) device tensors, oldest first.
     """
     torch = self._torch
     if not hasattr(self._lib, f"{self.name}_batch_rts"):
-      raise KalmanError(f"lib{self.name}.so has no batch_rts: the smoother is generated for non-MSCKF models of up to 24 error states")
+      raise KalmanError(f"lib{self.name}.so has no batch_rts entry point")
     T = int(trace_x.shape[0])
     xf = self._dev(trace_x, (T, self.batch, self.dim_x))
     Pf = self._dev(trace_P, (T, self.batch, self.dim_err, self.dim_err))
     td = self._dev(np.asarray(ts, dtype=np.float64) if not isinstance(ts, torch.Tensor) else ts, (T,))
     xs = xf if inplace else torch.empty_like(xf)
     Ps = Pf if inplace else torch.empty_like(Pf)
+    xl = Pl = None
+    if last_predicted is not None:
+      xl = self._dev(last_predicted[0], (self.batch, self.dim_x))
+      Pl = self._dev(last_predicted[1], (self.batch, self.dim_err, self.dim_err))
     # bit 0: the recomputed predicted states are renormalised like the forward pass did (a property of the filter);
     # bit 1: the reference's norm_quats argument (smoothed states)
     nq = self.norm_quats | ((self.norm_quats if norm_quats is None else int(bool(norm_quats))) << 1)
     self._call("batch_rts", self._p(xf), self._p(Pf), self._p(td), T, self._p(self.Q), self.batch, nq, self._p(xs), self._p(Ps),
-               self._stream())
-    self._keepalive_rts = (xf, Pf, td)
+               self._p(xl), self._p(Pl), self._stream())
+    self._keepalive_rts = (xf, Pf, td, xl, Pl)
     return xs, Ps

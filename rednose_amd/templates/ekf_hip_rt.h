@@ -13,6 +13,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <utility>
 #include <stdint.h>
 #include <stdio.h>
@@ -508,7 +509,12 @@ __device__ __forceinline__ void normalize_quat(double (&x)[DIM], int idx) {
 // ------------------------------------------------------------------------------------------------
 // host side: scratch for the single-filter host-pointer entry points (the reference's scalar ABI)
 // ------------------------------------------------------------------------------------------------
+// The reference's generated functions are re-entrant (stack arrays only, ekf_c.c:11-12,46-50).  Here they stage through ONE
+// device buffer per library, so every host-pointer entry point holds `mu` from the first H2D copy to the last D2H copy:
+// concurrent callers (e.g. two EKF_sym instances of one library on two threads) serialise instead of racing on the
+// buffer contents or on ensure()'s free / realloc.
 struct Scratch {
+  std::mutex mu;
   double* dev = nullptr;
   size_t cap = 0;   // doubles
   int ensure(size_t doubles) {

@@ -16,9 +16,10 @@
 // the forward pass; the predicted pair (xk1_k, Pk1_k) is recomputed here from the filtered pair of step k with the
 // same f/F code -- half the trace (140 GB instead of 279 GB at 2100 x 16384 live steps).  Outputs may alias inputs.
 //
-// Mapping: 32-lane group per filter (2 filters per wavefront), all E x E work matrices in the wave's private LDS,
-// lane c owns row/column c.  Pk1_k is SPD: Cholesky (unrolled, row-owner) + one forward/back substitution per lane
-// (lane c solves for column c of Ck^T).  No MFMA: 22 x 22 fp64 blocks, and the pass is bound by LDS/VALU latency.
+// Two kernels: k_rts for lane-per-filter models (the first mapping written: 2 filters per wavefront, every E x E matrix in
+// LDS, rolled loops -- these models have at most 7 error states, 4 - 7 wavefronts per SIMD) and k_rts_group for lane-group
+// models (see its header).  No MFMA: the blocks are <= 64 x 64 fp64 per filter and on CDNA4 the fp64 matrix rate equals the
+// vector rate.
 #pragma once
 
 #include "ekf_hip_rt.h"
@@ -104,24 +105,7 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
 
       // ---- recompute the predicted pair of step k+1 exactly as the forward pass did ----------------------
       const bool first = (k == T - 2);     // recursion start: smoothed(T-1) := predicted(T-1)  (estimates[-1][0], [2])
-      if constexpr (Model::SPARSE) {
-        // generated sparse predict (F has ~33 non-trivial entries of 484): the same code the forward kernels run
-        double mcol[E], p1col[E];
-#pragma unroll
-        for (int i = 0; i < D; i++) x1k[i] = xk[i];
-        Model::predict_cov(x1k, prow, mcol, p1col, L, s_Q, dt, cc, on);        // L <- Pk1_k (full matrix), x1k <- f(xk)
-        if (norm_quats & 1) Model::normalize(x1k);
-        if (on) {
-#pragma unroll
-          for (int i = 0; i < E; i++) {
-            M[i * E + c] = mcol[i];
-            if (first) Nn[i * E + c] = p1col[i];
-            Dm[i * E + c] = Nn[i * E + c] - p1col[i];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < E; j++) prow[j] = A[cc * E + j];                 // predict_cov consumed the row registers
-      } else {
+      {
         Model::f(xk, dt, x1k);
         if (norm_quats & 1) Model::normalize(x1k);
         if (c == 0 && g < cnt) Model::F(xk, dt, Fm);
@@ -270,242 +254,327 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
   }
 }
 
-// ---- lane-group models with a generated sparse predict (Model::SPARSE): register-resident solves -----------------------
-// Same recursion and quirks as k_rts below; what differs is where the work lives.  Lane c keeps its row of the Cholesky
-// factor, its right-hand side / solution column and its rows of T = Ck (Pk1_n - Pk1_k) and Pk_n in REGISTERS; LDS holds
-// only what other lanes must see (the factor, Ck, the difference matrix, Pk1_n) and every LDS read is a broadcast or a
-// lane-private row, issued from fully unrolled code so that none of them sits on a dependent chain:
-//   * Cholesky, left-looking: at column j every lane reads pivot row j (final since step j-1) and forms BOTH its own
-//     entry and the pivot redundantly -> no publish / wait round trip per column (the rolled version paid two wave
-//     syncs + sqrt + division per column); reciprocal square root by v_rsq_f64 + Newton.
-//   * forward / back substitution, right-looking on the register column: as soon as y[m] is final, all later entries are
-//     updated by independent FMAs.
-//   * the filtered pair of step k-1 streams HBM -> LDS (global_load_lds) while step k computes; Pk_k's row is taken to
-//     registers first, so one buffer suffices.
-// LDS: 4 E x E matrices per filter (36 KB per wave for E = 22, 4 waves per CU) instead of 7 (51 KB, 3 waves).
-// Measured (live, 16 384 filters): 26.5 us per step and wavefront against ~42 us for k_rts; timing with phases removed
-// puts ~20 us of that in the factorisation -- a serial chain of (j + 10) DEPENDENT fp64 operations per column j
-// (dot product, v_rsq_f64 + two Newton steps, scaling) plus an LDS write -> broadcast-read turnaround, on a wavefront
-// that is alone on its SIMD (LDS holds 8 filters per CU).  Things that did NOT help, measured: 4 partial sums per dot
-// product (+12 %: more instructions, same chain through the pivot), __builtin_amdgcn_sched_barrier / asm memory fences /
-// never-taken aliasing stores between unrolled iterations (each sends the register allocator to 6 KB of scratch per lane),
-// per-column predicates (one exec mask per column is hoisted out of the step loop: 190 SGPR spills; a single predicate
-// and harmless stores above the pivot brought that to 61).  A variant with only two LDS matrices per filter (rows of
-// Pk1_n carried in registers, the prefetch landing in the dead difference matrix: 18 KB per wave, enough for two waves
-// per SIMD) needs <= 256 registers for that, and the generated predict alone keeps ~270 live: 1 264 spilled VGPRs under
-// every -amdgpu-sched-strategy, so it was dropped.  A later variant -- right-looking factorisation with redundantly tracked
-// diagonals, the two products as rolled loops with LDS-resident multipliers, and the factor read through an LDS pointer
-// "redefined" by an empty asm once per column (which stops hipcc from hoisting the substitution loads: 0 spills, 256 + 156
-// registers) -- ran at 21.2 us per step and wavefront (96 M steps/s) but returned wrong states for SOME inputs of the
-// 24-error-state random model (tools/lds_poison.hip + a numpy restatement found it; 11, 13, 17 and 22 states were fine).
-// The pinned LDS pointer alone, on this otherwise unchanged kernel (0 spills, 23.4 us per step and wavefront, 87 M steps/s),
-// reproduces exactly that failure -- wrong for 24 states, right for the others -- so it is the asm-pinned address-space-3
-// pointer that miscompiles there (cause not found), and this version, spills and all, stays.
+// =====================================================================================================================
+// k_rts_group -- smoother for lane-group models (8 .. 64 error states in the main block), second mapping.
+//
+// What bounded k_rts_wide (above) was not arithmetic: 4 E x E matrices per filter in LDS (36 KB per wavefront for 22 error
+// states) left one wavefront per SIMD, and the fully unrolled register-resident algebra needed 256 + 256 registers and still
+// spilled 129 of them -- a scratch access costs a lone wavefront about a microsecond.  This kernel is built around the two
+// budgets instead:
+//   * LDS: TWO main-block matrices per filter.  s_B holds Pk1_k, is factored in place, and finally takes Ck^T; s_C holds the
+//     difference Pk1_n - Pk1_k.  The filtered covariance never passes through LDS: lane c loads row c of Pk_k straight from HBM
+//     into registers (a row is contiguous; 16-byte loads when rows are 16-byte aligned) and stores row c of the smoothed
+//     covariance the same way.  Q is read from global memory (L1/L2 hits; 1 column per lane and step).
+//     22 error states: 15.5 KB of matrices + ~2 KB of vectors per wavefront -> 8 wavefronts per CU.
+//   * registers: <= 256 up to 22 error states (__launch_bounds__(64, 2), two wavefronts per SIMD; about six row vectors are
+//     live at the widest point, so larger models get the full file and one wavefront per SIMD: Model::WAVES).  Per lane only ONE row / column of a matrix is
+//     live at a time next to the right-hand side y: the state-dependent scalars (f, F non-zeros) are evaluated by one lane per
+//     filter into an LDS slot -- the phase-1 function of the three-phase step kernels (emit_wide2.scal_predict) -- instead of
+//     being replicated in every lane, and the state vectors live in LDS between the places that use them.
+// The recursion, its quirks (start from the PREDICTED pair of the last step, in-place renormalisation of every xk1_n) and the
+// norm_quats bit mask are those of k_rts.  MSCKF models (ekf_sym.py:675-686): only the main block [:EM, :EM] of the covariance and
+// the main states [:DM] are smoothed; everything else of (xk_k, Pk_k) passes through.  The main block of the predicted pair is
+// recomputed from the filtered main block (F_main Pk_k[:EM, :EM] F_main^T + dt Q[:EM, :EM], ekf_c.c:24,28), which assumes what
+// an MSCKF means: main dynamics that do not read the window clones.  The predicted pair of the LAST step, which the reference
+// returns verbatim as the newest smoothed estimate, can be passed in (xl, Pl); otherwise it is recomputed as well (exact for
+// models without a window; for MSCKF models the window part of that one estimate is then the filtered one).
+//
+// Model: constants D, E, DM, EM, SLOT, OFF_X, OFF_DT and the functions
+//   scal(xin, dt, sl, norm)                      one filter's f / F non-zeros -> slot (x' = f(x) [normalised] at sl[OFF_X..])
+//   mat_predict(row, sB, gQ, sl, cc, act, y)     row c of Pk_k -> y = column c of M = F Pk_k^T, sB <- Pk1_k (EM x EM)
+//   inv_err, err, normalize                      as for k_rts
+// Forces `v` to exist in registers at this point of the instruction stream (an empty volatile asm that "modifies" it):
+// arithmetic producing v cannot sink below, arithmetic consuming it cannot rise above.  No instruction is emitted.
+__device__ __forceinline__ void pin(double& v) { asm volatile("" : "+v"(v)); }
+
+template <int E, int EM>
+__device__ __forceinline__ void rts_load_row(const double* __restrict__ p, double (&r)[EM]) {
+  if constexpr (E % 2 == 0 && EM % 2 == 0) {
+    const double2* __restrict__ p2 = reinterpret_cast<const double2*>(p);
+#pragma unroll
+    for (int j = 0; j < EM / 2; j++) { const double2 v = p2[j]; r[2 * j] = v.x; r[2 * j + 1] = v.y; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < EM; j++) r[j] = p[j];
+  }
+}
+
+template <int E, int EM>
+__device__ __forceinline__ void rts_store_row(double* __restrict__ p, const double (&r)[EM]) {
+  if constexpr (E % 2 == 0 && EM % 2 == 0) {
+    double2* __restrict__ p2 = reinterpret_cast<double2*>(p);
+#pragma unroll
+    for (int j = 0; j < EM / 2; j++) { double2 v; v.x = r[2 * j]; v.y = r[2 * j + 1]; p2[j] = v; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < EM; j++) p[j] = r[j];
+  }
+}
+
 template <class Model>
-__global__ __launch_bounds__(64) void k_rts_wide(const double* __restrict__ xf, const double* __restrict__ Pf,
-                                                 const double* __restrict__ ts, const int64_t T,
-                                                 const double* __restrict__ gQ, const int64_t n, const int norm_quats,
-                                                 double* __restrict__ xs, double* __restrict__ Ps) {
-  constexpr int D = Model::D, E = Model::E, EE = E * E, GL = 32, FPW = 2;
-  constexpr int DP = D + (D & 1);
-  constexpr int ABUF = (FPW * EE + 3) / 2 * 2, XBUF = (FPW * D + 3) / 2 * 2;
-  __shared__ __attribute__((aligned(16))) double s_A[ABUF];       // Pk_k staging, prefetched one step ahead
-  __shared__ __attribute__((aligned(16))) double s_L[FPW * EE];   // Pk1_k -> its Cholesky factor -> Ck
-  __shared__ __attribute__((aligned(16))) double s_D[FPW * EE];   // Pk1_n - Pk1_k
-  __shared__ __attribute__((aligned(16))) double s_N[FPW * EE];   // Pk1_n; also the staging of the smoothed output
-  __shared__ __attribute__((aligned(16))) double s_Q[EE];
-  __shared__ __attribute__((aligned(16))) double s_xin[XBUF];     // xk_k staging, prefetched
-  __shared__ __attribute__((aligned(16))) double s_x[FPW * DP];   // smoothed state going out
-  __shared__ __attribute__((aligned(16))) double s_xk[2 * FPW * DP];  // xk_k and xk1_k parked during the factorisation
-  __shared__ __attribute__((aligned(16))) double s_xn[FPW * DP];      // xk1_n, the smoothed state of step k+1
-  __shared__ __attribute__((aligned(16))) double s_il[FPW * E];       // reciprocal pivots of the factor
-  __shared__ __attribute__((aligned(16))) double s_d[FPW * E];
+__global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __restrict__ xf, const double* __restrict__ Pf,
+                                                     const double* __restrict__ ts, const int64_t T,
+                                                     const double* __restrict__ gQ, const int64_t n, const int norm_quats,
+                                                     double* __restrict__ xs, double* __restrict__ Ps,
+                                                     const double* __restrict__ xl, const double* __restrict__ Pl) {
+  constexpr int D = Model::D, E = Model::E, EE = E * E, DM = Model::DM, EM = Model::EM, MM = EM * EM;
+  constexpr int GL = EM <= 16 ? 16 : (EM <= 32 ? 32 : 64), FPW = 64 / GL;
+  constexpr int SLOT = Model::SLOT;
+  constexpr int MMP = MM + (MM & 1), DP = D + (D & 1), EP = E + (E & 1), EMP = EM + (EM & 1);
+  __shared__ __attribute__((aligned(16))) double s_B[FPW * MMP];    // Pk1_k -> Cholesky factor (lower) -> Ck^T
+  __shared__ __attribute__((aligned(16))) double s_C[FPW * MMP];    // Pk1_n - Pk1_k
+  __shared__ __attribute__((aligned(16))) double s_sl[FPW * SLOT];  // per-filter scalars of the predict (x' at OFF_X)
+  __shared__ __attribute__((aligned(16))) double s_xk[FPW * DP];    // xk_k
+  __shared__ __attribute__((aligned(16))) double s_xn[FPW * DP];    // xk1_n, then xk_n
+  __shared__ __attribute__((aligned(16))) double s_de[FPW * EP];    // inv_err(xk1_k, xk1_n)
+  __shared__ __attribute__((aligned(16))) double s_dx[FPW * EP];    // Ck delta
+  __shared__ __attribute__((aligned(16))) double s_il[FPW * EMP];   // reciprocal pivots of the factor
 
   const int lane = threadIdx.x;
   const int g = lane / GL;
   const int c = lane % GL;
-  const bool act = c < E;
+  const bool act = c < EM;
   const int cc = act ? c : 0;
-  copy_g2l<EE>(gQ, EE, s_Q, lane);
   const int64_t tiles = (n + FPW - 1) / FPW;
+  const bool inplace_P = (Ps == Pf), inplace_x = (xs == xf);
 
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t base = tile * FPW;
     const int cnt = (n - base) < FPW ? (int)(n - base) : FPW;
     const int gg = g < cnt ? g : 0;
     const bool on = act && g < cnt;
-    double* L = s_L + gg * EE;
-    double* Dm = s_D + gg * EE;
-    double* Nn = s_N + gg * EE;
-    double* sd = s_d + gg * E;
-    double* sxk = s_xk + gg * 2 * DP;
+    const bool lead = (c == 0) && g < cnt;           // the one lane per filter that does the state algebra
+    const int64_t fil = base + gg;
+    double* B = s_B + gg * MMP;
+    double* C = s_C + gg * MMP;
+    double* sl = s_sl + gg * SLOT;
+    double* sxk = s_xk + gg * DP;
     double* sxn = s_xn + gg * DP;
-    double* sil = s_il + gg * E;
+    double* sde = s_de + gg * EP;
+    double* sdx = s_dx + gg * EP;
+    double* sil = s_il + gg * EMP;
 
-    if (T >= 2) {
-      async_copy_g2l_any<ABUF>(Pf + ((T - 2) * n + base) * EE, cnt * EE, s_A, lane);
-      async_copy_g2l_any<XBUF>(xf + ((T - 2) * n + base) * D, cnt * D, s_xin, lane);
-    }
-    for (int64_t k = T - 2; k >= 0; k--) {
-      // ---- the filtered pair of step k has landed: row c of Pk_k and xk_k to registers, then reuse the buffers ------
-      const int shA = odd_start(Pf + (k * n + base) * EE), shx = odd_start(xf + (k * n + base) * D);
-      const double dt = ts[k + 1] - ts[k];
-      async_wait();
-      wave_lds_sync();
-      double xk[D], x1k[D], prow[E];
-#pragma unroll
-      for (int i = 0; i < D; i++) xk[i] = s_xin[shx + gg * D + i];
-#pragma unroll
-      for (int j = 0; j < E; j++) prow[j] = s_A[shA + gg * EE + cc * E + j];
-      wave_lds_sync();
-      if (k >= 1) {
-        async_copy_g2l_any<ABUF>(Pf + ((k - 1) * n + base) * EE, cnt * EE, s_A, lane);
-        async_copy_g2l_any<XBUF>(xf + ((k - 1) * n + base) * D, cnt * D, s_xin, lane);
-      }
-
-      // ---- predicted pair of step k+1, recomputed with the forward kernels' generated sparse predict -------------------
-      const bool first = (k == T - 2);     // recursion start: smoothed(T-1) := predicted(T-1)  (estimates[-1][0], [2])
-      double y[E];
-      {
-        double p1col[E], pk[E], xn1[D];
-#pragma unroll
-        for (int j = 0; j < E; j++) pk[j] = prow[j];
-#pragma unroll
-        for (int i = 0; i < D; i++) x1k[i] = xk[i];
-        Model::predict_cov(x1k, prow, y, p1col, L, s_Q, dt, cc, on);        // L <- Pk1_k, y <- column c of M = Fk Pk_k^T
-        if (norm_quats & 1) Model::normalize(x1k);
-        if (on) {
-#pragma unroll
-          for (int i = 0; i < E; i++) {
-            if (first) Nn[i * E + c] = p1col[i];
-            Dm[i * E + c] = Nn[i * E + c] - p1col[i];
+    // what is not smoothed passes through (MSCKF window blocks; nothing for ordinary models): done up front for the whole
+    // trace of this tile, by the tile's own wavefront, before any of its main blocks is written
+    if constexpr (EM < E || DM < D) {
+      if (!inplace_P || !inplace_x) {
+        for (int64_t k = 0; k < T; k++) {
+          if (!inplace_P) {
+            for (int i = lane; i < cnt * EE; i += 64) {
+              const int e = i % EE, r = e / E, q = e % E;
+              if (r >= EM || q >= EM) Ps[(k * n + base) * EE + i] = Pf[(k * n + base) * EE + i];
+            }
+          }
+          if (!inplace_x) {
+            for (int i = lane; i < cnt * D; i += 64) {
+              if (i % D >= DM) xs[(k * n + base) * D + i] = xf[(k * n + base) * D + i];
+            }
           }
         }
-#pragma unroll
-        for (int i = 0; i < D; i++) xn1[i] = first ? x1k[i] : sxn[i];
-        if (norm_quats & 2) Model::normalize(xn1);
+      }
+    }
+
+    for (int64_t k = T - 2; k >= 0; k--) {
+      const bool first = (k == T - 2);
+      // ---- A. filtered pair of step k: row c of Pk_k to registers, xk_k to LDS --------------------------------------
+      const double* Pk = Pf + ((k * n + fil) * EE + (int64_t)cc * E);
+      double y[EM];
+      {
+        for (int i = c; i < D; i += GL) sxk[i] = xf[(k * n + fil) * D + i];
+        const double dt = ts[k + 1] - ts[k];
         wave_lds_sync();
-        // smoothed step k+1 is final now: write it out (state after the in-place renormalisation).  The replicated state
-        // vectors wait in LDS until the state update (in registers they would hold ~140 VGPRs through the factorisation)
-        if (c == 0 && g < cnt) {
+        // ---- B. f(xk_k), non-zeros of Fk: once per filter -> slot (no matrix row is live in registers meanwhile) ---------
+        if (lead) Model::scal(sxk, dt, sl, norm_quats & 1);
+        wave_lds_sync();
+        // ---- C. predicted pair of step k+1 (main block): B <- Pk1_k, y <- column c of M = Fk Pk_k^T -----------------------
+        double prow[EM];
+        rts_load_row<E, EM>(Pk, prow);
+        Model::mat_predict(prow, B, gQ, sl, cc, on, y);
+      }
+      // ---- D. recursion start / difference matrix / smoothed estimate of step k+1 leaves ------------------------------------
+      // Row c of Pk1_n waited in this lane's row of the difference buffer since the end of the previous step (no other lane
+      // touches it): no matrix row stays in registers across the phases above.
+      double lrow[EM], nrow[EM];
 #pragma unroll
-          for (int i = 0; i < D; i++) { s_x[g * D + i] = xn1[i]; sxn[i] = xn1[i]; sxk[i] = xk[i]; sxk[DP + i] = x1k[i]; }
+      for (int j = 0; j < EM; j++) { lrow[j] = B[cc * EM + j]; nrow[j] = C[cc * EM + j]; }
+      if (first) {
+        if (Pl != nullptr) {
+          rts_load_row<E, EM>(Pl + (fil * EE + (int64_t)cc * E), nrow);
+        } else {
+#pragma unroll
+          for (int j = 0; j < EM; j++) nrow[j] = lrow[j];
+        }
+        if (g < cnt) {
+          for (int i = c; i < D; i += GL) sxn[i] = (xl != nullptr) ? xl[fil * D + i] : sl[Model::OFF_X + i];
         }
         wave_lds_sync();
-        copy_l2g<FPW * D>(xs + ((k + 1) * n + base) * D, cnt * D, s_x, lane);
-        copy_l2g<FPW * EE>(Ps + ((k + 1) * n + base) * EE, cnt * EE, s_N, lane);
-        // Pk1_n has been consumed (difference formed, output issued): its row c now parks row c of Pk_k until the end of
-        // the step, where the smoothed Pk_n is accumulated on top of it
-        wave_lds_sync();
-        if (on) {
+      }
+      if (lead && (norm_quats & 2)) {
+        double xn1[D];
 #pragma unroll
-          for (int j = 0; j < E; j++) Nn[c * E + j] = pk[j];
+        for (int i = 0; i < D; i++) xn1[i] = sxn[i];
+        Model::normalize(xn1);
+#pragma unroll
+        for (int i = 0; i < D; i++) sxn[i] = xn1[i];
+      }
+      if (on) {
+#pragma unroll
+        for (int j = 0; j < EM; j++) C[c * EM + j] = nrow[j] - lrow[j];
+        rts_store_row<E, EM>(Ps + (((k + 1) * n + fil) * EE + (int64_t)c * E), nrow);
+      }
+      wave_lds_sync();
+      if (g < cnt) {
+        if (first && (EM < E || DM < D)) {
+          // window part of the newest estimate: the predicted pair when it was passed in
+          if (Pl != nullptr) {
+            for (int i = c; i < EE; i += GL) {
+              const int r = i / E, q = i % E;
+              if (r >= EM || q >= EM) Ps[((k + 1) * n + fil) * EE + i] = Pl[fil * EE + i];
+            }
+          }
+          for (int i = c; i < D; i += GL) xs[((k + 1) * n + fil) * D + i] = sxn[i];
+        } else {
+          for (int i = c; i < DM; i += GL) xs[((k + 1) * n + fil) * D + i] = sxn[i];
         }
       }
 
-      // ---- Cholesky of Pk1_k: lane c owns row c in registers, pivot rows are broadcast from LDS ---------------------------
-      double lrow[E];
-#pragma unroll
-      for (int j = 0; j < E; j++) lrow[j] = L[cc * E + j];
-#pragma unroll
-      for (int j = 0; j < E; j++) {
-        double s = lrow[j], sj = L[j * E + j];
+      // ---- E. Cholesky of Pk1_k, left-looking: lane c owns row c in registers; pivot row j (final since column j - 1) is
+      // broadcast from LDS and every lane forms its own entry AND the pivot redundantly -- no publish / wait per column -------
+      static_for<EM>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        double s0 = lrow[j], s1 = 0.0, p0 = B[j * EM + j], p1 = 0.0;
 #pragma unroll
         for (int m = 0; m < j; m++) {
-          const double r = L[j * E + m];          // final: written by lane j at step m
-          s = fma(-lrow[m], r, s);
-          sj = fma(-r, r, sj);
+          const double r = B[j * EM + m];
+          if (m & 1) { s1 = fma(-lrow[m], r, s1); p1 = fma(-r, r, p1); }
+          else       { s0 = fma(-lrow[m], r, s0); p0 = fma(-r, r, p0); }
         }
+        const double sj = p0 + p1;
         const double ilj = fast_rsqrt(sj);
-        lrow[j] = (c == j) ? sj * ilj : s * ilj;
-        // every row publishes its entry (rows above the pivot write a value nobody reads: one predicate for the whole
-        // factorisation instead of one exec mask per column) and the pivot reciprocal, identical in all lanes of the group;
-        // LDS is in-order within the wave, so the next column's broadcast reads see these stores
-        if (on) { L[c * E + j] = lrow[j]; sil[j] = ilj; }
-      }
+        lrow[j] = (c == j) ? sj * ilj : (s0 + s1) * ilj;
+        // rows above the pivot store a value nobody reads (one predicate for the whole factorisation).  The LDS serves one
+        // wavefront's instructions in order, so the next column's broadcast reads see these stores -- but the COMPILER only
+        // knows that through the fence: without it, it may (and for some sizes did) move a later column's loads of another
+        // lane's entries above this store, and it also hoists loads until the register file overflows.
+        if (on) { B[c * EM + j] = lrow[j]; sil[j] = ilj; }
+        wave_lds_sync();
+      });
       wave_lds_sync();
-      // ---- Ck^T = Pk1_k^-1 M: lane c solves for column c in registers (right-looking substitutions) -------------------
-#pragma unroll
-      for (int m = 0; m < E; m++) {
+      // ---- F. Ck^T = Pk1_k^-1 M: lane c solves for column c in registers (right-looking substitutions) -------------------
+      // Fully unrolled (the register column needs compile-time indices) through static_for -- `#pragma unroll` does not
+      // duplicate the wavefront fence, and a loop that stays rolled sends the register column to scratch memory.  Two things
+      // keep the register pressure at one pivot's worth: the fence per pivot keeps the coefficient loads of later pivots
+      // behind it, and pin() keeps the FMAs of this pivot in front of it.  Without pin() hipcc issues the loads of ALL
+      // pivots first and every FMA after the last fence (arithmetic is free to cross a fence): 460 live coefficients,
+      // 1 050 spilled registers, a scratch round trip per operand.  Neither costs an instruction.
+      static_for<EM>([&](auto Mi) {
+        constexpr int m = decltype(Mi)::value;
         y[m] *= sil[m];
 #pragma unroll
-        for (int i = m + 1; i < E; i++) y[i] = fma(-L[i * E + m], y[m], y[i]);
-      }
+        for (int i = m + 1; i < EM; i++) y[i] = fma(-B[i * EM + m], y[m], y[i]);
 #pragma unroll
-      for (int m = E - 1; m >= 0; m--) {
+        for (int i = m + 1; i < EM; i++) pin(y[i]);
+        wave_lds_sync();
+      });
+      static_for<EM>([&](auto Mi) {
+        constexpr int m = EM - 1 - decltype(Mi)::value;
         y[m] *= sil[m];
 #pragma unroll
-        for (int i = 0; i < m; i++) y[i] = fma(-L[m * E + i], y[m], y[i]);
-      }
-      // y is column c of X = Ck^T, i.e. row c of Ck; the factor is dead: its buffer takes Ck^T (column c written by lane c)
-      wave_lds_sync();
-      if (on) {
+        for (int i = 0; i < m; i++) y[i] = fma(-B[m * EM + i], y[m], y[i]);
 #pragma unroll
-        for (int j = 0; j < E; j++) L[j * E + c] = y[j];
-      }
-      // ---- state: delta = Ck inv_err(xk1_k, xk1_n); xk_n = err(xk_k, delta) -------------------------------
-      {
-        double delta[E], xa[D], xb[D], xn1[D];
+        for (int i = 0; i < m; i++) pin(y[i]);
+        wave_lds_sync();
+      });
+      // y is column c of Ck^T, i.e. row c of Ck
+      // ---- G. state: delta = Ck inv_err(xk1_k, xk1_n)[:EM]; xk_n[:DM] = err(xk_k, delta)[:DM] -----------------------------
+      if (lead) {
+        double xb[D], xn1[D], delta[E];
 #pragma unroll
-        for (int i = 0; i < D; i++) { xa[i] = sxk[i]; xb[i] = sxk[DP + i]; xn1[i] = sxn[i]; }
+        for (int i = 0; i < D; i++) { xb[i] = sl[Model::OFF_X + i]; xn1[i] = sxn[i]; }
         Model::inv_err(xb, xn1, delta);
+#pragma unroll
+        for (int i = 0; i < E; i++) sde[i] = delta[i];
+      }
+      wave_lds_sync();
+      {
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-        for (int j = 0; j + 1 < E; j += 2) { s0 = fma(y[j], delta[j], s0); s1 = fma(y[j + 1], delta[j + 1], s1); }
-        if (E & 1) s0 = fma(y[E - 1], delta[E - 1], s0);
-        if (on) sd[c] = s0 + s1;
-        wave_lds_sync();
-#pragma unroll
-        for (int j = 0; j < E; j++) delta[j] = sd[j];
-        Model::err(xa, delta, xn1);          // xk_n, becomes xk1_n of the next (older) step
-        if (c == 0 && g < cnt) {
-#pragma unroll
-          for (int i = 0; i < D; i++) sxn[i] = xn1[i];
-        }
+        for (int j = 0; j + 1 < EM; j += 2) { s0 = fma(y[j], sde[j], s0); s1 = fma(y[j + 1], sde[j + 1], s1); }
+        if (EM & 1) s0 = fma(y[EM - 1], sde[EM - 1], s0);
+        if (on) sdx[c] = s0 + s1;
       }
-      // ---- covariance: Pk_n = Pk_k + (Ck Dm) Ck^T, row c in registers ---------------------------------------
-      double trow[E];
+      wave_lds_sync();
+      if (lead) {
+        double xa[D], xnew[D], delta[E];
 #pragma unroll
-      for (int m = 0; m < E; m++) trow[m] = 0.0;
+        for (int i = 0; i < D; i++) xa[i] = sxk[i];
 #pragma unroll
-      for (int j = 0; j < E; j++) {
+        for (int i = 0; i < E; i++) delta[i] = (i < EM) ? sdx[i] : sde[i];
+        Model::err(xa, delta, xnew);
 #pragma unroll
-        for (int m = 0; m < E; m++) trow[m] = fma(y[j], Dm[j * E + m], trow[m]);     // row j of Dm: contiguous broadcast
+        for (int i = 0; i < D; i++) sxn[i] = (i < DM) ? xnew[i] : xa[i];       // xk_n: becomes xk1_n of the next (older) step
       }
-      double nn[E];
-#pragma unroll
-      for (int m = 0; m < E; m++) nn[m] = Nn[cc * E + m];
-#pragma unroll
-      for (int j = 0; j < E; j++) {
-#pragma unroll
-        for (int m = 0; m < E; m++) nn[m] = fma(trow[j], L[j * E + m], nn[m]);      // row j of Ck^T: contiguous broadcast
-      }
+      // ---- H. covariance: Pk_n = Pk_k + (Ck Dm) Ck^T, row c ----------------------------------------------------------------
+      // Rolled loops over the inner index: the multiplier of each step (an entry of this lane's row of Ck, then of T) comes
+      // from LDS, where the lane parked that row, so no register array is indexed by the loop variable; the accumulator row is
+      // the only array live.  Ck^T replaces the factor in B (column c written by lane c), T replaces the difference matrix.
+      wave_lds_sync();           // every lane is done with the factor
       if (on) {
 #pragma unroll
-        for (int m = 0; m < E; m++) Nn[c * E + m] = nn[m];   // Pk1_n of the next (older) step
+        for (int j = 0; j < EM; j++) B[j * EM + c] = y[j];
       }
       wave_lds_sync();
-    }
-    // the oldest smoothed state goes out un-normalised (ekf_sym.py:665-667 never reaches it)
-    if (T >= 2) {
-      wave_lds_sync();
-      if (c == 0 && g < cnt) {
+      {
+        double trow[EM];
 #pragma unroll
-        for (int i = 0; i < D; i++) s_x[g * D + i] = sxn[i];
+        for (int m = 0; m < EM; m++) trow[m] = 0.0;
+#pragma unroll 2
+        for (int j = 0; j < EM; j++) {
+          const double ckj = B[j * EM + cc];                                            // Ck[c][j]
+#pragma unroll
+          for (int m = 0; m < EM; m++) trow[m] = fma(ckj, C[j * EM + m], trow[m]);       // row j of Dm: contiguous broadcast
+        }
+        wave_lds_sync();         // every lane has read all of Dm: its buffer takes T (row c written by lane c)
+        if (on) {
+#pragma unroll
+          for (int m = 0; m < EM; m++) C[c * EM + m] = trow[m];
+        }
+      }
+      {
+        double nn[EM];
+        rts_load_row<E, EM>(Pk, nn);          // row c of Pk_k again (L2 hit): cheaper than 2 EM registers held through the step
+        wave_lds_sync();
+#pragma unroll 2
+        for (int j = 0; j < EM; j++) {
+          const double tj = C[cc * EM + j];
+#pragma unroll
+          for (int m = 0; m < EM; m++) nn[m] = fma(tj, B[j * EM + m], nn[m]);          // row j of Ck^T: contiguous broadcast
+        }
+        // row c of Pk_n = Pk1_n of the next (older) step parks in this lane's own row of C (T's row c is consumed)
+        if (on) {
+#pragma unroll
+          for (int m = 0; m < EM; m++) C[c * EM + m] = nn[m];
+        }
       }
       wave_lds_sync();
-      copy_l2g<FPW * D>(xs + base * D, cnt * D, s_x, lane);
-      copy_l2g<FPW * EE>(Ps + base * EE, cnt * EE, s_N, lane);
+    }
+    // ---- the oldest smoothed estimate goes out un-normalised (ekf_sym.py:665-667 never reaches it) --------------------------
+    if (T >= 2) {
+      if (on) {
+        double nrow[EM];
+#pragma unroll
+        for (int j = 0; j < EM; j++) nrow[j] = C[c * EM + j];
+        rts_store_row<E, EM>(Ps + ((int64_t)fil * EE + (int64_t)c * E), nrow);
+      }
+      if (g < cnt) {
+        for (int i = c; i < DM; i += GL) xs[fil * D + i] = sxn[i];
+      }
       wave_lds_sync();
     }
-    // T == 1: nothing to smooth, the single estimate's predicted pair is not available -> copy filtered through
-    if (T == 1) {
-      copy_g2l<FPW * EE>(Pf + base * EE, cnt * EE, s_L, lane);
-      copy_g2l<FPW * D>(xf + base * D, cnt * D, s_x, lane);
-      wave_lds_sync();
-      copy_l2g<FPW * EE>(Ps + base * EE, cnt * EE, s_L, lane);
-      copy_l2g<FPW * D>(xs + base * D, cnt * D, s_x, lane);
-      wave_lds_sync();
+    // T == 1: nothing to smooth, the single estimate's predicted pair is not available -> the filtered pair passes through
+    if (T == 1 && (!inplace_P || !inplace_x)) {
+      if (!inplace_P) { for (int i = lane; i < cnt * EE; i += 64) Ps[base * EE + i] = Pf[base * EE + i]; }
+      if (!inplace_x) { for (int i = lane; i < cnt * D; i += 64) xs[base * D + i] = xf[base * D + i]; }
     }
   }
 }

@@ -142,13 +142,39 @@ def test_scalar_abi_feature_update(env):
 
 
 def test_unsupported_entry_points_fail_loudly(env):
-  """Feature-track kinds are step-granular only and MSCKF models have no smoother: both must raise, not mis-compute."""
+  """Feature-track kinds are step-granular only: the fused run must raise, not mis-compute."""
   torch, gen, FK = env
   from rednose_amd.helpers import KalmanError
   f = _filter(env, 4)
   with pytest.raises(KalmanError):
     f.run(np.array([0.1]), np.array([2], dtype=np.int32), np.zeros((1, 4, 6)), {2: FK.obs_noise[2]})
   with pytest.raises(KalmanError):
-    f.rts_smooth(np.zeros((2, 4, FK.dim_state)), np.tile(np.eye(FK.dim_state), (2, 4, 1, 1)), np.array([0.0, 0.1]))
-  with pytest.raises(KalmanError):
     f.update(2, np.zeros((4, 6)), FK.obs_noise[2])              # extra arguments missing
+
+
+@pytest.mark.parametrize("inplace", [False, True])
+def test_smoother_main_block_vs_reference(env, inplace):
+  """EKF_sym.rts_smooth of the reference on the MSCKF trajectory (window shifts included): only the main block of the
+  covariance and the main states are smoothed, the window part of every estimate passes through
+  (/root/reference/rednose/helpers/ekf_sym.py:675-686).  The predicted pair of the last step is handed over, as the
+  reference takes it from the last estimate."""
+  torch, gen, FK = env
+  g = _gold(env)
+  n = 7
+  f = _filter(env, n)
+  T = len(g["ts"])
+  D = FK.dim_state
+  xf = np.tile(g["xk_k"][:, None, :], (1, n, 1)); Pf = np.tile(g["Pk_k"][:, None], (1, n, 1, 1))
+  last = (np.tile(g["xk_km1"][-1], (n, 1)), np.tile(g["Pk_km1"][-1], (n, 1, 1)))
+  if inplace:
+    xf, Pf = torch.as_tensor(xf, device=f.device), torch.as_tensor(Pf, device=f.device)
+  xs, Ps = f.rts_smooth(xf, Pf, g["ts"], norm_quats=False, inplace=inplace, last_predicted=last)
+  torch.cuda.synchronize()
+  X, P = xs.cpu().numpy(), Ps.cpu().numpy()
+  for j in (0, n - 1):
+    assert_close(X[:, j], g["xs_smooth"], rtol=1e-8, floor=1e-10, what="MSCKF smoothed states")
+    assert_close(P[:, j].reshape(T, -1), g["Ps_smooth"].reshape(T, -1), rtol=1e-7, floor=1e-9, what="MSCKF smoothed covariances")
+  # what is not smoothed is the filtered estimate, bit for bit
+  d1 = 6
+  assert np.array_equal(X[:-1, 0, d1:], g["xk_k"][:-1, d1:])
+  assert np.array_equal(P[:-1, 0, d1:, :], g["Pk_k"][:-1, d1:, :]) and np.array_equal(P[:-1, 0, :, d1:], g["Pk_k"][:-1, :, d1:])

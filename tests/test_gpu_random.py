@@ -99,11 +99,6 @@ def test_fused_run_and_step_path_vs_oracle(env):
     assert_close(got.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-8, floor=1e-10, what=f"{M.name} {name} P")
   assert_close(tx.cpu().numpy().reshape(T * n, -1), xf.reshape(T * n, -1), rtol=1e-8, floor=1e-10, what=f"{M.name} trace x")
   assert_close(tP.cpu().numpy().reshape(T * n, -1), Pf.reshape(T * n, -1), rtol=1e-8, floor=1e-10, what=f"{M.name} trace P")
-  if M.dim > 24:
-    from rednose_amd.helpers import KalmanError
-    with pytest.raises(KalmanError):         # no smoother above 24 error states
-      f.rts_smooth(tx, tP, ts)
-    return
   # smoother vs a numpy restatement of ekf_sym.py:651-690 on the oracle's f / F (additive error state, no quaternions):
   # the recursion starts from the PREDICTED pair of the last step
   xs, Ps = f.rts_smooth(tx, tP, ts)
@@ -205,7 +200,7 @@ def test_trace_vs_step_path_many_shapes(dim):
       assert dx < 1e-9 and dP < 1e-9, f"{M.name} rep {rep} n={n} T={T} t={t}: |dx|={dx:.3e} |dP|={dP:.3e}"
 
 
-@pytest.mark.parametrize("dim", [13, 24])
+@pytest.mark.parametrize("dim", [8, 13, 24, 32])
 def test_smoother_many_shapes(dim):
   """The smoother against the numpy restatement over several random batch sizes / trace lengths (every filter, every step)."""
   import torch
@@ -247,3 +242,66 @@ def test_smoother_many_shapes(dim):
         worst = max(worst, np.abs(xs[k, j] - xkn).max() / max(1.0, np.abs(xkn).max()))
         x1n = xs[k, j].copy()
     assert worst < 1e-7, f"{M.name} rep {rep} n={n} T={T}: smoothed states off by {worst:.2e} (relative)"
+
+
+@pytest.mark.parametrize("dim", [5, 11])
+def test_predict_with_zero_dt_is_not_skipped_for_affine_models(dim):
+  """f = A0 x + dt (...) with A0 != I: predict(dt = 0) changes x and P (x <- A0 x, P <- A0 P A0^T) and the reference runs it
+  on every call, the first one of a filter included (ekf_c.c:15-28, ekf_sym.cc:198-206).  Both kernel families (5 states:
+  lane per filter, 11: lane group) against the oracle -- the dt == 0 shortcut of the lane-group kernels may only be emitted
+  when predict(0) is symbolically the identity (FilterSpec.identity_at_dt0)."""
+  import torch
+  from examples import ensure_generated
+  import examples.random_kf as R
+  from oracle_lib import OracleLib
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  M = getattr(R, f"RandomAffine{dim}Kalman")
+  gen = ensure_generated([M.name]); o = OracleLib(M.name)
+  rng = np.random.default_rng(dim)
+  n = 77
+  x0 = M.initial_x[None] + rng.normal(size=(n, dim)) * 0.3
+  A = rng.normal(size=(n, dim, dim)) * 0.2
+  P0 = np.diag(M.initial_P_diag)[None] + A @ A.transpose(0, 2, 1)
+  f = BatchedEKF(gen, M.name, M.Q, M.initial_x, np.diag(M.initial_P_diag), dim, dim, batch=n)
+  # (a) single calls with dt = 0: predict alone, and the fused predict+update
+  f.init_state(x0, P0, 0.0)
+  f.predict(0.0)
+  xr, Pr = x0.copy(), P0.copy()
+  for i in range(n):
+    o.predict(xr[i], Pr[i], M.Q, 0.0)
+  torch.cuda.synchronize()
+  assert np.abs(xr - x0).max() > 1e-3, "the model must not be the identity at dt = 0 for this test to mean anything"
+  assert_close(f.state(), xr, rtol=1e-11, floor=1e-13, what=f"{M.name} predict(0) x")
+  assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-11, floor=1e-13, what=f"{M.name} predict(0) P")
+  for k in (1, 2, 3):
+    Z = o.zdim(k)
+    z = rng.normal(size=(n, Z))
+    f.init_state(x0, P0, None)           # first call of a filter: dt = 0 (ekf_sym.cc:198-200)
+    y = f.predict_and_update_batch(0.3, k, z.copy(), M.obs_noise[k])
+    xr, Pr, zr = x0.copy(), P0.copy(), z.copy()
+    o.batch_step(k, xr, Pr, zr, M.obs_noise[k], M.Q, 0.0)
+    torch.cuda.synchronize()
+    assert_close(f.state(), xr, rtol=1e-11, floor=1e-13, what=f"{M.name} first call kind {k} x")
+    assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-11, floor=1e-13, what=f"{M.name} first call kind {k} P")
+    assert_close(y.cpu().numpy(), zr, rtol=1e-11, atol=1e-13 * max(1.0, np.abs(z).max()), what=f"{M.name} first call kind {k} y")
+  # (b) fused run with repeated timestamps (dt = 0 between them) against the oracle's run and the step-granular path
+  T = 12
+  kinds = np.array([(1, 2, 3)[t % 3] for t in range(T)], dtype=np.int32)
+  ts = np.repeat(np.cumsum(rng.uniform(0.005, 0.03, size=T // 2)), 2)
+  zs = rng.normal(size=(T, n, 3)) * 0.5
+  Rs = {k: M.obs_noise[k] for k in (1, 2, 3)}
+  f.init_state(x0, P0, None)
+  f.run(ts, kinds, zs.copy(), Rs)
+  s = BatchedEKF(gen, M.name, M.Q, M.initial_x, np.diag(M.initial_P_diag), dim, dim, batch=n); s.init_state(x0, P0, None)
+  for t in range(T):
+    Z = Rs[int(kinds[t])].shape[0]
+    s.predict_and_update_batch(float(ts[t]), int(kinds[t]), zs[t, :, :Z].copy(), Rs[int(kinds[t])])
+  torch.cuda.synchronize()
+  xr, Pr, zr = x0.copy(), P0.copy(), zs.copy()
+  Rt = np.zeros((T, 9))
+  for t, k in enumerate(kinds):
+    Rt[t, :Rs[int(k)].size] = Rs[int(k)].reshape(-1)
+  o.batch_run(kinds, np.diff(np.concatenate([[ts[0]], ts])), xr, Pr, zr, Rt, M.Q)
+  for name, got in (("fused run", f), ("step path", s)):
+    assert_close(got.state(), xr, rtol=1e-9, floor=1e-11, what=f"{M.name} {name} x")
+    assert_close(got.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-9, floor=1e-11, what=f"{M.name} {name} P")

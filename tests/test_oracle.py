@@ -206,3 +206,25 @@ def test_port_flavour_equals_ref_flavour(name):
     both(f"H_{k}", x, ea, shape=Z * a.D)
     if name == "feature" and k == 2:
       both("He_2", x, ea, shape=Z * 3)
+
+
+def test_zero_dt_shortcut_is_guarded_symbolically():
+  """The lane-group kernels skip the covariance phase of predict(dt = 0) only for models where that is the identity:
+  f(x, 0) == x and F(x, 0) == I symbolically (ekf_c.c:15-28 evaluates f and F unconditionally)."""
+  import examples.random_kf as R
+  from examples.live_kf import LiveKalman
+  from examples.kinematic9_kf import Kinematic9Kalman
+  from rednose_amd.helpers.ekf_sym import gen_code
+  import tempfile
+  with tempfile.TemporaryDirectory() as d:
+    assert gen_code(d, **R.Random11Kalman.model(), compile=False).identity_at_dt0()
+    assert gen_code(d, **Kinematic9Kalman.model(), compile=False).identity_at_dt0()
+    for dim in R.AFFINE_SIZES:
+      spec = gen_code(d, **getattr(R, f"RandomAffine{dim}Kalman").model(), compile=False)
+      assert not spec.identity_at_dt0()
+    with open(os.path.join(d, "randaff11.hip"), encoding="utf-8") as f:
+      src = f.read()
+    assert "dt_scalar == 0.0" not in src and "if (true || dt != 0.0)" in src
+    with open(os.path.join(d, "rand11.hip"), encoding="utf-8") as f:
+      src = f.read()
+    assert "dt_scalar == 0.0" in src
