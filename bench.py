@@ -2,25 +2,35 @@
 """bench.py -- EKF predict+update steps/sec at batch N on MI355X, with roofline and CPU baseline.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W   -> ONE JSON line on rank 0.
-For N > 1 the driver launches one rank per GPU with torch.distributed.run (RCCL); the batch axis shards
-with no data-path collective (filters are independent), so scaling is weak: every rank owns
-`--batch` filters; the only collectives are the barrier and a MAX/SUM all-reduce of the timing.
+For N > 1 the driver launches one rank per GPU with torch.distributed.run (RCCL); the batch axis shards with no
+data-path collective (filters are independent).  Default scaling is weak: every rank owns `--batch` filters;
+`--global-batch G` fixes the total instead (strong scaling, rank r owns rednose_amd.helpers.sharding.shard_range(G, r, N)).
+The only collectives are the barrier and the SUM-of-steps / MAX-of-seconds all-reduce of sharding.aggregate_throughput.
 
-Workload (BASELINE.json configs[1]): kinematic6 (6-state 3-D pos/vel, 3-D position observation), batch
-65 536 per GPU, fp64.  A step = ONE fused predict(dt) + update(kind) launch over the whole batch through
-the generated library's C ABI ({name}_batch_predict_update_{kind}); state round-trips HBM every step
-(the reference's per-call semantics).  Inputs (x, P, the observation stream) are resident in HBM before
-the timed region.
+Workload (BASELINE.json configs[1]): kinematic6 (6-state 3-D pos/vel, 3-D position observation), batch 65 536 per GPU,
+fp64.  A step = ONE fused predict(dt) + update(kind) launch over the whole batch through the generated library's C ABI
+({name}_batch_predict_update_{kind}); state round-trips HBM every step (the reference's per-call semantics).  Inputs (x, P,
+the observation stream) are resident in HBM before the timed region.
 
-roofline: HBM-bound.  Algorithmic bytes per filter-step actually moved with a shared R and scalar dt:
-reads x(6)+P(36)+z(3), writes x(6)+P(36)+y(3) = 90 doubles = 720 B (SURVEY.md 8d quotes 800 B when dt and R
-are per-filter arrays; bytes that are not moved are not counted).  achieved = 720 B x batch / mean launch
-duration measured with HIP events on the launch stream over the timed region.
+roofline: HBM-bound.  Algorithmic bytes per filter-step actually moved with a shared R and scalar dt: reads x(6)+P(36)+z(3),
+writes x(6)+P(36)+y(3) = 90 doubles = 720 B (SURVEY.md 8d quotes 800 B when dt and R are per-filter arrays; bytes that are
+not moved are not counted).  achieved = 720 B x batch / mean launch duration measured with HIP events on the launch stream
+over the timed region.  `traffic` comes from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+profiles/collect.sh, corrected as MI355X_MICROARCH.md prescribes) and is reported only while the digest recorded there is the
+digest of the library being timed -- a number measured on another build is not printed.
+
+"extra" (1 GPU only) reports the other BASELINE configs, each with its own roofline object: live step-granular stream
+(config 3) and its dt > 0 launch alone, the 2-state kinematic model step-granular and fused (K steps per launch, the default
+fast path for tiny models), the fused run of kinematic6 (bound by fp64 VALU issue: the fraction is of the vector fp64 issue
+rate), 1 M filters, kinematic9, the MSCKF model, and config 4 at its stated size: live with the Mahalanobis gate,
+16 384 filters x 2 100 steps, forward pass keeping the filtered trace + RTS backward pass, swept in batch chunks.
 """
 import argparse
 import ctypes
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -31,14 +41,66 @@ for p in (REPO, os.path.join(REPO, "oracle")):
   if p not in sys.path:
     sys.path.insert(0, p)
 
-HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9     # 256 CUs x 4 SIMDs x 16 fp64 lanes per clock x 2.4 GHz = 39.3 T lane-instructions/s
+#                                               (78.6 TFLOP/s vector fp64 counts an FMA as two)
 
 
-def cpu_baseline(name, kind, K6, batch, budget_s=6.0):
-  """Oracle (C restatement of ekf_c.c + reference-generated sympy C, gcc -O2 as in the reference's SConstruct)
+def hbm_roofline(bytes_per_launch, launch_s, kernel, traffic=None, **more):
+  a = bytes_per_launch / launch_s / 1e9
+  return dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS, traffic=traffic, kernel=kernel,
+              algorithmic_bytes_per_launch=bytes_per_launch, launch_us=launch_s * 1e6, **more)
+
+
+def measured_traffic(name, n, gen):
+  """HBM bytes per launch from the committed PMC passes -- only if they were taken on the library that is being timed."""
+  tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
+  if not os.path.exists(tf):
+    return None
+  with open(tf, encoding="utf-8") as fh:
+    rec = json.load(fh).get(f"{name}_b{n}")
+  dg = os.path.join(gen, f"{name}.digest")
+  if rec is None or not os.path.exists(dg):
+    return None
+  with open(dg, encoding="utf-8") as fh:
+    if rec.get("lib_digest") != fh.read().strip():
+      return None
+  return rec["hbm_bytes_per_launch"]
+
+
+def fp64_valu_instructions(lib, kernel="k_run"):
+  """fp64 VALU instructions in the body of a kernel of a generated library (llvm-objdump): for the single-kind lane-per-filter
+  models timed below that is, to a few per cent, the count per filter-step of the fused run (its t-loop is the body)."""
+  objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+  if not os.path.exists(objdump):
+    return None
+  llvm = "/opt/rocm/lib/llvm/bin"
+  try:
+    fb, co = f"/tmp/rn_bench_{os.getpid()}.hipfb", f"/tmp/rn_bench_{os.getpid()}.co"
+    subprocess.run([f"{llvm}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fb], check=True, capture_output=True)
+    subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fb}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                    f"--output={co}"], check=True, capture_output=True)
+    dis = subprocess.run([objdump, "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+    os.unlink(co)
+    os.unlink(fb)
+  except Exception:      # pylint: disable=broad-except
+    return None
+  count, inside = 0, False
+  for line in dis.split("\n"):
+    m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+    if m:
+      inside = kernel in m.group(1)
+      continue
+    if inside and re.search(r"\bv_\w+_f64", line):
+      count += 1
+  return count or None
+
+
+def cpu_baseline(name, kind, K6, batch, budget_s=5.0, suffix="", cflags=None):
+  """Oracle (C restatement of ekf_c.c + reference-generated sympy C, gcc flags of the reference's SConstruct unless `cflags`)
   timed on the host cores of this box: 1 thread (the reference's execution model) and all cores."""
   from oracle_lib import OracleLib
-  lib = OracleLib(name)
+  lib = OracleLib(name, suffix=suffix, cflags=cflags)
   try:
     gomp = ctypes.CDLL("libgomp.so.1")
   except OSError:
@@ -65,8 +127,8 @@ def cpu_baseline(name, kind, K6, batch, budget_s=6.0):
       el += time.perf_counter() - t0
       steps += 1
     out[label] = dict(value=n * steps / el, cores=int(threads), steps=steps, seconds=el)
-  flav = "reference-generated sympy C + C restatement of ekf_c.c" if lib.flavour == "ref" else "port (sympy C99 + C restatement of ekf_c.c)"
-  return out, n, flav
+  flav = "reference-generated sympy C + C restatement of ekf_c.c" if lib.flavour == "ref" else "our sympy C99 + C restatement of ekf_c.c"
+  return out, n, flav, ("reference" if lib.flavour == "ref" else "port")
 
 
 def kinematic_stream(torch, M, n, total, dev, rank):
@@ -84,36 +146,66 @@ def kinematic_stream(torch, M, n, total, dev, rank):
   return x0, np.diag(M.initial_P_diag), sched
 
 
-def live_stream(torch, M, f, n, total, dev, rank):
-  """stationary device, per 10 ms tick a PHONE_GYRO(4) then a PHONE_ACCEL(10) observation at the same
-  time (second has dt = 0), every 10th tick an ECEF_POS(12); per-filter initial attitude error <= 0.05 rad."""
+def live_true_accel(M, gen, name="live"):
+  """Expected specific force at the true (initial) state through the library's own h_10 (GPU, batch of one)."""
   from rednose_amd.helpers.ekf_sym import EKF_sym
-  gdev = torch.Generator(device=dev).manual_seed(2025 + rank)
-  x_true = M.initial_x.copy()
-  # expected specific force at the true state through the library's own h_10 (GPU, batch of one)
-  s = EKF_sym(f._folder, f.name, M.Q, M.initial_x, np.diag(M.initial_P_diag), 23, 22)
+  s = EKF_sym(gen, name, M.Q, M.initial_x, np.diag(M.initial_P_diag), 23, 22)
   hacc = np.zeros(3)
-  s.hs[10](np.ascontiguousarray(x_true), np.zeros(1), hacc)
+  s.hs[10](np.ascontiguousarray(M.initial_x.copy()), np.zeros(1), hacc)
+  return hacc
+
+
+def live_x0(torch, M, n, dev, gdev):
   e = (torch.rand((n, 3), generator=gdev, dtype=torch.float64, device=dev) - 0.5) * 0.1
-  x0 = torch.as_tensor(x_true, dtype=torch.float64, device=dev).repeat(n, 1)
+  x0 = torch.as_tensor(M.initial_x, dtype=torch.float64, device=dev).repeat(n, 1)
   q = torch.cat([torch.ones((n, 1), dtype=torch.float64, device=dev), 0.5 * e], dim=1)
   x0[:, 3:7] = q / q.norm(dim=1, keepdim=True)
-  sched = []
-  tick = 0
-  while len(sched) < total:
+  return x0
+
+
+def live_schedule(total):
+  """per 10 ms tick a PHONE_GYRO(4) then a PHONE_ACCEL(10) observation at the same time (second has
+  dt = 0), every 10th tick an ECEF_POS(12): 2 100 steps per 10 s."""
+  kinds, ts, tick = [], [], 0
+  while len(kinds) < total:
     t = 0.01 * tick
-    sched.append((4, t, 0.025 * torch.randn((n, 3), generator=gdev, dtype=torch.float64, device=dev)))
-    sched.append((10, t, torch.as_tensor(hacc, device=dev)[None] + 0.5 * torch.randn((n, 3), generator=gdev, dtype=torch.float64, device=dev)))
+    kinds += [4, 10]
+    ts += [t, t]
     if tick % 10 == 9:
-      sched.append((12, t, torch.as_tensor(x_true[:3], device=dev)[None] + 5.0 * torch.randn((n, 3), generator=gdev, dtype=torch.float64, device=dev)))
+      kinds.append(12)
+      ts.append(t)
     tick += 1
-  return x0, np.diag(M.initial_P_diag), sched[:total]
+  return np.array(kinds[:total], dtype=np.int32), np.array(ts[:total])
 
 
-def run_model(torch, dist, args, model, n, K, W, dev, rank, world):
-  """Warm up W steps, time exactly K steps (barrier + synchronize on both sides).  Returns timing dict (max over ranks)."""
-  from examples import ensure_generated
-  from rednose_amd.helpers.ekf_sym import BatchedEKF
+def live_observations(torch, M, hacc, kinds, n, dev, gdev, outlier_frac=0.0):
+  """(T, n, 3) observations of a stationary device: gyro N(0, 0.025^2), accel h_10(x_true) + N(0, 0.5^2), position
+  pos_true + N(0, 5^2); `outlier_frac` of the position fixes replaced by pos_true + N(0, 500^2) (config 4)."""
+  T = len(kinds)
+  zs = torch.randn((T, n, 3), generator=gdev, dtype=torch.float64, device=dev)
+  kd = torch.as_tensor(kinds, device=dev)
+  scale = torch.where(kd == 4, 0.025, torch.where(kd == 10, 0.5, 5.0)).to(torch.float64)
+  mean = torch.zeros((T, 3), dtype=torch.float64, device=dev)
+  mean[kd == 10] = torch.as_tensor(hacc, device=dev)
+  mean[kd == 12] = torch.as_tensor(M.initial_x[:3], device=dev)
+  zs = zs * scale[:, None, None] + mean[:, None, :]
+  if outlier_frac > 0:
+    gi = torch.nonzero(kd == 12).flatten()
+    sel = torch.rand((len(gi), n), generator=gdev, device=dev) < outlier_frac
+    zs[gi] += sel[..., None] * 500.0 * torch.randn((len(gi), n, 3), generator=gdev, dtype=torch.float64, device=dev)
+  return zs
+
+
+def live_stream(torch, M, gen, n, total, dev, rank):
+  gdev = torch.Generator(device=dev).manual_seed(2025 + rank)
+  hacc = live_true_accel(M, gen)
+  x0 = live_x0(torch, M, n, dev, gdev)
+  kinds, ts = live_schedule(total)
+  zs = live_observations(torch, M, hacc, kinds, n, dev, gdev)
+  return x0, np.diag(M.initial_P_diag), [(int(kinds[i]), float(ts[i]), zs[i]) for i in range(total)]
+
+
+def model_class(model):
   if model == "kinematic6":
     from examples.kinematic6_kf import Kinematic6Kalman as M
   elif model == "kinematic":
@@ -122,18 +214,33 @@ def run_model(torch, dist, args, model, n, K, W, dev, rank, world):
     from examples.kinematic9_kf import Kinematic9Kalman as M
   else:
     from examples.live_kf import LiveKalman as M
+  return M
+
+
+def gen_dir(names):
+  from examples import ensure_generated
+  return ensure_generated(names, **({'folder': os.environ['RN_GEN_DIR']} if 'RN_GEN_DIR' in os.environ else {}))
+
+
+def run_model(torch, dist, model, n, K, W, dev, rank, world, only_kind=None):
+  """Warm up W steps, time exactly K steps (barrier + synchronize on both sides).  Returns a timing dict; `wall` and `dev_ms`
+  are this rank's (the aggregation over ranks is the caller's: sharding.aggregate_throughput)."""
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  M = model_class(model)
   if rank == 0:
-    ensure_generated([model], **({'folder': os.environ['RN_GEN_DIR']} if 'RN_GEN_DIR' in os.environ else {}))
+    gen_dir([model])
   if world > 1:
     dist.barrier()
-  gen = ensure_generated([model], **({'folder': os.environ['RN_GEN_DIR']} if 'RN_GEN_DIR' in os.environ else {}))
+  gen = gen_dir([model])
   D, E = M.initial_x.shape[0], M.initial_P_diag.shape[0]
   quat = list(getattr(M, "quaternion_idxs", []))
   f = BatchedEKF(gen, M.name, M.Q, M.initial_x, np.diag(M.initial_P_diag), D, E, batch=n, device=dev, quaternion_idxs=quat)
-  f._folder = gen
   total = W + K
   if model == "live":
-    x0, P0, sched = live_stream(torch, M, f, n, total, dev, rank)
+    x0, P0, sched = live_stream(torch, M, gen, n, total, dev, rank)
+    if only_kind is not None:      # one kind, every launch advancing time (the launch that runs the covariance predict)
+      pool = [s_ for s_ in sched if s_[0] == only_kind]
+      sched = [(only_kind, 0.01 * i, pool[i % len(pool)][2].clone()) for i in range(total)]
   else:
     x0, P0, sched = kinematic_stream(torch, M, n, total, dev, rank)
   f.init_state(x0, P0, None)
@@ -170,13 +277,132 @@ def run_model(torch, dist, args, model, n, K, W, dev, rank, world):
   wall = time.perf_counter() - t0
   dev_ms = ev0.elapsed_time(ev1)
   assert torch.isfinite(f.x).all() and torch.isfinite(f.P).all(), "filter diverged: refusing to report a timing"
-  stats = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
-  if world > 1:
-    dist.all_reduce(stats, op=dist.ReduceOp.MAX)
   zdims = [f.zdims[sched[i][0]] for i in range(W, W + K)]
   bytes_per_step = 8.0 * (2 * (D + E * E) + 2 * float(np.mean(zdims)))
-  return dict(M=M, D=D, E=E, Z=float(np.mean(zdims)), wall=float(stats[0]), dev_ms=float(stats[1]), bytes_per_step=bytes_per_step,
+  return dict(M=M, D=D, E=E, Z=float(np.mean(zdims)), wall=wall, dev_ms=dev_ms, bytes_per_step=bytes_per_step, gen=gen,
               kinds=sorted(set(s[0] for s in sched[W:W + K])))
+
+
+def fused_run_extra(torch, model, n, T, dev):
+  """{name}_batch_run: x and P stay in registers for T steps, only z / y cross HBM.  Bound by fp64 VALU issue."""
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  M = model_class(model)
+  gen = gen_dir([model])
+  D, E = M.initial_x.shape[0], M.initial_P_diag.shape[0]
+  f = BatchedEKF(gen, M.name, M.Q, M.initial_x, np.diag(M.initial_P_diag), D, E, batch=n, device=dev)
+  Z = int(np.atleast_2d(M.obs_noise[1]).shape[0])
+  zs = torch.randn((T, n, Z), dtype=torch.float64, device=dev) * 0.1
+  ts = np.arange(1, T + 1) * 0.01
+  kinds = np.ones(T, dtype=np.int32)
+  best = None
+  for rep in range(3):
+    zc = zs.clone()
+    f.init_state(M.initial_x, np.diag(M.initial_P_diag), 0.0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    f.run(ts, kinds, zc, {1: M.obs_noise[1]})
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    best = ms if best is None or ms < best else best
+  assert torch.isfinite(f.x).all()
+  moved = 8.0 * (2 * Z) * n * T + 8.0 * 2 * (D + E * E) * n
+  rate = n * T / (best * 1e-3)
+  insts = fp64_valu_instructions(os.path.join(gen, f"lib{M.name}.so"))
+  roof = {"bound": "fp64-valu", "achieved": None, "peak": FP64_VALU_LANE_OPS / 1e12, "unit": "T fp64 lane-instructions/s", "frac": None,
+          "fp64_valu_instructions_per_filter_step": insts, "hbm_GBs": moved / (best * 1e-3) / 1e9, "hbm_frac": moved / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
+          "kernel": "k_run"}
+  if insts:
+    roof["achieved"] = insts * rate / 1e12
+    roof["frac"] = insts * rate / FP64_VALU_LANE_OPS
+  return {"model": M.name, "batch": n, "T": T, "value": rate, "unit": "steps/s", "ms": best, "hbm_bytes_moved": moved, "roofline": roof,
+          "note": "state resident in VGPRs for T steps (x / P cross HBM once per launch, z / y once per step); bound by fp64 VALU issue, "
+                  "the count is every v_*_f64 instruction of the kernel (llvm-objdump), an upper bound of the per-step loop body"}
+
+
+def config4_extra(torch, dev, rank, nb=16384, T=2100, chunk=2048):
+  """BASELINE config 4 at its stated size: live with the Mahalanobis gate on ECEF_POS, 2 % GNSS outliers, forward pass keeping
+  the filtered trace, RTS backward pass -- swept in chunks of `chunk` filters (the trace of a chunk is T x chunk x 4 056 B:
+  17.4 GB at 2 048; filters are independent, the result is that of one sweep).  The trace buffers are allocated once, outside
+  the timed region; forward and backward times are the sums of per-chunk HIP-event intervals."""
+  from examples.live_kf import LiveKalman as L
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  gen = gen_dir(["live_maha"])
+  f = BatchedEKF(gen, "live_maha", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22, batch=nb, device=dev, quaternion_idxs=[3],
+                 maha_test_kinds=[12])
+  gdev = torch.Generator(device=dev).manual_seed(4242 + rank)
+  hacc = live_true_accel(L, gen, "live_maha")
+  x0 = live_x0(torch, L, nb, dev, gdev)
+  kinds, ts = live_schedule(T)
+  zs = live_observations(torch, L, hacc, kinds, nb, dev, gdev, outlier_frac=0.02)
+  Rs = {int(k): np.atleast_2d(L.obs_noise[int(k)]) for k in set(kinds.tolist())}
+  chunk = min(chunk, nb)
+  tx = torch.empty((T, chunk, 23), dtype=torch.float64, device=dev)
+  tP = torch.empty((T, chunk, 22, 22), dtype=torch.float64, device=dev)
+  gi = torch.as_tensor(np.where(kinds == 12)[0], device=dev)
+  res = None
+  for rep in range(2):                      # first sweep warms up (library load, allocator); the second is reported
+    f.init_state(x0, np.diag(L.initial_P_diag), None)
+    fwd = bwd = 0.0
+    gated = []
+    finite = True
+    for lo in range(0, nb, chunk):
+      hi = min(nb, lo + chunk)
+      bx, bP = (tx, tP) if hi - lo == chunk else (tx[:, :hi - lo].contiguous(), tP[:, :hi - lo].contiguous())
+      zc = zs[:, lo:hi].contiguous()
+      f.filter_time = None
+      e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+      e0.record()
+      _, _, _, fl = f.run(ts, kinds, zc, Rs, flags=True, out=(bx, bP), filters=(lo, hi))
+      e1.record()
+      xs, Ps = f.rts_smooth(bx, bP, ts, inplace=True) if hi - lo == nb else f._rts_on(bx, bP, ts, hi - lo, None)   # pylint: disable=protected-access
+      e2.record()
+      torch.cuda.synchronize()
+      fwd += e0.elapsed_time(e1)
+      bwd += e1.elapsed_time(e2)
+      gated.append((fl[gi] & 1).float().mean().item())
+      finite = finite and bool(torch.isfinite(xs[0]).all()) and bool(torch.isfinite(Ps[0]).all()) and bool(torch.isfinite(xs[-1]).all())
+    assert finite, "config 4: non-finite smoothed estimate"
+    res = dict(fwd_ms=fwd, bwd_ms=bwd, gated=float(np.mean(gated)))
+  del tx, tP
+  fwd_bytes = nb * T * 8.0 * ((23 + 484) + 2 * 3) + nb * T           # filtered trace written, z read, y written, flags
+  bwd_bytes = nb * (T - 1) * 8.0 * 2 * (23 + 484)                     # filtered pair read, smoothed pair written
+  return {"batch": nb, "T": T, "chunk_filters": chunk,
+          "forward_steps_per_s": nb * T / (res["fwd_ms"] * 1e-3), "backward_steps_per_s": nb * (T - 1) / (res["bwd_ms"] * 1e-3),
+          "combined_steps_per_s": nb * T / ((res["fwd_ms"] + res["bwd_ms"]) * 1e-3),
+          "forward_ms": res["fwd_ms"], "backward_ms": res["bwd_ms"], "gated_fraction_of_gnss": res["gated"],
+          "trace_bytes_per_chunk": int(T * chunk * (23 + 484) * 8),
+          "roofline_forward": hbm_roofline(fwd_bytes, res["fwd_ms"] * 1e-3, "k_run (trace + gate flags)"),
+          "roofline_backward": hbm_roofline(bwd_bytes, res["bwd_ms"] * 1e-3, "rn::k_rts_group"),
+          "note": "forward = fused batch_run writing the filtered trace + gate flags; backward = batch_rts recomputing the predicted pairs; "
+                  "bytes: forward 4 104 B + 1 flag per filter-step, backward 8 112 B per filter-step"}
+
+
+def msckf_extra(torch, dev):
+  from examples.feature_kf import WideFeatureKalman as FK
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  genf = gen_dir(["feature36"])
+  nf, Kf = 16384, 100
+  ff = BatchedEKF(genf, FK.name, FK.Q, FK.initial_x, np.diag(FK.initial_P_diag), 6, 6, batch=nf, device=dev, **FK.filter_kwargs())
+  lm = torch.tensor([2.0, 1.0, 8.0], dtype=torch.float64, device=dev) + torch.randn((nf, 3), dtype=torch.float64, device=dev)
+  zf = [0.05 * torch.randn((nf, 6), dtype=torch.float64, device=dev) for _ in range(8)]
+  for i in range(10):
+    ff.predict_and_update_batch(0.01 * (i + 1), 2, zf[i % 8].clone(), FK.obs_noise[2], extra_args=lm)
+  zc = [zf[i % 8].clone() for i in range(Kf)]
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for i in range(Kf):
+    ff.predict_and_update_batch(0.01 * (i + 11), 2, zc[i], FK.obs_noise[2], extra_args=lm)
+  e1.record()
+  torch.cuda.synchronize()
+  assert torch.isfinite(ff.x).all() and torch.isfinite(ff.P).all()
+  msf = e0.elapsed_time(e1) / Kf
+  bf = 8.0 * (2 * (36 + 36 * 36) + 6 + 3 + 3)
+  return {"batch": nf, "steps": Kf, "value": nf / (msf * 1e-3), "unit": "steps/s",
+          "roofline": hbm_roofline(bf * nf, msf * 1e-3, "k_step_2<true>"),
+          "note": "fused predict + feature-track update (Z = 6 projected to 3), one filter per wavefront, per-filter landmarks"}
 
 
 def main():
@@ -184,7 +410,8 @@ def main():
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=2000)
   ap.add_argument("--warmup", type=int, default=100)
-  ap.add_argument("--batch", type=int, default=None, help="filters per GPU (default 65536; 16384 for --model live)")
+  ap.add_argument("--batch", type=int, default=None, help="filters per GPU (default 65536; 16384 for --model live): weak scaling")
+  ap.add_argument("--global-batch", type=int, default=None, help="total filters over all GPUs (strong scaling): rank r owns shard_range(G, r, N)")
   ap.add_argument("--model", default="kinematic6", choices=["kinematic6", "kinematic", "kinematic9", "live"])
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-extras", action="store_true", help="skip the additional configs reported under 'extra'")
@@ -192,6 +419,7 @@ def main():
 
   import torch
   import torch.distributed as dist
+  from rednose_amd.helpers import sharding
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
@@ -212,152 +440,76 @@ def main():
       dist.init_process_group(backend=backend)
 
   K, W = args.steps, args.warmup
-  n = args.batch or (16384 if args.model == "live" else 65536)
-  r = run_model(torch, dist, args, args.model, n, K, W, dev, rank, world)
+  if args.global_batch:
+    lo, hi = sharding.shard_range(args.global_batch, rank, world)
+    n, scaling = hi - lo, "strong"
+  else:
+    n, scaling = args.batch or (16384 if args.model == "live" else 65536), "weak"
+  r = run_model(torch, dist, args.model, n, K, W, dev, rank, world)
   M, D, E = r["M"], r["D"], r["E"]
+  agg_dev = dev if (world > 1 and os.environ.get("RN_BENCH_BACKEND", "nccl") == "nccl") else None
+  value, steps_total, wall_max = sharding.aggregate_throughput(n * K, r["wall"], dist if world > 1 else None, device=agg_dev)
+  _, _, dev_ms_max = sharding.aggregate_throughput(1.0, r["dev_ms"], dist if world > 1 else None, device=agg_dev)
 
   extra = {}
-  if not args.no_extras and world == 1:
-    others = {"kinematic6": [("live", 16384, 420, 42), ("kinematic", 65536, 500, 50), ("kinematic6", 1 << 20, 200, 20),
-                             ("kinematic9", 65536, 300, 30)],
-              "live": [], "kinematic": [], "kinematic9": []}[args.model]
-    for om, on, oK, oW in others:
-      o = run_model(torch, dist, args, om, on, oK, oW, dev, rank, world)
-      ls = o["dev_ms"] * 1e-3 / oK
-      extra[om if on != (1 << 20) else om + "_1M"] = {"batch": on, "steps": oK, "value": on * oK / o["wall"], "unit": "steps/s", "launch_us": ls * 1e6,
-                   "algorithmic_bytes_per_filter_step": o["bytes_per_step"], "achieved_GBs": o["bytes_per_step"] * on / ls / 1e9,
-                   "frac_of_8TBs": o["bytes_per_step"] * on / ls / 1e9 / HBM_PEAK_GBS, "kinds": o["kinds"]}
-
-  if not args.no_extras and world == 1 and args.model != "live":
-    # fused multi-step mode ({name}_batch_run): x and P stay on chip for T steps, only z / y cross HBM
-    from examples import ensure_generated
-    from rednose_amd.helpers.ekf_sym import BatchedEKF
-    gen = ensure_generated([args.model])
-    f = BatchedEKF(gen, M.name, M.Q, M.initial_x, np.diag(M.initial_P_diag), D, E, batch=n, device=dev)
-    T = 500
-    Z = int(np.atleast_2d(M.obs_noise[1]).shape[0])
-    zs = torch.randn((T, n, Z), dtype=torch.float64, device=dev) * 0.1
-    ts = np.arange(1, T + 1) * 0.01
-    f.init_state(M.initial_x, np.diag(M.initial_P_diag), 0.0)
-    f.run(ts, np.ones(T, dtype=np.int32), zs.clone(), {1: M.obs_noise[1]})      # warm-up
-    torch.cuda.synchronize()
-    f.init_state(M.initial_x, np.diag(M.initial_P_diag), 0.0)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    f.run(ts, np.ones(T, dtype=np.int32), zs, {1: M.obs_noise[1]})
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1)
-    moved = 8.0 * (2 * Z) * n * T + 8.0 * 2 * (D + E * E) * n
-    extra["fused_run"] = {"model": M.name, "batch": n, "T": T, "value": n * T / (ms * 1e-3), "unit": "steps/s", "ms": ms,
-                          "hbm_bytes_moved": moved, "achieved_GBs": moved / (ms * 1e-3) / 1e9,
-                          "note": "state resident in VGPRs for T steps; bound by fp64 VALU issue, not HBM"}
-
   if not args.no_extras and world == 1 and args.model == "kinematic6":
-    # MSCKF: null-space projected feature-track updates of the windowed-camera example, 36 error
-    # states, per-filter landmarks; timed through the generic Python method (no pre-bound variant takes extra arguments)
-    from examples import ensure_generated
-    from examples.feature_kf import WideFeatureKalman as FK
-    from rednose_amd.helpers.ekf_sym import BatchedEKF
-    genf = ensure_generated(["feature36"])
-    nf, Kf = 16384, 100
-    ff = BatchedEKF(genf, FK.name, FK.Q, FK.initial_x, np.diag(FK.initial_P_diag), 6, 6, batch=nf, device=dev, **FK.filter_kwargs())
-    lm = torch.tensor([2.0, 1.0, 8.0], dtype=torch.float64, device=dev) + torch.randn((nf, 3), dtype=torch.float64, device=dev)
-    zf = [0.05 * torch.randn((nf, 6), dtype=torch.float64, device=dev) for _ in range(8)]
-    for i in range(10):
-      ff.predict_and_update_batch(0.01 * (i + 1), 2, zf[i % 8].clone(), FK.obs_noise[2], extra_args=lm)
-    zc = [zf[i % 8].clone() for i in range(Kf)]
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for i in range(Kf):
-      ff.predict_and_update_batch(0.01 * (i + 11), 2, zc[i], FK.obs_noise[2], extra_args=lm)
-    e1.record()
-    torch.cuda.synchronize()
-    assert torch.isfinite(ff.x).all() and torch.isfinite(ff.P).all()
-    msf = e0.elapsed_time(e1) / Kf
-    bf = 8.0 * (2 * (36 + 36 * 36) + 6 + 3 + 3)
-    extra["feature36_msckf"] = {"batch": nf, "steps": Kf, "value": nf / (msf * 1e-3), "unit": "steps/s", "launch_us": msf * 1e3,
-                                "algorithmic_bytes_per_filter_step": bf, "frac_of_8TBs": bf * nf / (msf * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "note": "fused predict + feature-track update (Z = 6 projected to 3), one filter per wavefront"}
-    del ff, zf, zc
-
-    # BASELINE config 4: live with the Mahalanobis gate on ECEF_POS, forward pass keeping the filtered trace, then the
-    # batched RTS backward pass.  T = 210 steps (1 s of IMU@100Hz + GNSS@10Hz), batch 16384, 2 % GNSS outliers.
-    from examples import ensure_generated
-    from examples.live_kf import LiveKalman as L
-    from rednose_amd.helpers.ekf_sym import BatchedEKF
-    gen = ensure_generated(["live_maha"])
-    nb = 16384
-    f = BatchedEKF(gen, "live_maha", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22, batch=nb, device=dev, quaternion_idxs=[3],
-                   maha_test_kinds=[12])
-    f._folder = gen
-    x0, P0, sched = live_stream(torch, L, f, nb, 210, dev, rank)
-    kinds = np.array([s_[0] for s_ in sched], dtype=np.int32)
-    tsl = np.array([s_[1] for s_ in sched])
-    zsl = torch.stack([s_[2].expand(nb, 3) for s_ in sched]).contiguous()
-    gsel = torch.rand((int((kinds == 12).sum()), nb), device=dev) < 0.02
-    zsl[torch.as_tensor(np.where(kinds == 12)[0], device=dev)] += gsel[..., None] * 500.0 * torch.randn((gsel.shape[0], nb, 3), dtype=torch.float64, device=dev)
-    Rs = {int(k): np.atleast_2d(L.obs_noise[int(k)]) for k in set(kinds.tolist())}
-    res = {}
-    for rep in range(2):
-      f.init_state(x0, P0, None)
-      e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-      e0.record()
-      _, tx, tP, fl = f.run(tsl, kinds, zsl.clone(), Rs, trace=True, flags=True)
-      e1.record()
-      xs, Ps = f.rts_smooth(tx, tP, tsl, inplace=True)
-      e2.record()
-      torch.cuda.synchronize()
-      res = {"fwd_ms": e0.elapsed_time(e1), "bwd_ms": e1.elapsed_time(e2)}
-    assert torch.isfinite(xs).all() and torch.isfinite(Ps).all()
-    T4 = len(kinds)
-    extra["live_maha_rts"] = {"batch": nb, "T": T4, "forward_steps_per_s": nb * T4 / (res["fwd_ms"] * 1e-3),
-                              "backward_steps_per_s": nb * (T4 - 1) / (res["bwd_ms"] * 1e-3), "forward_ms": res["fwd_ms"], "backward_ms": res["bwd_ms"],
-                              "gated_fraction_of_gnss": float(fl[torch.as_tensor(np.where(kinds == 12)[0], device=dev)].float().mean()),
-                              "trace_bytes": int(tx.numel() + tP.numel()) * 8,
-                              "note": "forward = fused batch_run with filtered trace + gate flags; backward = batch_rts recomputing the predicted pairs"}
-    del tx, tP, xs, Ps, zsl
+    def stepwise(om, on, oK, oW, kernel, key=None, only_kind=None, note=None):
+      o = run_model(torch, dist, om, on, oK, oW, dev, rank, world, only_kind=only_kind)
+      ls = o["dev_ms"] * 1e-3 / oK
+      rec = {"batch": on, "steps": oK, "value": on * oK / o["wall"], "unit": "steps/s", "kinds": o["kinds"],
+             "algorithmic_bytes_per_filter_step": o["bytes_per_step"],
+             "roofline": hbm_roofline(o["bytes_per_step"] * on, ls, kernel, traffic=measured_traffic(o["M"].name, on, o["gen"]))}
+      if note:
+        rec["note"] = note
+      extra[key or om] = rec
+    stepwise("live", 16384, 420, 42, "k_step_{4,10,12}<true> (IMU + GNSS stream mix)")
+    stepwise("live", 16384, 200, 20, "k_step_4<true>", key="live_dt_gt0", only_kind=4,
+             note="every launch advances time: the launch that runs the covariance predict (in the stream, 2 of 2.1 launches have dt = 0)")
+    stepwise("kinematic", 65536, 500, 50, "k_step_1<true>",
+             note="2-state model, 112 B per filter-step: one launch per step is bounded by launch latency; see kinematic_fused")
+    stepwise("kinematic6", 1 << 20, 200, 20, "k_step_1<true>", key="kinematic6_1M")
+    stepwise("kinematic9", 65536, 300, 30, "k_step_1<true>")
+    extra["kinematic_fused"] = fused_run_extra(torch, "kinematic", 65536, 2000, dev)
+    extra["fused_run"] = fused_run_extra(torch, "kinematic6", n, 500, dev)
+    extra["feature36_msckf"] = msckf_extra(torch, dev)
+    extra["live_maha_rts"] = config4_extra(torch, dev, rank)
 
   if rank == 0:
-    launch_s = r["dev_ms"] * 1e-3 / K
-    achieved = r["bytes_per_step"] * n / launch_s / 1e9
-    traffic = None
-    tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
-    if os.path.exists(tf):
-      with open(tf, encoding="utf-8") as fh:
-        rec = json.load(fh)
-      key = f"{M.name}_b{n}"
-      if key in rec:
-        traffic = rec[key]["hbm_bytes_per_launch"]
+    launch_s = dev_ms_max * 1e-3 / K
     kern = "k_step_1<true>" if args.model != "live" else "k_step_{4,10,12}<true> (stream mix)"
     out = {
       "metric": "EKF predict+update steps/sec at batch N",
-      "value": n * world * K / r["wall"],
+      "value": value,
       "unit": "steps/s",
       "n_gpus": world,
       "steps": K,
       "warmup": W,
-      "ms_per_step": r["wall"] * 1e3 / K,
+      "ms_per_step": wall_max * 1e3 / K,
       "higher_is_better": True,
-      "scaling": "weak",
+      "scaling": scaling,
       "vs_baseline": None,
       "dtype": "f64",
       "data": "synthetic",
       "config": {"workload": f"{M.name} (D={D}, E={E}, Z={r['Z']:g}) fused predict+update, step-granular (state round-trips HBM each step), "
-                             f"batch {n} per GPU, shared R, scalar dt", "batch_per_gpu": n, "global_batch": n * world,
-                 "parallelism": f"batch-sharded x{world}, no data-path collective"},
-      "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                   "traffic": traffic, "kernel": kern, "algorithmic_bytes_per_launch": r["bytes_per_step"] * n,
-                   "launch_us": launch_s * 1e6},
+                             f"batch {n} on rank 0, shared R, scalar dt", "batch_per_gpu": n,
+                 "global_batch": int(round(steps_total / K)), "parallelism": f"batch-sharded x{world}, no data-path collective"},
+      "roofline": hbm_roofline(r["bytes_per_step"] * n, launch_s, kern, traffic=measured_traffic(M.name, n, r["gen"])),
     }
     if not args.no_cpu_baseline and world == 1:
       kind = 1 if args.model != "live" else 10
-      cb, ncpu, flav = cpu_baseline(M.name, kind, M, n)
+      cb, ncpu, flav, ckind = cpu_baseline(M.name, kind, M, n)
       one = cb["1core"]
-      out["cpu_baseline"] = {"value": one["value"], "unit": "steps/s", "cores": 1, "kind": "port",
-                             "sample": f"{ncpu} filters x {one['steps']} steps ({one['seconds']:.1f} s), {flav}, gcc -O2",
+      out["cpu_baseline"] = {"value": one["value"], "unit": "steps/s", "cores": 1, "kind": ckind,
+                             "sample": f"{ncpu} filters x {one['steps']} steps ({one['seconds']:.1f} s), {flav}, gcc -g -fPIC -O2 (the reference's flags)",
                              "all_cores": cb.get("allcores")}
+      if not args.no_extras:
+        c3, _, _, _ = cpu_baseline(M.name, kind, M, n, budget_s=3.0, suffix="_o3native", cflags=["-fPIC", "-O3", "-march=native"])
+        out["cpu_baseline"]["O3_march_native"] = {"1core": c3["1core"], "all_cores": c3.get("allcores")}
+        if args.model == "kinematic6":
+          from examples.live_kf import LiveKalman as L
+          cl, nl, _, _ = cpu_baseline("live", 10, L, 16384, budget_s=3.0)
+          out["cpu_baseline"]["live_kind10"] = {"1core": cl["1core"], "all_cores": cl.get("allcores"),
+                                                "sample": f"{nl} filters, fused predict + PHONE_ACCEL update, gcc -O2"}
     if extra:
       out["extra"] = extra
     print(json.dumps(out))

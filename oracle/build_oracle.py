@@ -267,6 +267,16 @@ def build(name, flavour="auto", cflags=None, suffix="", verbose=True):
   return lib
 
 
+def compile_glue(name, sub, cflags=None, suffix=""):
+  """gcc on an existing {sub}/{name}_glue.c (written by build()) with other flags -> {sub}/lib{name}{suffix}.so."""
+  out_dir = os.path.join(HERE, sub)
+  lib = os.path.join(out_dir, f"lib{name}{suffix}.so")
+  cmd = ["gcc", "-std=gnu11"] + (cflags or CFLAGS_REF) + ["-fopenmp", "-shared", "-I", HERE, os.path.join(out_dir, f"{name}_glue.c"),
+                                                         os.path.join(HERE, "ekf_oracle.c"), "-o", lib, "-lm"]
+  subprocess.run(cmd, check=True)
+  return lib
+
+
 def _parse_port(cpp_text):
   dims = {k: int(re.search(rf"#define {k} (\d+)", cpp_text).group(1)) for k in ("DIM", "EDIM", "MEDIM")}
   thresh = {int(k): float(v) for k, v in re.findall(r"MAHA_THRESH_(\d+) = ([0-9.eE+-]+);", cpp_text)}

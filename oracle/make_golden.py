@@ -148,14 +148,14 @@ def live_single_steps():
   np.savez_compressed(os.path.join(GOLD, "live_single_steps.npz"), **recs)
 
 
-def live_stream(n_ticks=40):
+def live_stream(n_ticks=40, out_name="live_stream.npz", keep_every=7, seed=2025):
   """IMU@100 Hz (gyro then accel at the same t) + ECEF_POS every 10th tick, stationary device, reference numpy
   path with quaternion_idxs=[3].  To get the C++ orchestrator's behaviour (renormalise after predict AND after
   update, /root/reference/rednose/helpers/ekf_sym.cc:207,213) from the Python class, each observation is applied
   as  f.predict(t)  [normalises, ekf_sym.py:461]  followed by predict_and_update_batch(t, ...) whose internal
   predict then has dt == 0 and is an exact identity (F = I, dt*Q = 0)."""
   L = _live_setup()
-  rng = np.random.default_rng(2025)
+  rng = np.random.default_rng(seed)
   f = ref_filter("live", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22, quaternion_idxs=[3])
   x_true = L.initial_x.copy()
   x0 = L.initial_x.copy()
@@ -180,9 +180,13 @@ def live_stream(n_ticks=40):
     est.append(r)
     xs.append(f.state().copy()); Ps.append(f.covs().copy()); ys.append(np.asarray(r[6][0]).flatten())
   xs, Ps = np.array(xs), np.array(Ps)
-  keep = np.arange(0, len(sched), 7).tolist() + [len(sched) - 1]
-  np.savez_compressed(os.path.join(GOLD, "live_stream.npz"), x0=x0, P0=P0, kinds=np.array(sched), ts=np.array(ts),
-                      zs=np.array(zs), ys=np.array(ys), xs=xs, x_pred=np.array(xps), P_idx=np.array(keep), Ps=Ps[keep])
+  keep = np.arange(0, len(sched), keep_every).tolist() + [len(sched) - 1]
+  if out_name == "live_stream.npz":
+    np.savez_compressed(os.path.join(GOLD, out_name), x0=x0, P0=P0, kinds=np.array(sched), ts=np.array(ts),
+                        zs=np.array(zs), ys=np.array(ys), xs=xs, x_pred=np.array(xps), P_idx=np.array(keep), Ps=Ps[keep])
+  else:      # long stream (BASELINE config 3: 10 s, 2 100 steps): states / covariances at the kept steps only
+    np.savez_compressed(os.path.join(GOLD, out_name), x0=x0, P0=P0, kinds=np.array(sched, dtype=np.int32), ts=np.array(ts),
+                        zs=np.array(zs), idx=np.array(keep), xs=xs[keep], Ps=Ps[keep])
   print("live stream:", len(sched), "steps; final pos err", xs[-1][:3] - x_true[:3], "quat", xs[-1][3:7])
   return f, est
 
@@ -393,6 +397,7 @@ if __name__ == "__main__":
   compare_rewind()
   live_single_steps()
   live_stream()
+  live_stream(n_ticks=1000, out_name="live_stream_2100.npz", keep_every=100, seed=2026)
   rts_goldens()
   maha_goldens()
   kinematic9_goldens()

@@ -29,6 +29,14 @@ def find_or_build(name, flavour="auto", suffix="", cflags=None):
     fn = os.path.join(HERE, sub, f"lib{name}{suffix}.so")
     if os.path.exists(fn):
       return fn, sub[1:]
+  # a variant with other compiler flags (suffix) of a model whose generated glue is already there: compile that glue --
+  # no code generation, works on the GPU box (where /root/reference does not exist), and flags like -march=native are
+  # resolved on the machine that will run the code
+  if suffix:
+    for sub in order:
+      glue = os.path.join(HERE, sub, f"{name}_glue.c")
+      if os.path.exists(glue):
+        return build_oracle.compile_glue(name, sub, cflags=cflags, suffix=suffix), sub[1:]
   fl = flavour if flavour != "auto" else ("ref" if build_oracle.have_reference() else "port")
   return build_oracle.build(name, fl, cflags=cflags, suffix=suffix, verbose=False), fl
 

@@ -480,6 +480,8 @@ def kernels(spec):
       A(f"  __shared__ __attribute__((aligned(16))) double s_Q[{EE}];      // process noise, staged once per wavefront")
       A(f"  for (int i = lane; i < {EE}; i += 64) s_Q[i] = ({dop} && gQ != nullptr) ? gQ[i] : 0.0;")
       A("  const double* qcol = s_Q;")
+    elif tune.wide_lean == 1 and tune.wide_lean_q:
+      A(f"  double qcol[{E}];                          // column cc of Q: loaded per tile AFTER the scalar phase (see below)")
     else:
       A(f"  double qcol[{E}];                          // column cc of Q, resident for the whole launch")
       A("#pragma unroll")
@@ -514,9 +516,19 @@ def kernels(spec):
     A(f"        scal_keep(s_x + lane * {D}, sl, {dop} ? norm_quats : 0);      // predict(dt = 0) still renormalises")
     A("      }")
     if upd:
+      A("      __builtin_amdgcn_sched_barrier(0);       // f / F first, then h / H: interleaved for ILP they need the sum of both register sets")
       A(f"      {_obs_call(k, 'true')};")
     A("    }")
     A("    rn::wave_lds_sync();")
+    if tune.wide_lean == 1 and tune.wide_lean_q:
+      A("    {")
+      A("      // Q's column is fetched here, behind an opaque zero, so that its 2 x dim_err registers are not live during the scalar")
+      A("      // phase above (the widest point of the kernel: with them it spilled); an L2 hit per tile, hidden under the first P wait")
+      A("      int qoff = 0;")
+      A("      asm volatile(\"\" : \"+v\"(qoff) :: \"memory\");")
+      A("#pragma unroll")
+      A(f"      for (int i = 0; i < {E}; i++) qcol[i] = ({dop} && gQ != nullptr) ? gQ[i * {E} + cc + qoff] : 0.0;")
+      A("    }")
     TL(2)
     A(f"    // ---------------- phase 2: {GL}-lane group per filter, {FPW} filters at a time, covariance algebra ----------")
     A(f"    const int ngroups = (cnt + {FPW - 1}) / {FPW};")

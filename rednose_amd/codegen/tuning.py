@@ -80,8 +80,46 @@ class Tuning:
                              # the three-phase step kernels into a device buffer read back by {name}_debug_timeline (tools/timeline.py)
 
 
+NO_MODEL_DEFAULTS = set()  # models whose build with the per-model defaults spilled registers: gen_code falls back to the general structure
+_MODEL_DEFAULTS = {}       # knob values chosen per model by model_defaults() while that model is being emitted
+
+
+def model_defaults(spec):
+  """Per-model defaults, applied by emit() around the emission of one library (RN_TUNE still overrides every knob).
+
+  Two 32-lane groups per wavefront and at most 24 error states, no feature-track kinds (live: 22): the register-lean
+  structure -- rows of P stay in LDS, Q column in registers, tiles of 8 filters, single P buffer, <= 256 registers -- puts
+  TWO wavefronts on every SIMD.  Measured on live, 16 384 filters (round 2, phase timeline of both builds in one call,
+  tools/timeline.py): a lone wavefront spends 4.5 us per pair of filters (0.5 waiting for the previous write-back, 1.5
+  predict, 2.0 update, 0.5 issuing stores: a chain of dependent LDS and fp64 operations that issues one instruction every
+  ~8 cycles), two co-resident wavefronts 6.4 us per pair EACH, i.e. 3.2 us per pair and SIMD: the dt > 0 launch ends after
+  32.4 us instead of 42.8 us."""
+  if spec is None or spec.name in NO_MODEL_DEFAULTS:
+    return {}
+  msckf = any(k.He_sym is not None for k in spec.kinds)
+  if not msckf and 22 <= spec.dim_err <= 24:
+    return dict(wide_lean=1, wide_lean_q=1, wide_ft=8, wide_lb=2, wide_db=0)
+  return {}
+
+
+class using_model:
+  """Context manager: emit one model's kernels with its per-model defaults."""
+
+  def __init__(self, spec):
+    self.vals = model_defaults(spec)
+
+  def __enter__(self):
+    _MODEL_DEFAULTS.clear()
+    _MODEL_DEFAULTS.update(self.vals)
+
+  def __exit__(self, *exc):
+    _MODEL_DEFAULTS.clear()
+
+
 def current():
-  vals = {}
+  vals = dict(_MODEL_DEFAULTS)
+  if os.environ.get("RN_TUNE_NO_MODEL_DEFAULTS"):
+    vals = {}
   names = {f.name for f in fields(Tuning)}
   for kv in os.environ.get("RN_TUNE", "").split(","):
     if "=" in kv:

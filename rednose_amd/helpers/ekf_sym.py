@@ -62,6 +62,21 @@ def gen_code(folder, name, f_sym, dt_sym, x_sym, obs_eqs, dim_x, dim_err, eskf_p
         f.write(source)
       rn_build.compile_filter(folder, name, verbose=verbose)
       bad = rn_build.spilled_kernels(rn_build.compile_filter.last_usage)
+    from rednose_amd.codegen import tuning as rn_tuning
+    heavy = [k for k in bad if rn_build.compile_filter.last_usage[k]["vgpr_spill"] > 8]
+    if heavy and rn_tuning.model_defaults(spec) and not os.environ.get("RN_ALLOW_SPILLS"):
+      # the two-wavefronts-per-SIMD structure chosen for this model size does not fit 256 registers with this model's
+      # expressions: build the general structure instead
+      if verbose:
+        print(f"{name}: {heavy} spill under the per-model tuning defaults -> regenerating with the general structure")
+      rn_tuning.NO_MODEL_DEFAULTS.add(name)
+      header, source = emit(spec)
+      with open(os.path.join(folder, f"{name}.h"), "w", encoding="utf-8") as f:
+        f.write(header)
+      with open(os.path.join(folder, f"{name}.hip"), "w", encoding="utf-8") as f:
+        f.write(source)
+      rn_build.compile_filter(folder, name, verbose=verbose)
+      bad = rn_build.spilled_kernels(rn_build.compile_filter.last_usage)
     bad_rts = [k for k in bad if k.startswith("k_rts")]
     if bad_rts and not os.environ.get("RN_ALLOW_SPILLS"):
       raise RuntimeError(f"{name}: smoother kernel {bad_rts} spills registers (see {folder}/{name}.kernels.txt); "
@@ -689,7 +704,7 @@ class BatchedEKF:
     return ~(self.maha_dist(kind, z, R, extra_args) > chi2_ppf(maha_thresh, self.zdims[kind]))
 
   # -- fused multi-step run -------------------------------------------------------------------------
-  def run(self, ts, kinds, zs, Rs=None, trace=False, flags=False):
+  def run(self, ts, kinds, zs, Rs=None, trace=False, flags=False, out=None, filters=None):
     """T predict+update steps in ONE launch; x and P stay on chip between steps.
 
     ts (T,) observation times, kinds (T,) observation kinds -- the schedule is shared by all filters;
@@ -697,7 +712,10 @@ class BatchedEKF:
     residuals y.  Rs: {kind: (Z, Z)} (default: none -> KeyError) or a (T, zmax, zmax) array whose leading
     Z*Z entries per step are the row-major R of that step.  trace=True also returns the filtered states
     (T, N, D) and covariances (T, N, E, E) -- what the RTS smoother consumes.
-    Returns (ys, trace_x, trace_P, flags) with None for outputs not requested.
+    out = (trace_x, trace_P): preallocated contiguous float64 device tensors for the trace (implies trace=True; a 16 384 x
+    210-step live trace is 14 GB -- callers that repeat a run reuse one allocation instead of paying a fresh one each time).
+    filters = (lo, hi): run only filters lo .. hi-1 of the batch (their x / P records are contiguous); N above is then
+    hi - lo.  Returns (ys, trace_x, trace_P, flags) with None for outputs not requested.
     """
     torch = self._torch
     ts = np.asarray(ts, dtype=np.float64)
@@ -717,7 +735,10 @@ class BatchedEKF:
     t0 = self.filter_time if self.filter_time is not None else ts[0]
     dts = np.diff(np.concatenate([[t0], ts]))
     assert (dts >= 0).all(), "batched filters do not rewind: the schedule must be in time order"
-    zs = self._dev(zs, (T, self.batch, zmax))
+    lo, hi = (0, self.batch) if filters is None else (int(filters[0]), int(filters[1]))
+    assert 0 <= lo <= hi <= self.batch
+    nb = hi - lo
+    zs = self._dev(zs, (T, nb, zmax))
     if isinstance(Rs, dict) or Rs is None:
       table = np.zeros((T, zmax * zmax))
       for t, k in enumerate(kinds.tolist()):
@@ -728,16 +749,85 @@ class BatchedEKF:
     Rd = self._dev(table)
     kd = torch.as_tensor(kinds, device=self.device)
     dd = self._dev(dts)
-    tx = torch.empty((T, self.batch, self.dim_x), dtype=torch.float64, device=self.device) if trace else None
-    tP = torch.empty((T, self.batch, self.dim_err, self.dim_err), dtype=torch.float64, device=self.device) if trace else None
-    fl = torch.zeros((T, self.batch), dtype=torch.uint8, device=self.device) if flags else None
-    self._call("batch_run", self._p(self.x), self._p(self.P), self._p(self.Q), self._p(kd), self._p(dd), T, self._p(zs),
-               self._p(Rd), self.batch, self.norm_quats, self._p(fl), self._p(tx), self._p(tP), self._stream())
+    if out is not None:
+      tx, tP = out
+      for t_, shp in ((tx, (T, nb, self.dim_x)), (tP, (T, nb, self.dim_err, self.dim_err))):
+        assert t_.is_contiguous() and t_.dtype == torch.float64 and tuple(t_.shape) == shp and t_.device == self.device, "out: wrong trace buffer"
+    else:
+      tx = torch.empty((T, nb, self.dim_x), dtype=torch.float64, device=self.device) if trace else None
+      tP = torch.empty((T, nb, self.dim_err, self.dim_err), dtype=torch.float64, device=self.device) if trace else None
+    fl = torch.zeros((T, nb), dtype=torch.uint8, device=self.device) if flags else None
+    if nb == 0:
+      return zs, tx, tP, fl
+    xv, Pv = self.x[lo:hi], self.P[lo:hi]          # contiguous views: record lo starts 16-byte aligned whenever record 0 does
+    self._call("batch_run", self._p(xv), self._p(Pv), self._p(self.Q), self._p(kd), self._p(dd), T, self._p(zs),
+               self._p(Rd), nb, self.norm_quats, self._p(fl), self._p(tx), self._p(tP), self._stream())
     self.filter_time = float(ts[-1])
     self._keepalive = (kd, dd, Rd)      # the launch is asynchronous: keep its inputs alive
     return zs, tx, tP, fl
 
   # -- offline smoothing ----------------------------------------------------------------------------
+  def smooth(self, ts, kinds, zs, Rs, passes=1, chunk=None, norm_quats=None, on_chunk=None, flags=False):
+    """Offline estimation over a whole observation stream: forward filter keeping the filtered trace, then the RTS
+    backward pass -- `passes` times, each pass restarting the filter from the oldest smoothed estimate of the previous
+    one ("multiple forward and backwards passes of the data", /root/reference/README.md:41-45, built on rts_smooth,
+    ekf_sym.py:651-690).
+
+    ts, kinds, zs, Rs: as for run() (zs (T, N, zmax) is NOT consumed here).  The filter starts every pass at the filter
+    time it had when smooth() was called (None: the first step has dt = 0) and, for pass 1, from its current (x, P).
+    chunk: filters per forward/backward sweep.  The filtered trace of T steps costs T * (D + E*E) * 8 bytes per filter
+    (live: 17 MB per filter at 2 100 steps, 279 GB for 16 384 filters with the predicted pairs the reference keeps,
+    140 GB here); filters are independent, so the batch is swept in chunks whose trace fits -- the result is identical
+    to one sweep.  on_chunk(lo, hi, xs, Ps, ys, flags) receives each chunk's smoothed trajectory (device tensors, valid
+    only during the call: the buffers are reused); without it the whole smoothed trajectory is returned, which needs the
+    trace of the full batch to fit.  On return x / P hold the FILTERED state after the last pass and filter_time = ts[-1].
+    Returns (xs (T, N, D), Ps (T, N, E, E)) or None when on_chunk is given.
+    """
+    torch = self._torch
+    ts = np.asarray(ts, dtype=np.float64)
+    T = len(ts)
+    assert passes >= 1 and T >= 1
+    zmax = getattr(self._lib, f"{self.name}_zmax")()
+    zs = self._dev(zs, (T, self.batch, zmax))
+    step = self.batch if chunk is None else max(1, min(int(chunk), self.batch))
+    if on_chunk is None and step < self.batch:
+      raise KalmanError("smooth(chunk=...) hands the smoothed trajectory out chunk by chunk: pass on_chunk")
+    t_init = self.filter_time
+    tx = torch.empty((T, step, self.dim_x), dtype=torch.float64, device=self.device)
+    tP = torch.empty((T, step, self.dim_err, self.dim_err), dtype=torch.float64, device=self.device)
+    for lo in range(0, self.batch, step):
+      hi = min(self.batch, lo + step)
+      m = hi - lo
+      bx, bP = (tx, tP) if m == step else (tx[:, :m].contiguous(), tP[:, :m].contiguous())
+      for p in range(passes):
+        self.filter_time = t_init
+        zc = zs[:, lo:hi].contiguous()          # run() consumes its observations (overwrites them with the residuals)
+        ys, _, _, fl = self.run(ts, kinds, zc, Rs, flags=flags, out=(bx, bP), filters=(lo, hi))
+        # the smoother works on the trace of this chunk only: a view of the orchestrator restricted to its filters
+        xs, Ps = self._rts_on(bx, bP, ts, m, norm_quats)
+        if p + 1 < passes:
+          self.x[lo:hi].copy_(xs[0])
+          self.P[lo:hi].copy_(Ps[0])
+      if on_chunk is not None:
+        on_chunk(lo, hi, xs, Ps, ys, fl)
+    self.filter_time = float(ts[-1])
+    if on_chunk is None:
+      return xs, Ps
+    return None
+
+  def _rts_on(self, tx, tP, ts, m, norm_quats):
+    """In-place backward pass over a trace of m filters (m <= batch)."""
+    torch = self._torch
+    if not hasattr(self._lib, f"{self.name}_batch_rts"):
+      raise KalmanError(f"lib{self.name}.so has no batch_rts entry point")
+    T = int(tx.shape[0])
+    td = self._dev(np.asarray(ts, dtype=np.float64) if not isinstance(ts, torch.Tensor) else ts, (T,))
+    nq = self.norm_quats | ((self.norm_quats if norm_quats is None else int(bool(norm_quats))) << 1)
+    self._call("batch_rts", self._p(tx), self._p(tP), self._p(td), T, self._p(self.Q), m, nq, self._p(tx), self._p(tP),
+               None, None, self._stream())
+    self._keepalive_rts = (tx, tP, td)
+    return tx, tP
+
   def rts_smooth(self, trace_x, trace_P, ts, norm_quats=None, inplace=False, last_predicted=None):
     """Batched Rauch-Tung-Striebel backward pass over the filtered trace returned by run(trace=True).
 

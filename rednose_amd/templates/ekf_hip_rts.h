@@ -467,24 +467,51 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
       // behind it, and pin() keeps the FMAs of this pivot in front of it.  Without pin() hipcc issues the loads of ALL
       // pivots first and every FMA after the last fence (arithmetic is free to cross a fence): 460 live coefficients,
       // 1 050 spilled registers, a scratch round trip per operand.  Neither costs an instruction.
-      static_for<EM>([&](auto Mi) {
-        constexpr int m = decltype(Mi)::value;
-        y[m] *= sil[m];
+      // The coefficients of pivot m + 1 (and its reciprocal pivot) are requested before the FMAs of pivot m, so their LDS
+      // latency overlaps that arithmetic instead of being exposed once per pivot.
+      {
+        double cur[EM], nxt[EM], ilc, iln = 0.0;
 #pragma unroll
-        for (int i = m + 1; i < EM; i++) y[i] = fma(-B[i * EM + m], y[m], y[i]);
+        for (int i = 1; i < EM; i++) cur[i] = B[i * EM + 0];
+        ilc = sil[0];
+        static_for<EM>([&](auto Mi) {
+          constexpr int m = decltype(Mi)::value;
+          if constexpr (m + 1 < EM) {
 #pragma unroll
-        for (int i = m + 1; i < EM; i++) pin(y[i]);
-        wave_lds_sync();
-      });
-      static_for<EM>([&](auto Mi) {
-        constexpr int m = EM - 1 - decltype(Mi)::value;
-        y[m] *= sil[m];
+            for (int i = m + 2; i < EM; i++) nxt[i] = B[i * EM + (m + 1)];
+            iln = sil[m + 1];
+          }
+          y[m] *= ilc;
 #pragma unroll
-        for (int i = 0; i < m; i++) y[i] = fma(-B[m * EM + i], y[m], y[i]);
+          for (int i = m + 1; i < EM; i++) y[i] = fma(-cur[i], y[m], y[i]);
 #pragma unroll
-        for (int i = 0; i < m; i++) pin(y[i]);
-        wave_lds_sync();
-      });
+          for (int i = m + 1; i < EM; i++) pin(y[i]);
+          wave_lds_sync();
+#pragma unroll
+          for (int i = m + 2; i < EM; i++) cur[i] = nxt[i];
+          ilc = iln;
+        });
+#pragma unroll
+        for (int i = 0; i < EM - 1; i++) cur[i] = B[(EM - 1) * EM + i];
+        ilc = sil[EM - 1];
+        static_for<EM>([&](auto Mi) {
+          constexpr int m = EM - 1 - decltype(Mi)::value;
+          if constexpr (m >= 1) {
+#pragma unroll
+            for (int i = 0; i < m - 1; i++) nxt[i] = B[(m - 1) * EM + i];
+            iln = sil[m - 1];
+          }
+          y[m] *= ilc;
+#pragma unroll
+          for (int i = 0; i < m; i++) y[i] = fma(-cur[i], y[m], y[i]);
+#pragma unroll
+          for (int i = 0; i < m; i++) pin(y[i]);
+          wave_lds_sync();
+#pragma unroll
+          for (int i = 0; i < m - 1; i++) cur[i] = nxt[i];
+          ilc = iln;
+        });
+      }
       // y is column c of Ck^T, i.e. row c of Ck
       // ---- G. state: delta = Ck inv_err(xk1_k, xk1_n)[:EM]; xk_n[:DM] = err(xk_k, delta)[:DM] -----------------------------
       if (lead) {
@@ -528,11 +555,22 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
         double trow[EM];
 #pragma unroll
         for (int m = 0; m < EM; m++) trow[m] = 0.0;
+        // operands of step j + 1 are requested before the FMAs of step j (register double buffer)
+        double cur[EM], nxt[EM], ckc, ckn;
+#pragma unroll
+        for (int m = 0; m < EM; m++) cur[m] = C[m];
+        ckc = B[cc];
 #pragma unroll 2
         for (int j = 0; j < EM; j++) {
-          const double ckj = B[j * EM + cc];                                            // Ck[c][j]
+          const int jn = (j + 1 < EM) ? j + 1 : j;
 #pragma unroll
-          for (int m = 0; m < EM; m++) trow[m] = fma(ckj, C[j * EM + m], trow[m]);       // row j of Dm: contiguous broadcast
+          for (int m = 0; m < EM; m++) nxt[m] = C[jn * EM + m];                          // row j + 1 of Dm: contiguous broadcast
+          ckn = B[jn * EM + cc];                                                         // Ck[c][j + 1]
+#pragma unroll
+          for (int m = 0; m < EM; m++) trow[m] = fma(ckc, cur[m], trow[m]);
+#pragma unroll
+          for (int m = 0; m < EM; m++) cur[m] = nxt[m];
+          ckc = ckn;
         }
         wave_lds_sync();         // every lane has read all of Dm: its buffer takes T (row c written by lane c)
         if (on) {
@@ -544,11 +582,21 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
         double nn[EM];
         rts_load_row<E, EM>(Pk, nn);          // row c of Pk_k again (L2 hit): cheaper than 2 EM registers held through the step
         wave_lds_sync();
+        double cur[EM], nxt[EM], tc, tn;
+#pragma unroll
+        for (int m = 0; m < EM; m++) cur[m] = B[m];
+        tc = C[cc * EM];
 #pragma unroll 2
         for (int j = 0; j < EM; j++) {
-          const double tj = C[cc * EM + j];
+          const int jn = (j + 1 < EM) ? j + 1 : j;
 #pragma unroll
-          for (int m = 0; m < EM; m++) nn[m] = fma(tj, B[j * EM + m], nn[m]);          // row j of Ck^T: contiguous broadcast
+          for (int m = 0; m < EM; m++) nxt[m] = B[jn * EM + m];                         // row j + 1 of Ck^T: contiguous broadcast
+          tn = C[cc * EM + jn];
+#pragma unroll
+          for (int m = 0; m < EM; m++) nn[m] = fma(tc, cur[m], nn[m]);
+#pragma unroll
+          for (int m = 0; m < EM; m++) cur[m] = nxt[m];
+          tc = tn;
         }
         // row c of Pk_n = Pk1_n of the next (older) step parks in this lane's own row of C (T's row c is consumed)
         if (on) {

@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 
 from conftest import REPO
 
@@ -67,3 +68,29 @@ def test_two_rank_sharding_matches_single_process():
   OracleLib("kinematic6").batch_step(1, x, P, z, np.eye(3) * 0.01, np.eye(6) * 0.1, 0.01)
   assert np.array_equal(np.concatenate([res[0][7], res[1][7]]), x)
   assert res[0][6] == res[1][6] == [state_checksum(res[0][7]), state_checksum(res[1][7])]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["weak", "strong"])
+def test_bench_two_ranks_on_one_gpu(mode):
+  """bench.py's N > 1 path end to end: two ranks launched the way the driver launches them (torch.distributed.run,
+  127.0.0.1 rendezvous), both on the ONE leased GPU over gloo (RCCL refuses two ranks per device; RN_BENCH_BACKEND exists for
+  exactly this dry run).  Checks the aggregated JSON line: SUM of steps over ranks, one line, rank 0 only."""
+  import json
+  import subprocess
+  import sys
+  env = dict(os.environ, RN_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+  size = ["--batch", "4096"] if mode == "weak" else ["--global-batch", "8190"]
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
+         "--no-cpu-baseline"] + size
+  res = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=REPO, timeout=600)
+  assert res.returncode == 0, res.stderr[-3000:]
+  lines = [ln for ln in res.stdout.split("\n") if ln.startswith("{")]
+  assert len(lines) == 1, res.stdout[-2000:]
+  out = json.loads(lines[0])
+  total = 8192 if mode == "weak" else 8190
+  assert out["n_gpus"] == 2 and out["steps"] == 30 and out["scaling"] == mode
+  assert out["config"]["global_batch"] == total
+  assert abs(out["value"] - total * 30 / (out["ms_per_step"] * 1e-3 * 30)) < 1e-6 * out["value"]
+  assert 0 < out["roofline"]["frac"] < 1 and "extra" not in out
