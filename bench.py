@@ -249,7 +249,8 @@ def run_model(torch, dist, model, n, K, W, dev, rank, world, only_kind=None):
   # the timed loop calls the library's C entry point through pre-bound arguments (what a C/C++ caller does);
   # BatchedEKF.predict_and_update_batch adds several microseconds of Python argument handling per call
   bound = {k: f.bind_step(k, Rs[k]) for k in sorted(set(s_[0] for s_ in sched))}
-  sched = [(k, t, z.contiguous()) for (k, t, z) in sched]
+  sched = [(k, t, z.clone()) for (k, t, z) in sched]       # own allocation per step: the C ABI wants 16-byte aligned observations, and row
+  #                                                          i of a (T, n, Z) tensor is not when n * Z is odd (uneven shards)
   t_prev = [None]
 
   def step(i):
@@ -321,10 +322,10 @@ def fused_run_extra(torch, model, n, T, dev):
                   "the count is every v_*_f64 instruction of the kernel (llvm-objdump), an upper bound of the per-step loop body"}
 
 
-def config4_extra(torch, dev, rank, nb=16384, T=2100, chunk=2048):
+def config4_extra(torch, dev, rank, nb=16384, T=2100, chunk=4096):
   """BASELINE config 4 at its stated size: live with the Mahalanobis gate on ECEF_POS, 2 % GNSS outliers, forward pass keeping
   the filtered trace, RTS backward pass -- swept in chunks of `chunk` filters (the trace of a chunk is T x chunk x 4 056 B:
-  17.4 GB at 2 048; filters are independent, the result is that of one sweep).  The trace buffers are allocated once, outside
+  35 GB at 4 096 -- 2 048 tiles, two wavefronts on every SIMD; filters are independent, the result is that of one sweep).  The trace buffers are allocated once, outside
   the timed region; forward and backward times are the sums of per-chunk HIP-event intervals."""
   from examples.live_kf import LiveKalman as L
   from rednose_amd.helpers.ekf_sym import BatchedEKF

@@ -27,7 +27,7 @@ def source_digest(*texts):
   h = hashlib.sha256()
   for t in texts:
     h.update(t.encode("utf-8"))
-  for hdr in ("ekf_hip_rt.h", "ekf_hip_rts.h"):
+  for hdr in ("ekf_hip_rt.h", "ekf_hip_rts.h", "ekf_plugin.h"):
     with open(os.path.join(TEMPLATE_DIR, hdr), "rb") as f:
       h.update(f.read())
   h.update((" ".join(HIPCC_FLAGS) + os.environ.get("RN_HIPCC_FLAGS", "")).encode())

@@ -7,9 +7,10 @@ This is the replacement for the BACK half of the reference's gen_code
     {name}_predict (:162), {name}_set_{var} (:166-171) -- so `load_code` style loaders keep working;
   * `lib{name}.so` is self-contained and lives beside the header.
 What is new: `int {name}_batch_*` entry points over DEVICE pointers (include/rednose_amd_filter.h),
-and every symbol, scalar ones included, executes on the GPU.  The C++-ABI `EKF` plugin struct /
-`ekf_get()` (:186-203, rednose/helpers/ekf.h) is not emitted: it exists to feed the Eigen-based
-`EKFSym`, which is outside the hot path (DESIGN.md "out of scope").
+and every symbol, scalar ones included, executes on the GPU.  The C++ plugin hook of the reference
+(:186-203: `const EKF {name} = {...}` + `ekf_lib_init` -> `extern "C" void *ekf_get()`, rednose/helpers/ekf.h:14-42)
+is emitted too (plugin_text below, templates/ekf_plugin.h), so the reference's `ekf_load_and_register`
+(ekf_load.cc:22-39) and through it `EKFSym` can load a rednose_amd library unmodified.
 """
 import sympy as sp
 
@@ -54,6 +55,31 @@ def emit(spec):
     return _emit(spec)
 
 
+def plugin_text(spec):
+  """The reference's plugin descriptor (ekf_sym.py:186-203): name, kinds, feature kinds and the scalar entry points by kind /
+  by name, published through ekf_get() and, when the host defines it, ekf_register() at load time (ekf.h:35-42)."""
+  name = spec.name
+  feat = [k.kind for k in spec.kinds if k.He_sym is not None]
+  L = ["", "// ---- C++ plugin hook (/root/reference/rednose/helpers/ekf.h:14-42, emitted by the reference at ekf_sym.py:186-203) ----",
+       '#include "ekf_plugin.h"', "namespace {", "const EKF& rn_plugin_descriptor() {", "  static const EKF e = [] {", "    EKF d;",
+       f'    d.name = "{name}";', f"    d.kinds = {{ {', '.join(str(k.kind) for k in spec.kinds)} }};",
+       f"    d.feature_kinds = {{ {', '.join(str(k) for k in feat)} }};"]
+  for fn in ("f_fun", "F_fun", "err_fun", "inv_err_fun", "H_mod_fun", "predict"):
+    L.append(f"    d.{fn} = {name}_{fn};")
+  for k in spec.kinds:
+    L.append(f"    d.hs[{k.kind}] = {name}_h_{k.kind}; d.Hs[{k.kind}] = {name}_H_{k.kind}; d.updates[{k.kind}] = {name}_update_{k.kind};")
+  for k in feat:
+    L.append(f"    d.Hes[{k}] = {name}_He_{k};")
+  for var in spec.global_vars:
+    L.append(f'    d.sets["{var.name}"] = {name}_set_{var.name};')
+  for r in spec.extra_routines:
+    L.append(f'    d.extra_routines["{r[0]}"] = reinterpret_cast<extra_routine_t>({name}_{r[0]});')
+  L += ["    return d;", "  }();", "  return e;", "}", "}  // namespace",
+        'extern "C" void *ekf_get() { return (void *)&rn_plugin_descriptor(); }',
+        "static void __attribute__((constructor)) rn_plugin_register(void) { if (ekf_register) ekf_register(&rn_plugin_descriptor()); }", ""]
+  return "\n".join(L)
+
+
 def _emit(spec):
   name = spec.name
   D, E, M = spec.dim_x, spec.dim_err, spec.dim_main_err
@@ -96,6 +122,7 @@ def _emit(spec):
   hdr = ["#pragma once", "#include <stdint.h>", "#ifdef __cplusplus", 'extern "C" {', "#endif"]
   src = [f"// GENERATED by rednose_amd.helpers.ekf_sym.gen_code for filter '{name}' -- do not edit.",
          f"// DIM={D} EDIM={E} MEDIM={M} kinds={[k.kind for k in spec.kinds]} family={fam}",
+         *(["#define RN_RTS_TL 1"] if (fam == "wide" and __import__("rednose_amd.codegen.tuning", fromlist=["x"]).current().wide_timeline) else []),
          '#include "ekf_hip_rt.h"', '#include "ekf_hip_rts.h"', "", "namespace {",
          f"constexpr int DIM = {D};", f"constexpr int EDIM = {E};", f"constexpr int MEDIM = {M};", ""]
 
@@ -236,6 +263,18 @@ __global__ __launch_bounds__(64) void k_augment(double* __restrict__ gx, double*
   return rn::OK;
 }}""")
     hdr.append(f"int {name}_debug_timeline(unsigned long long *out);")
+    abi.append(f"""int {name}_debug_rts_timeline(unsigned long long *out) {{
+  RN_HIP(hipDeviceSynchronize());
+  RN_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(rn::g_rts_tl), sizeof(unsigned long long) * 256 * 16, 0, hipMemcpyDeviceToHost));
+  return rn::OK;
+}}
+int {name}_debug_blocks(unsigned long long *out) {{
+  RN_HIP(hipDeviceSynchronize());
+  RN_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tlb), sizeof(unsigned long long) * 4096 * 2, 0, hipMemcpyDeviceToHost));
+  return rn::OK;
+}}""")
+    hdr.append(f"int {name}_debug_rts_timeline(unsigned long long *out);")
+    hdr.append(f"int {name}_debug_blocks(unsigned long long *out);")
   # batched, device pointers
   abi.append(f"""int {name}_batch_predict(double *x, double *P, const double *Q, const double *dt_vec, double dt, int64_t n, int norm_quats, void *stream) {{
   RN_REQUIRE(n >= 0 && x && P && Q, rn::ERR_ARG);
@@ -375,6 +414,7 @@ void {name}_predict(double *in_x, double *in_P, double *in_Q, double dt) {{
     hdr.append(f"void {name}_update_{k.kind}(double *in_x, double *in_P, double *in_z, double *in_R, double *in_ea);")
   abi += wrappers
   abi.append('}  // extern "C"')
+  abi.append(plugin_text(spec))
 
   hdr += ["#ifdef __cplusplus", "}", "#endif", ""]
   return "\n".join(hdr), "\n".join(src) + "\n" + "\n".join(abi) + "\n"

@@ -440,6 +440,7 @@ def kernels(spec):
   lbs = f"__launch_bounds__(64, {tune.wide_lb})" if tune.wide_lb else "__launch_bounds__(64)"
   if tune.wide_timeline:
     out.append("__device__ unsigned long long g_tl[256 * 64 * 2];      // debug timeline (tuning knob wide_timeline)")
+    out.append("__device__ unsigned long long g_tlb[4096 * 2];         // start / end of EVERY workgroup's first tile")
 
   def kernel(kname, k=None):
     upd = k is not None
@@ -499,6 +500,8 @@ def kernels(spec):
     A("    const int64_t base = tile * FT2;")
     A("    const int cnt = (n - base) < FT2 ? (int)(n - base) : FT2;")
     TL(0)
+    if TLK:
+      A("    if (lane == 0 && tile == blockIdx.x && blockIdx.x < 4096) g_tlb[blockIdx.x * 2] = wall_clock64();")
     A("    // ---------------- phase 1: lane l = filter l, x-dependent scalars -> LDS slot ----------------")
     A(f"    rn::copy_g2l<FT2 * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);")
     if upd:
@@ -581,6 +584,8 @@ def kernels(spec):
       A(f"    rn::copy_l2g<FT2 * {Z}>(gz + base * {Z}, cnt * {Z}, s_z, lane);")
     A("    rn::wave_lds_sync();")
     TL(63)
+    if TLK:
+      A("    if (lane == 0 && tile == blockIdx.x && blockIdx.x < 4096) g_tlb[blockIdx.x * 2 + 1] = wall_clock64();")
     A("  }")
     A("}")
     return "\n".join(L) + "\n"

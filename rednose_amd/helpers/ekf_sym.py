@@ -77,7 +77,7 @@ def gen_code(folder, name, f_sym, dt_sym, x_sym, obs_eqs, dim_x, dim_err, eskf_p
         f.write(source)
       rn_build.compile_filter(folder, name, verbose=verbose)
       bad = rn_build.spilled_kernels(rn_build.compile_filter.last_usage)
-    bad_rts = [k for k in bad if k.startswith("k_rts")]
+    bad_rts = [k for k in bad if k.startswith("k_rts") and rn_build.compile_filter.last_usage[k]["scratch"] > 0]
     if bad_rts and not os.environ.get("RN_ALLOW_SPILLS"):
       raise RuntimeError(f"{name}: smoother kernel {bad_rts} spills registers (see {folder}/{name}.kernels.txt); "
                          "set RN_ALLOW_SPILLS=1 to build it anyway")
@@ -682,8 +682,9 @@ class BatchedEKF:
     def step(z, dt):
       rc = fn(px, pP, pQ, None, dt, void_p(z.data_ptr()), pR, per, None, n, nq, pfl, stream)
       if rc != 0:
-        self._call("clear_error")
-        raise KalmanError(f"{self.name}_batch_predict_update_{kind} -> {rc}")
+        msg = self._ffi.string(getattr(self._lib, f"{self.name}_last_error_string")()).decode()
+        getattr(self._lib, f"{self.name}_clear_error")()
+        raise KalmanError(f"{self.name}_batch_predict_update_{kind} -> {rc}: {msg}")
     return step
 
   # -- analysis: Mahalanobis test without touching the state -----------------------------------------

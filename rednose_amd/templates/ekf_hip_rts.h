@@ -311,6 +311,15 @@ __device__ __forceinline__ void rts_store_row(double* __restrict__ p, const doub
   }
 }
 
+// Debug phase timeline (builds with -DRN_RTS_TL, tuning knob wide_timeline): lane 0 of the first 256 workgroups stamps the
+// 100 MHz wall clock at the phase boundaries of the backward step k == T / 2 of its first tile (tools/timeline.py).
+#ifdef RN_RTS_TL
+__device__ unsigned long long g_rts_tl[256 * 16];
+#define RN_RTS_STAMP(i) do { if (lane == 0 && blockIdx.x < 256 && tile == blockIdx.x && k == T / 2) g_rts_tl[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define RN_RTS_STAMP(i) do { } while (0)
+#endif
+
 template <class Model>
 __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __restrict__ xf, const double* __restrict__ Pf,
                                                      const double* __restrict__ ts, const int64_t T,
@@ -379,19 +388,23 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
       // ---- A. filtered pair of step k: row c of Pk_k to registers, xk_k to LDS --------------------------------------
       const double* Pk = Pf + ((k * n + fil) * EE + (int64_t)cc * E);
       double y[EM];
+      RN_RTS_STAMP(0);
       {
         for (int i = c; i < D; i += GL) sxk[i] = xf[(k * n + fil) * D + i];
         const double dt = ts[k + 1] - ts[k];
         wave_lds_sync();
         // ---- B. f(xk_k), non-zeros of Fk: once per filter -> slot (no matrix row is live in registers meanwhile) ---------
+        RN_RTS_STAMP(1);
         if (lead) Model::scal(sxk, dt, sl, norm_quats & 1);
         wave_lds_sync();
+        RN_RTS_STAMP(2);
         // ---- C. predicted pair of step k+1 (main block): B <- Pk1_k, y <- column c of M = Fk Pk_k^T -----------------------
         double prow[EM];
         rts_load_row<E, EM>(Pk, prow);
         Model::mat_predict(prow, B, gQ, sl, cc, on, y);
       }
       // ---- D. recursion start / difference matrix / smoothed estimate of step k+1 leaves ------------------------------------
+      RN_RTS_STAMP(3);
       // Row c of Pk1_n waited in this lane's row of the difference buffer since the end of the previous step (no other lane
       // touches it): no matrix row stays in registers across the phases above.
       double lrow[EM], nrow[EM];
@@ -438,6 +451,7 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
         }
       }
 
+      RN_RTS_STAMP(4);
       // ---- E. Cholesky of Pk1_k, left-looking: lane c owns row c in registers; pivot row j (final since column j - 1) is
       // broadcast from LDS and every lane forms its own entry AND the pivot redundantly -- no publish / wait per column -------
       static_for<EM>([&](auto J) {
@@ -460,6 +474,7 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
         wave_lds_sync();
       });
       wave_lds_sync();
+      RN_RTS_STAMP(5);
       // ---- F. Ck^T = Pk1_k^-1 M: lane c solves for column c in registers (right-looking substitutions) -------------------
       // Fully unrolled (the register column needs compile-time indices) through static_for -- `#pragma unroll` does not
       // duplicate the wavefront fence, and a loop that stays rolled sends the register column to scratch memory.  Two things
@@ -512,6 +527,7 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
           ilc = iln;
         });
       }
+      RN_RTS_STAMP(6);
       // y is column c of Ck^T, i.e. row c of Ck
       // ---- G. state: delta = Ck inv_err(xk1_k, xk1_n)[:EM]; xk_n[:DM] = err(xk_k, delta)[:DM] -----------------------------
       if (lead) {
@@ -541,6 +557,7 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
 #pragma unroll
         for (int i = 0; i < D; i++) sxn[i] = (i < DM) ? xnew[i] : xa[i];       // xk_n: becomes xk1_n of the next (older) step
       }
+      RN_RTS_STAMP(7);
       // ---- H. covariance: Pk_n = Pk_k + (Ck Dm) Ck^T, row c ----------------------------------------------------------------
       // Rolled loops over the inner index: the multiplier of each step (an entry of this lane's row of Ck, then of T) comes
       // from LDS, where the lane parked that row, so no register array is indexed by the loop variable; the accumulator row is
@@ -578,6 +595,7 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
           for (int m = 0; m < EM; m++) C[c * EM + m] = trow[m];
         }
       }
+      RN_RTS_STAMP(8);
       {
         double nn[EM];
         rts_load_row<E, EM>(Pk, nn);          // row c of Pk_k again (L2 hit): cheaper than 2 EM registers held through the step
@@ -605,6 +623,7 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
         }
       }
       wave_lds_sync();
+      RN_RTS_STAMP(9);
     }
     // ---- the oldest smoothed estimate goes out un-normalised (ekf_sym.py:665-667 never reaches it) --------------------------
     if (T >= 2) {

@@ -41,3 +41,43 @@ def test_cpp_orchestrator_known_answers(tmp_path):
     for got, want in zip((v[0], v[2], v[1], v[3]), lit):
       assert round(abs(got - want), 7) == 0                                # the reference's assertAlmostEqual
     assert abs(v[0] - g["xs"][-1][0]) < 1e-10 and abs(v[1] - g["xs"][-1][1]) < 1e-10
+
+
+def _build_plugin_host():
+  src = os.path.join(REPO, "tests", "cpp", "test_ekf_plugin.cpp")
+  exe = os.path.join(REPO, "tests", "cpp", "test_ekf_plugin")
+  hdr = os.path.join(REPO, "include", "rednose_amd", "ekf_plugin.h")
+  if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    # -rdynamic: the library's weak ekf_register must bind to the host's definition, as it does when the reference's
+    # ekf_load.cc lives in a shared object of its own
+    subprocess.run(["g++", "-O2", "-std=c++17", "-rdynamic", "-I", os.path.join(REPO, "include"), src, "-o", exe, "-ldl"], check=True)
+  return exe
+
+
+@pytest.mark.parametrize("name,kinds,nfeat", [("kinematic", "1", 0), ("live", "3 4 9 10 12 13 14 19", 0), ("feature", "1 2", 1)])
+def test_plugin_descriptor_loads_like_the_reference_host(name, kinds, nfeat):
+  """ekf_get() / struct EKF / self-registration (rednose/helpers/ekf.h:14-42, ekf_load.cc:22-39) of a generated library,
+  through a host program written like the reference's loader.  No device needed: only the descriptor is read."""
+  from examples import ensure_generated
+  gen = ensure_generated([name])
+  out = subprocess.run([_build_plugin_host(), gen, name], check=True, capture_output=True, text=True).stdout.strip().split("\n")
+  assert out[0] == f"name {name} kinds {kinds} feature_kinds {nfeat} registered 1 same 1", out
+  assert out[1].startswith("complete 1"), out
+
+
+@pytest.mark.gpu
+def test_plugin_known_answers_through_descriptor(tmp_path):
+  """The calls EKFSym makes (ekf->predict, ekf->updates.at(kind)) over /root/reference/examples/test_kinematic_kf.py's stream."""
+  from examples import ensure_generated
+  gen = ensure_generated(["kinematic"])
+  g = golden("kinematic_stream.npz")
+  stream = tmp_path / "stream.txt"
+  with open(stream, "w", encoding="utf-8") as f:
+    for t, z in zip(g["ts"], g["zs"]):
+      f.write(f"{float(t)!r} {float(z)!r}\n")
+  out = subprocess.run([_build_plugin_host(), gen, "kinematic", str(stream)], check=True, capture_output=True, text=True).stdout.strip().split("\n")
+  v = out[-1].split()
+  assert v[0] == "steps" and v[1] == "500"
+  got = (float(v[3]), float(v[6]), float(v[4]), float(v[7]))
+  for a, want in zip(got, g["literals"]):
+    assert round(abs(a - want), 7) == 0

@@ -34,6 +34,10 @@ def main():
     steps[4](z[4].clone(), 0.01)
   torch.cuda.synchronize()
   buf = (ctypes.c_ulonglong * (256 * 64 * 2))()
+  import re
+  with open(os.path.join(gen, "live.hip"), encoding="utf-8") as fh:
+    ft = int(re.search(r"constexpr int FT2 = (\d+);", fh.read()).group(1))
+  ngroups = ft // 2
   for kind, dt in ((4, 0.01), (10, 0.0), (12, 0.0), (4, 0.01)):
     zz = z[kind].clone()
     torch.cuda.synchronize()
@@ -41,7 +45,7 @@ def main():
     torch.cuda.synchronize()
     assert tl(ctypes.cast(buf, ctypes.c_void_p)) == 0
     a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 64, 2).astype(np.float64)
-    nb = min(256, (n + 15) // 16)
+    nb = min(256, (n + ft - 1) // ft)
     a = a[:nb]
     wall = a[:, :, 1] / 100.0          # microseconds
     cyc = a[:, :, 0]
@@ -50,7 +54,7 @@ def main():
     names = {0: "start", 1: "x/z landed", 2: "phase 1 done", 3: "phase 2 done", 63: "end"}
     print(f"--- kind {kind} dt {dt}: {nb} workgroups; start spread {t0.max() - t0.min():.2f} us; "
           f"clock {(cyc[:, 63] - cyc[:, 0]).mean() / max(1e-9, (wall[:, 63] - wall[:, 0]).mean()):.0f} cycles/us")
-    order = [0, 1, 2] + [4 + i for i in range(4 * 8)] + [3, 63]
+    order = [0, 1, 2] + [4 + i for i in range(4 * ngroups)] + [3, 63]
     prev = 0.0
     for idx in order:
       v = rel[:, idx]
@@ -63,7 +67,52 @@ def main():
       print(f"  {nm:28s} {m:8.2f} us  (+{m - prev:6.2f})   min {v.min():7.2f} max {v.max():7.2f}")
       prev = m
     print(f"  last workgroup ends {(wall[:, 63].max() - t0.min()):.2f} us after the first one starts")
+    # every workgroup's first tile: start / end on the 100 MHz clock
+    bb = (ctypes.c_ulonglong * (4096 * 2))()
+    assert getattr(f._lib, "live_debug_blocks")(ctypes.cast(bb, ctypes.c_void_p)) == 0
+    b = np.frombuffer(bb, dtype=np.uint64).reshape(4096, 2).astype(np.float64) / 100.0
+    nblk = min(4096, (n + ft - 1) // ft)
+    b = b[:nblk]
+    b0 = b[:, 0].min()
+    st, en = b[:, 0] - b0, b[:, 1] - b0
+    print(f"  all {nblk} workgroups: starts {np.percentile(st, [0, 50, 90, 100]).round(2)} us, ends {np.percentile(en, [0, 50, 90, 100]).round(2)} us, "
+          f"duration {np.percentile(en - st, [0, 50, 100]).round(2)} us")
+
+
+def rts():
+  """Phase timeline of one backward step of the smoother (k_rts_group), averaged over the first 256 workgroups."""
+  import torch
+  from examples import ensure_generated, GENERATED_DIR
+  from examples.live_kf import LiveKalman as L
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  n, T = 16384, 40
+  gen = ensure_generated(["live"], folder=GENERATED_DIR)
+  f = BatchedEKF(gen, "live", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22, batch=n, quaternion_idxs=[3])
+  g = torch.Generator(device="cuda").manual_seed(0)
+  tx = torch.as_tensor(L.initial_x, device="cuda").repeat(T, n, 1).contiguous()
+  A = torch.randn((n, 22, 22), dtype=torch.float64, device="cuda", generator=g) * 0.01
+  P = torch.diag(torch.as_tensor(L.initial_P_diag, device="cuda")) * 1e-2 + A @ A.transpose(1, 2)
+  tP = P.repeat(T, 1, 1, 1).contiguous()
+  ts = np.arange(T) * 0.01
+  for _ in range(2):
+    f.rts_smooth(tx, tP, ts)
+  torch.cuda.synchronize()
+  buf = (ctypes.c_ulonglong * (256 * 16))()
+  assert getattr(f._lib, "live_debug_rts_timeline")(ctypes.cast(buf, ctypes.c_void_p)) == 0
+  a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 16).astype(np.float64) / 100.0
+  rel = a[:, :10] - a[:, :1]
+  names = ["step start", "x landed", "scalars (f, F) done", "predict done (B = Pk1_k)", "difference / output issued", "Cholesky done",
+           "solves done", "state update done", "T = Ck Dm done", "Pk_n done (step end)"]
+  print("--- smoother, one backward step (us after the step's start; 2 wavefronts per SIMD)")
+  prev = 0.0
+  for i, nm in enumerate(names):
+    m = rel[:, i].mean()
+    print(f"  {nm:30s} {m:8.2f} us (+{m - prev:6.2f})  min {rel[:, i].min():7.2f} max {rel[:, i].max():7.2f}")
+    prev = m
 
 
 if __name__ == "__main__":
+  if len(sys.argv) > 1 and sys.argv[1] == "rts":
+    rts()
+    sys.exit(0)
   main()
