@@ -404,6 +404,7 @@ class BatchedEKF:
     self._torch = torch
     self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
     self.name = name
+    self.folder = folder
     self.batch = int(batch)
     self.logger = logger
     self.maha_test_kinds = list(maha_test_kinds)

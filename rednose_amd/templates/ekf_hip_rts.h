@@ -387,6 +387,11 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
       const bool first = (k == T - 2);
       // ---- A. filtered pair of step k: row c of Pk_k to registers, xk_k to LDS --------------------------------------
       const double* Pk = Pf + ((k * n + fil) * EE + (int64_t)cc * E);
+      // The row this lane will need at the NEXT (older) step is touched now (two cache lines of it): by then it sits in L2
+      // instead of costing a full HBM round trip in front of the predict.  The values are not used; they stay live until the
+      // end of the step only so that the loads are not dropped.
+      const double* Pnext = Pf + (((k > 0 ? k - 1 : 0) * n + fil) * EE + (int64_t)cc * E);
+      const double touch0 = *(const volatile double*)Pnext, touch1 = *(const volatile double*)(Pnext + (EM > 16 ? 16 : EM - 1));
       double y[EM];
       RN_RTS_STAMP(0);
       {
@@ -623,6 +628,7 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
         }
       }
       wave_lds_sync();
+      asm volatile("" :: "v"(touch0), "v"(touch1));
       RN_RTS_STAMP(9);
     }
     // ---- the oldest smoothed estimate goes out un-normalised (ekf_sym.py:665-667 never reaches it) --------------------------

