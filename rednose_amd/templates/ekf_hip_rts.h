@@ -563,68 +563,109 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
         for (int i = 0; i < D; i++) sxn[i] = (i < DM) ? xnew[i] : xa[i];       // xk_n: becomes xk1_n of the next (older) step
       }
       RN_RTS_STAMP(7);
-      // ---- H. covariance: Pk_n = Pk_k + (Ck Dm) Ck^T, row c ----------------------------------------------------------------
-      // Rolled loops over the inner index: the multiplier of each step (an entry of this lane's row of Ck, then of T) comes
-      // from LDS, where the lane parked that row, so no register array is indexed by the loop variable; the accumulator row is
-      // the only array live.  Ck^T replaces the factor in B (column c written by lane c), T replaces the difference matrix.
-      wave_lds_sync();           // every lane is done with the factor
+      // ---- H. covariance: Pk_n = Pk_k + (Ck Dm) Ck^T on the matrix cores -----------------------------------------------------
+      // The two EM^3 products are the only GEMM-shaped work of the whole package, and in the row-per-lane form above they
+      // were bound by OPERAND DELIVERY, not arithmetic: every FMA needs one broadcast double from LDS (2 LDS cycles per 4 VALU
+      // cycles and wavefront, four SIMDs sharing one LDS: measured 80 % LDS-busy, 4.5 us per product and wavefront).
+      // v_mfma_f64_16x16x4 has the same peak rate as the vector unit on CDNA4 but distributes its operands itself: one
+      // ds_read_b64 per lane feeds a 16 x 16 x 4 block (LDS traffic / 10), all 64 lanes work on one filter (no idle lanes for
+      // EM < 32), and the accumulators never leave registers.  Operand / result layout measured on the device
+      // (tools/mfma_probe.hip): lane l supplies A[l % 16][l / 16] and B[l / 16][l % 16]; register r of lane l holds
+      // D[4 r + l / 16][l % 16].  Tiles beyond EM are fed zeros (k) or simply not stored (i, j).
+      wave_lds_sync();           // every lane is done with the factor: its buffer takes Ck^T (column c written by lane c)
       if (on) {
 #pragma unroll
         for (int j = 0; j < EM; j++) B[j * EM + c] = y[j];
       }
       wave_lds_sync();
-      {
-        double trow[EM];
-#pragma unroll
-        for (int m = 0; m < EM; m++) trow[m] = 0.0;
-        // operands of step j + 1 are requested before the FMAs of step j (register double buffer)
-        double cur[EM], nxt[EM], ckc, ckn;
-#pragma unroll
-        for (int m = 0; m < EM; m++) cur[m] = C[m];
-        ckc = B[cc];
-#pragma unroll 2
-        for (int j = 0; j < EM; j++) {
-          const int jn = (j + 1 < EM) ? j + 1 : j;
-#pragma unroll
-          for (int m = 0; m < EM; m++) nxt[m] = C[jn * EM + m];                          // row j + 1 of Dm: contiguous broadcast
-          ckn = B[jn * EM + cc];                                                         // Ck[c][j + 1]
-#pragma unroll
-          for (int m = 0; m < EM; m++) trow[m] = fma(ckc, cur[m], trow[m]);
-#pragma unroll
-          for (int m = 0; m < EM; m++) cur[m] = nxt[m];
-          ckc = ckn;
-        }
-        wave_lds_sync();         // every lane has read all of Dm: its buffer takes T (row c written by lane c)
-        if (on) {
-#pragma unroll
-          for (int m = 0; m < EM; m++) C[c * EM + m] = trow[m];
-        }
-      }
       RN_RTS_STAMP(8);
       {
-        double nn[EM];
-        rts_load_row<E, EM>(Pk, nn);          // row c of Pk_k again (L2 hit): cheaper than 2 EM registers held through the step
-        wave_lds_sync();
-        double cur[EM], nxt[EM], tc, tn;
+        constexpr int TI = (EM + 15) / 16, KS = (EM + 3) / 4;
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        const int li = lane & 15, lk = lane >> 4;
+        for (int fg = 0; fg < cnt; fg++) {
+          double* Bf = s_B + fg * MMP;          // X = Ck^T of filter fg:  X[k][i] = Ck[i][k]
+          double* Cf = s_C + fg * MMP;          // Dm of filter fg, then T, then Pk_n
+          v4d acc[TI][TI];
+          // ---- T = Ck Dm --------------------------------------------------------------------------------------------------
 #pragma unroll
-        for (int m = 0; m < EM; m++) cur[m] = B[m];
-        tc = C[cc * EM];
-#pragma unroll 2
-        for (int j = 0; j < EM; j++) {
-          const int jn = (j + 1 < EM) ? j + 1 : j;
+          for (int it = 0; it < TI; it++) {
 #pragma unroll
-          for (int m = 0; m < EM; m++) nxt[m] = B[jn * EM + m];                         // row j + 1 of Ck^T: contiguous broadcast
-          tn = C[cc * EM + jn];
+            for (int jt = 0; jt < TI; jt++) acc[it][jt] = v4d{0.0, 0.0, 0.0, 0.0};
+          }
 #pragma unroll
-          for (int m = 0; m < EM; m++) nn[m] = fma(tc, cur[m], nn[m]);
+          for (int ks = 0; ks < KS; ks++) {
+            const int kk = 4 * ks + lk;
+            double a[TI], b[TI];
 #pragma unroll
-          for (int m = 0; m < EM; m++) cur[m] = nxt[m];
-          tc = tn;
-        }
-        // row c of Pk_n = Pk1_n of the next (older) step parks in this lane's own row of C (T's row c is consumed)
-        if (on) {
+            for (int t = 0; t < TI; t++) {
+              const int ij = 16 * t + li;
+              const bool ok = kk < EM && ij < EM;
+              const int idx = ok ? kk * EM + ij : 0;
+              a[t] = ok ? Bf[idx] : 0.0;            // Ck[i][k]
+              b[t] = ok ? Cf[idx] : 0.0;            // Dm[k][j]
+            }
 #pragma unroll
-          for (int m = 0; m < EM; m++) C[c * EM + m] = nn[m];
+            for (int it = 0; it < TI; it++) {
+#pragma unroll
+              for (int jt = 0; jt < TI; jt++) acc[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[it], b[jt], acc[it][jt], 0, 0, 0);
+            }
+          }
+          wave_lds_sync();         // all of Dm has been read: its buffer takes T
+#pragma unroll
+          for (int it = 0; it < TI; it++) {
+#pragma unroll
+            for (int jt = 0; jt < TI; jt++) {
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                const int i = 16 * it + 4 * r + lk, j = 16 * jt + li;
+                if (i < EM && j < EM) Cf[i * EM + j] = acc[it][jt][r];
+              }
+            }
+          }
+          wave_lds_sync();
+          // ---- Pk_n = Pk_k + T Ck^T: the accumulators start from Pk_k (L2 hit: this step read it a few microseconds ago) -------
+          const double* Pkf = Pf + (k * n + base + fg) * EE;
+#pragma unroll
+          for (int it = 0; it < TI; it++) {
+#pragma unroll
+            for (int jt = 0; jt < TI; jt++) {
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                const int i = 16 * it + 4 * r + lk, j = 16 * jt + li;
+                acc[it][jt][r] = (i < EM && j < EM) ? Pkf[i * E + j] : 0.0;
+              }
+            }
+          }
+#pragma unroll
+          for (int ks = 0; ks < KS; ks++) {
+            const int kk = 4 * ks + lk;
+            double a[TI], b[TI];
+#pragma unroll
+            for (int t = 0; t < TI; t++) {
+              const int ij = 16 * t + li;
+              const bool ok = kk < EM && ij < EM;
+              a[t] = ok ? Cf[ij * EM + kk] : 0.0;   // T[i][k]
+              b[t] = ok ? Bf[kk * EM + ij] : 0.0;   // X[k][j] = Ck[j][k]
+            }
+#pragma unroll
+            for (int it = 0; it < TI; it++) {
+#pragma unroll
+              for (int jt = 0; jt < TI; jt++) acc[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[it], b[jt], acc[it][jt], 0, 0, 0);
+            }
+          }
+          wave_lds_sync();         // all of T has been read: Pk_n (= Pk1_n of the next, older step) parks in its buffer
+#pragma unroll
+          for (int it = 0; it < TI; it++) {
+#pragma unroll
+            for (int jt = 0; jt < TI; jt++) {
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                const int i = 16 * it + 4 * r + lk, j = 16 * jt + li;
+                if (i < EM && j < EM) Cf[i * EM + j] = acc[it][jt][r];
+              }
+            }
+          }
         }
       }
       wave_lds_sync();
