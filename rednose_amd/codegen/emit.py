@@ -180,8 +180,8 @@ def _emit(spec):
   static constexpr int OFF_DT = SLOT_OFF_DT;
   static __device__ __forceinline__ void scal(const double* xin, double dt, double* sl, int norm) {{ scal_predict(xin, dt, sl, norm); }}
   static constexpr int WAVES = {2 if M <= 22 else 1};       // wavefronts per SIMD the register budget is set for (see k_rts_group)
-  static __device__ __forceinline__ void mat_predict(const double (&row)[{M}], double* sB, const double* gQ, const double* sl, int cc, bool act,
-                                                     double (&y)[{M}]) {{ mat_predict_rts(row, sB, gQ, sl, cc, act, y); }}""" if group_rts else ""
+  static __device__ __forceinline__ void mat_predict(const double (&row)[{M}], double* sB, const double* gQc, const double* sl, int cc, bool act,
+                                                     double (&y)[{M}]) {{ mat_predict_rts(row, sB, gQc, sl, cc, act, y); }}""" if group_rts else ""
     src.append(f"""
 // adapter handed to the hand-written smoother kernels (templates/ekf_hip_rts.h)
 struct RtsModel {{

@@ -372,9 +372,9 @@ def device_functions(spec):
   b += ["if (act) {", "#pragma unroll", f"  for (int i = 0; i < {M}; i++) sB[cc * {M} + i] = y[i];", "}", "rn::wave_lds_sync();",
         f"double a[{M}];", "#pragma unroll", f"for (int k = 0; k < {M}; k++) a[k] = sB[k * {M} + cc];", "rn::wave_lds_sync();"]
   for i in range(M):
-    b.append(f"{{ const double v = {sum_terms(term(cf, f'a[{kk}]') for kk, cf in Fs.row_nz(i) if kk < M)} + dt*gQ[{i * E} + cc]; if (act) sB[{i * M} + cc] = v; }}")
+    b.append(f"{{ const double v = {sum_terms(term(cf, f'a[{kk}]') for kk, cf in Fs.row_nz(i) if kk < M)} + dt*gQc[{i * E}]; if (act) sB[{i * M} + cc] = v; }}")
   b += ["rn::wave_lds_sync();"]
-  out.append("\n".join([f"__device__ __forceinline__ void mat_predict_rts(const double (&row)[{M}], double* sB, const double* __restrict__ gQ, "
+  out.append("\n".join([f"__device__ __forceinline__ void mat_predict_rts(const double (&row)[{M}], double* sB, const double* __restrict__ gQc, "
                         f"const double* sl, const int cc, const bool act, double (&y)[{M}]) {{"] + _ind(b) + ["}"]))
 
   # ---- phase 2: update, matrix part ----------------------------------------------------------------------

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
 //
 // Model: constants D, E, DM, EM, SLOT, OFF_X, OFF_DT and the functions
 //   scal(xin, dt, sl, norm)                      one filter's f / F non-zeros -> slot (x' = f(x) [normalised] at sl[OFF_X..])
-//   mat_predict(row, sB, gQ, sl, cc, act, y)     row c of Pk_k -> y = column c of M = F Pk_k^T, sB <- Pk1_k (EM x EM)
+//   mat_predict(row, sB, gQc, sl, cc, act, y)    row c of Pk_k, gQc = column cc of Q -> y = column c of M = F Pk_k^T, sB <- Pk1_k (EM x EM)
 //   inv_err, err, normalize                      as for k_rts
 // Forces `v` to exist in registers at this point of the instruction stream (an empty volatile asm that "modifies" it):
 // arithmetic producing v cannot sink below, arithmetic consuming it cannot rise above.  No instruction is emitted.
@@ -308,6 +308,142 @@ __device__ __forceinline__ void rts_store_row(double* __restrict__ p, const doub
   } else {
 #pragma unroll
     for (int j = 0; j < EM; j++) p[j] = r[j];
+  }
+}
+
+// The two products of one filter on the matrix cores (see phase H of k_rts_group): in  Bf = X = Ck^T (X[k][i] = Ck[i][k]),
+// Cf = Dm;  out Cf = Pk_n = Pk_k + (Ck Dm) Ck^T;  Bf is scratch afterwards.  All 64 lanes of the wavefront work on this filter.
+// The result is produced in blocks of JB column tiles (JB = 2: at most 2 TI accumulator tiles live, 16 TI registers):
+//   T[:, jb] = Ck Dm[:, jb] depends on no other column of Dm, so it overwrites Dm[:, jb] in place;
+//   Pk_n[:, jb] = Pk_k[:, jb] + T X[:, jb] needs all of T but only X[:, jb], so it overwrites X[:, jb]; with more than one block
+//   the result is then moved from Bf to Cf (with one block it goes to Cf directly, all of T having been read).
+template <int E, int EM>
+__device__ __forceinline__ void rts_products(double* Bf, double* Cf, const double* __restrict__ Pkf, const int lane) {
+  constexpr int TI = (EM + 15) / 16, KS = (EM + 3) / 4, JB = TI <= 2 ? TI : 2, NB = (TI + JB - 1) / JB;
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  const int li = lane & 15, lk = lane >> 4;
+  // Pk_k in the result layout (the start value of the second product): with a single block it is requested now, so that its L2
+  // latency passes under the first product
+  v4d pk[NB == 1 ? TI : 1][NB == 1 ? JB : 1];
+  if constexpr (NB == 1) {
+#pragma unroll
+    for (int it = 0; it < TI; it++) {
+#pragma unroll
+      for (int jt = 0; jt < JB; jt++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = 16 * it + 4 * r + lk, j = 16 * jt + li;
+          pk[it][jt][r] = (i < EM && j < EM) ? Pkf[i * E + j] : 0.0;
+        }
+      }
+    }
+  }
+  // ---- T = Ck Dm ------------------------------------------------------------------------------------------------------------
+  static_for<NB>([&](auto JBI) {
+    constexpr int j0 = decltype(JBI)::value * JB;
+    constexpr int nj = (TI - j0) < JB ? (TI - j0) : JB;
+    v4d acc[TI][JB];
+#pragma unroll
+    for (int it = 0; it < TI; it++) {
+#pragma unroll
+      for (int jt = 0; jt < nj; jt++) acc[it][jt] = v4d{0.0, 0.0, 0.0, 0.0};
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      const int kk = 4 * ks + lk;
+      double a[TI], b[JB];
+#pragma unroll
+      for (int t = 0; t < TI; t++) {
+        const int i = 16 * t + li;
+        const bool ok = kk < EM && i < EM;
+        a[t] = ok ? Bf[ok ? kk * EM + i : 0] : 0.0;              // Ck[i][k]
+      }
+#pragma unroll
+      for (int u = 0; u < nj; u++) {
+        const int j = 16 * (j0 + u) + li;
+        const bool ok = kk < EM && j < EM;
+        b[u] = ok ? Cf[ok ? kk * EM + j : 0] : 0.0;              // Dm[k][j]
+      }
+#pragma unroll
+      for (int it = 0; it < TI; it++) {
+#pragma unroll
+        for (int jt = 0; jt < nj; jt++) acc[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[it], b[jt], acc[it][jt], 0, 0, 0);
+      }
+    }
+    wave_lds_sync();           // these columns of Dm have been read: they take the same columns of T
+#pragma unroll
+    for (int it = 0; it < TI; it++) {
+#pragma unroll
+      for (int jt = 0; jt < nj; jt++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = 16 * it + 4 * r + lk, j = 16 * (j0 + jt) + li;
+          if (i < EM && j < EM) Cf[i * EM + j] = acc[it][jt][r];
+        }
+      }
+    }
+    wave_lds_sync();
+  });
+  // ---- Pk_n = Pk_k + T Ck^T ---------------------------------------------------------------------------------------------------
+  static_for<NB>([&](auto JBI) {
+    constexpr int j0 = decltype(JBI)::value * JB;
+    constexpr int nj = (TI - j0) < JB ? (TI - j0) : JB;
+    v4d acc[TI][JB];
+#pragma unroll
+    for (int it = 0; it < TI; it++) {
+#pragma unroll
+      for (int jt = 0; jt < nj; jt++) {
+        if constexpr (NB == 1) {
+          acc[it][jt] = pk[it][jt];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int i = 16 * it + 4 * r + lk, j = 16 * (j0 + jt) + li;
+            acc[it][jt][r] = (i < EM && j < EM) ? Pkf[i * E + j] : 0.0;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      const int kk = 4 * ks + lk;
+      double a[TI], b[JB];
+#pragma unroll
+      for (int t = 0; t < TI; t++) {
+        const int i = 16 * t + li;
+        const bool ok = kk < EM && i < EM;
+        a[t] = ok ? Cf[ok ? i * EM + kk : 0] : 0.0;              // T[i][k]
+      }
+#pragma unroll
+      for (int u = 0; u < nj; u++) {
+        const int j = 16 * (j0 + u) + li;
+        const bool ok = kk < EM && j < EM;
+        b[u] = ok ? Bf[ok ? kk * EM + j : 0] : 0.0;              // X[k][j] = Ck[j][k]
+      }
+#pragma unroll
+      for (int it = 0; it < TI; it++) {
+#pragma unroll
+        for (int jt = 0; jt < nj; jt++) acc[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[it], b[jt], acc[it][jt], 0, 0, 0);
+      }
+    }
+    wave_lds_sync();           // one block: all of T has been read; several: these columns of X have been read
+    double* dst = NB == 1 ? Cf : Bf;
+#pragma unroll
+    for (int it = 0; it < TI; it++) {
+#pragma unroll
+      for (int jt = 0; jt < nj; jt++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = 16 * it + 4 * r + lk, j = 16 * (j0 + jt) + li;
+          if (i < EM && j < EM) dst[i * EM + j] = acc[it][jt][r];
+        }
+      }
+    }
+    wave_lds_sync();
+  });
+  if constexpr (NB > 1) {
+    for (int i = lane; i < EM * EM; i += 64) Cf[i] = Bf[i];
+    wave_lds_sync();
   }
 }
 
@@ -387,26 +523,28 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
       const bool first = (k == T - 2);
       // ---- A. filtered pair of step k: row c of Pk_k to registers, xk_k to LDS --------------------------------------
       const double* Pk = Pf + ((k * n + fil) * EE + (int64_t)cc * E);
-      // The row this lane will need at the NEXT (older) step is touched now (two cache lines of it): by then it sits in L2
-      // instead of costing a full HBM round trip in front of the predict.  The values are not used; they stay live until the
-      // end of the step only so that the loads are not dropped.
-      const double* Pnext = Pf + (((k > 0 ? k - 1 : 0) * n + fil) * EE + (int64_t)cc * E);
-      const double touch0 = *(const volatile double*)Pnext, touch1 = *(const volatile double*)(Pnext + (EM > 16 ? 16 : EM - 1));
       double y[EM];
       RN_RTS_STAMP(0);
       {
+        // row c of Pk_k is requested first: its HBM / L2 latency passes under the scalar phase, which
+        // keeps one lane per filter busy for about a microsecond (up to 32 error states; beyond, the registers are not there)
+        double prow[EM];
+        if constexpr (EM <= 32) rts_load_row<E, EM>(Pk, prow);
         for (int i = c; i < D; i += GL) sxk[i] = xf[(k * n + fil) * D + i];
         const double dt = ts[k + 1] - ts[k];
         wave_lds_sync();
-        // ---- B. f(xk_k), non-zeros of Fk: once per filter -> slot (no matrix row is live in registers meanwhile) ---------
+        // ---- B. f(xk_k), non-zeros of Fk: once per filter -> slot ----------------------------------------------------------
         RN_RTS_STAMP(1);
         if (lead) Model::scal(sxk, dt, sl, norm_quats & 1);
         wave_lds_sync();
         RN_RTS_STAMP(2);
         // ---- C. predicted pair of step k+1 (main block): B <- Pk1_k, y <- column c of M = Fk Pk_k^T -----------------------
-        double prow[EM];
-        rts_load_row<E, EM>(Pk, prow);
-        Model::mat_predict(prow, B, gQ, sl, cc, on, y);
+        if constexpr (EM > 32) rts_load_row<E, EM>(Pk, prow);
+        // column cc of Q behind an opaque zero: without it hipcc hoists one 64-bit address per entry out of the step loop
+        // (2 EM registers for the whole kernel; beyond the immediate-offset range they cannot share a base) and spills them
+        int qz = 0;
+        asm volatile("" : "+v"(qz));
+        Model::mat_predict(prow, B, gQ + cc + qz, sl, cc, on, y);
       }
       // ---- D. recursion start / difference matrix / smoothed estimate of step k+1 leaves ------------------------------------
       RN_RTS_STAMP(3);
@@ -489,7 +627,27 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
       // 1 050 spilled registers, a scratch round trip per operand.  Neither costs an instruction.
       // The coefficients of pivot m + 1 (and its reciprocal pivot) are requested before the FMAs of pivot m, so their LDS
       // latency overlaps that arithmetic instead of being exposed once per pivot.
-      {
+      if constexpr (EM > 32) {
+        // one wavefront per SIMD and four 2 EM-register vectors would not fit next to the rest: plain loads per pivot
+        static_for<EM>([&](auto Mi) {
+          constexpr int m = decltype(Mi)::value;
+          y[m] *= sil[m];
+#pragma unroll
+          for (int i = m + 1; i < EM; i++) y[i] = fma(-B[i * EM + m], y[m], y[i]);
+#pragma unroll
+          for (int i = m + 1; i < EM; i++) pin(y[i]);
+          wave_lds_sync();
+        });
+        static_for<EM>([&](auto Mi) {
+          constexpr int m = EM - 1 - decltype(Mi)::value;
+          y[m] *= sil[m];
+#pragma unroll
+          for (int i = 0; i < m; i++) y[i] = fma(-B[m * EM + i], y[m], y[i]);
+#pragma unroll
+          for (int i = 0; i < m; i++) pin(y[i]);
+          wave_lds_sync();
+        });
+      } else {
         double cur[EM], nxt[EM], ilc, iln = 0.0;
 #pragma unroll
         for (int i = 1; i < EM; i++) cur[i] = B[i * EM + 0];
@@ -579,97 +737,9 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
       }
       wave_lds_sync();
       RN_RTS_STAMP(8);
-      {
-        constexpr int TI = (EM + 15) / 16, KS = (EM + 3) / 4;
-        typedef double v4d __attribute__((ext_vector_type(4)));
-        const int li = lane & 15, lk = lane >> 4;
-        for (int fg = 0; fg < cnt; fg++) {
-          double* Bf = s_B + fg * MMP;          // X = Ck^T of filter fg:  X[k][i] = Ck[i][k]
-          double* Cf = s_C + fg * MMP;          // Dm of filter fg, then T, then Pk_n
-          v4d acc[TI][TI];
-          // ---- T = Ck Dm --------------------------------------------------------------------------------------------------
-#pragma unroll
-          for (int it = 0; it < TI; it++) {
-#pragma unroll
-            for (int jt = 0; jt < TI; jt++) acc[it][jt] = v4d{0.0, 0.0, 0.0, 0.0};
-          }
-#pragma unroll
-          for (int ks = 0; ks < KS; ks++) {
-            const int kk = 4 * ks + lk;
-            double a[TI], b[TI];
-#pragma unroll
-            for (int t = 0; t < TI; t++) {
-              const int ij = 16 * t + li;
-              const bool ok = kk < EM && ij < EM;
-              const int idx = ok ? kk * EM + ij : 0;
-              a[t] = ok ? Bf[idx] : 0.0;            // Ck[i][k]
-              b[t] = ok ? Cf[idx] : 0.0;            // Dm[k][j]
-            }
-#pragma unroll
-            for (int it = 0; it < TI; it++) {
-#pragma unroll
-              for (int jt = 0; jt < TI; jt++) acc[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[it], b[jt], acc[it][jt], 0, 0, 0);
-            }
-          }
-          wave_lds_sync();         // all of Dm has been read: its buffer takes T
-#pragma unroll
-          for (int it = 0; it < TI; it++) {
-#pragma unroll
-            for (int jt = 0; jt < TI; jt++) {
-#pragma unroll
-              for (int r = 0; r < 4; r++) {
-                const int i = 16 * it + 4 * r + lk, j = 16 * jt + li;
-                if (i < EM && j < EM) Cf[i * EM + j] = acc[it][jt][r];
-              }
-            }
-          }
-          wave_lds_sync();
-          // ---- Pk_n = Pk_k + T Ck^T: the accumulators start from Pk_k (L2 hit: this step read it a few microseconds ago) -------
-          const double* Pkf = Pf + (k * n + base + fg) * EE;
-#pragma unroll
-          for (int it = 0; it < TI; it++) {
-#pragma unroll
-            for (int jt = 0; jt < TI; jt++) {
-#pragma unroll
-              for (int r = 0; r < 4; r++) {
-                const int i = 16 * it + 4 * r + lk, j = 16 * jt + li;
-                acc[it][jt][r] = (i < EM && j < EM) ? Pkf[i * E + j] : 0.0;
-              }
-            }
-          }
-#pragma unroll
-          for (int ks = 0; ks < KS; ks++) {
-            const int kk = 4 * ks + lk;
-            double a[TI], b[TI];
-#pragma unroll
-            for (int t = 0; t < TI; t++) {
-              const int ij = 16 * t + li;
-              const bool ok = kk < EM && ij < EM;
-              a[t] = ok ? Cf[ij * EM + kk] : 0.0;   // T[i][k]
-              b[t] = ok ? Bf[kk * EM + ij] : 0.0;   // X[k][j] = Ck[j][k]
-            }
-#pragma unroll
-            for (int it = 0; it < TI; it++) {
-#pragma unroll
-              for (int jt = 0; jt < TI; jt++) acc[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[it], b[jt], acc[it][jt], 0, 0, 0);
-            }
-          }
-          wave_lds_sync();         // all of T has been read: Pk_n (= Pk1_n of the next, older step) parks in its buffer
-#pragma unroll
-          for (int it = 0; it < TI; it++) {
-#pragma unroll
-            for (int jt = 0; jt < TI; jt++) {
-#pragma unroll
-              for (int r = 0; r < 4; r++) {
-                const int i = 16 * it + 4 * r + lk, j = 16 * jt + li;
-                if (i < EM && j < EM) Cf[i * EM + j] = acc[it][jt][r];
-              }
-            }
-          }
-        }
-      }
+      for (int fg = 0; fg < cnt; fg++)
+        rts_products<E, EM>(s_B + fg * MMP, s_C + fg * MMP, Pf + (k * n + base + fg) * EE, lane);
       wave_lds_sync();
-      asm volatile("" :: "v"(touch0), "v"(touch1));
       RN_RTS_STAMP(9);
     }
     // ---- the oldest smoothed estimate goes out un-normalised (ekf_sym.py:665-667 never reaches it) --------------------------
