@@ -5,9 +5,13 @@
 // counterpart above the C ABI of a generated rednose_amd library (include/rednose_amd_filter.h):
 //   * library discovery as in ekf_load.cc:22-39 -- dlopen("<dir>/lib<name>.so"), symbols looked up by name;
 //   * same vocabulary and semantics: init_state (:45-51), state/covs (:53-59), get/set_filter_time (:61-67),
-//     predict (:196-209: first call adopts t, dt >= 0 required), predict_and_update_batch (:83-117 without the
-//     rewind ring: late observations are rejected, false is returned), quaternion renormalisation after predict
-//     and update when quaternion_idxs were given to gen_code (:207,213 -- done inside the kernels);
+//     predict (:196-209: first call adopts t, dt >= 0 required), predict_and_update_batch (:83-117) including the
+//     late-observation path: with rewind_to_keep > 0 (the reference keeps REWIND_TO_KEEP = 512, ekf_sym.h:18) a ring of
+//     checkpoints (filter time, x, P, the observation) lives in HBM; an observation older than the filter time rewinds
+//     the whole batch to the last checkpoint at or before it (:119-140), is applied, and the overtaken observations are
+//     replayed (:111-116); older than max_rewind_age or than the ring -> false (:87-94).  Quaternion renormalisation
+//     after predict and update when quaternion_idxs were given to gen_code (:207,213 -- done inside the kernels);
+//     set_global (:79-81) and get_extra_routine (:221-223);
 //   * no Eigen: state lives in HBM as x (N, D), P (N, E, E) row-major fp64; z is a DEVICE pointer (N, Z) that the
 //     kernel overwrites with the residual y; R is a host Z x Z matrix shared by the batch.
 // Errors throw std::runtime_error carrying {name}_last_error_string(); nothing aborts.
@@ -17,7 +21,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <cmath>
+#include <deque>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -29,8 +35,9 @@ class EKFSymBatch {
  public:
   EKFSymBatch(const std::string& directory, const std::string& name, const std::vector<double>& Q,
               const std::vector<double>& x_initial, const std::vector<double>& P_initial, int64_t batch,
-              bool normalize_quaternions = false, hipStream_t stream = nullptr)
-      : name_(name), n_(batch), norm_quats_(normalize_quaternions ? 1 : 0), stream_(stream) {
+              bool normalize_quaternions = false, hipStream_t stream = nullptr, int rewind_to_keep = 0, double max_rewind_age = 1.0)
+      : name_(name), n_(batch), norm_quats_(normalize_quaternions ? 1 : 0), stream_(stream), rewind_to_keep_(rewind_to_keep),
+        max_rewind_age_(max_rewind_age) {
     const std::string path = directory + "/lib" + name + ".so";
     handle_ = dlopen(path.c_str(), RTLD_NOW);
     if (!handle_) throw std::runtime_error("rednose_amd: cannot load " + path + ": " + dlerror());
@@ -54,6 +61,8 @@ class EKFSymBatch {
   }
 
   ~EKFSymBatch() {
+    for (auto& c : ring_) release(c);
+    for (auto& c : spare_) release(c);
     (void)hipFree(x_);
     (void)hipFree(P_);
     (void)hipFree(Q_);
@@ -78,7 +87,24 @@ class EKFSymBatch {
     hip(hipMemcpy(x_, xs, sizeof(double) * n_ * D_, hipMemcpyHostToDevice), "copy x");
     hip(hipMemcpy(P_, Ps, sizeof(double) * n_ * E_ * E_, hipMemcpyHostToDevice), "copy P");
     filter_time_ = filter_time;
+    reset_rewind();
   }
+
+  // forget every checkpoint (EKFSym::reset_rewind, ekf_sym.cc:69-73 there)
+  void reset_rewind() {
+    for (auto& c : ring_) spare_.push_back(c);
+    ring_.clear();
+  }
+
+  // run-time model scalar of gen_code's global_vars (EKFSym::set_global, ekf_sym.cc:79-81): per LIBRARY, like the reference
+  void set_global(const std::string& var, double value) {
+    sym<void (*)(double)>("set_" + var)(value);
+    if (sym<int (*)()>("last_error")() != 0) check(1, ("set_" + var).c_str());
+  }
+
+  // extra routine by name (EKFSym::get_extra_routine, ekf_sym.cc:221-223): the host-pointer entry point {name}_{routine}
+  typedef void (*extra_routine_t)(double*, double*);
+  extra_routine_t get_extra_routine(const std::string& routine) const { return sym<extra_routine_t>(routine); }
 
   std::vector<double> state() const {
     std::vector<double> out((size_t)n_ * D_);
@@ -114,13 +140,19 @@ class EKFSymBatch {
   bool predict_and_update_batch(double t, int kind, double* z_dev, const double* R_host, uint8_t* flags_dev = nullptr,
                                 const double* ea_dev = nullptr, bool augment = false) {
     const int Z = zdim_.at(kind);
-    if (!std::isnan(filter_time_) && t < filter_time_) return false;
-    const double dt = advance(t);
-    hip(hipMemcpyAsync(R_, R_host, sizeof(double) * Z * Z, hipMemcpyHostToDevice, stream_), "copy R");
-    auto fn = sym<step_fn>("batch_predict_update_" + std::to_string(kind));
-    check(fn(x_, P_, Q_, nullptr, dt, z_dev, R_, 0, ea_dev, n_, norm_quats_, flags_dev, stream_), "batch_predict_update");
-    filter_time_ = t;
+    std::vector<Checkpoint> replay;
+    if (!std::isnan(filter_time_) && t < filter_time_) {
+      // late observation (ekf_sym.cc:87-94): too old for the ring or for max_rewind_age -> ignored
+      if (ring_.empty() || t < ring_.front().t || t < ring_.back().t - max_rewind_age_) return false;
+      if (augment) throw std::runtime_error("rednose_amd: augment with a rewind is not supported (the reference asserts the same)");
+      replay = rewind(t);
+    }
+    step(t, kind, Z, z_dev, R_host, flags_dev, ea_dev);
     if (augment) this->augment();
+    for (auto& c : replay) {             // fast-forward through the observations that were overtaken (ekf_sym.cc:111-116)
+      step(c.obs_t, c.kind, zdim_.at(c.kind), c.z, c.R.data(), nullptr, c.has_ea ? c.ea : nullptr);
+      spare_.push_back(c);
+    }
     return true;
   }
 
@@ -141,6 +173,72 @@ class EKFSymBatch {
   void synchronize() const { hip(hipStreamSynchronize(stream_), "synchronize"); }
 
  private:
+  // one entry of the rewind ring: the batch state AFTER an observation was applied, and that observation
+  struct Checkpoint {
+    double t = NAN;                    // filter time after the step
+    double *x = nullptr, *P = nullptr; // device copies of the batch state
+    double obs_t = NAN;
+    int kind = 0;
+    double* z = nullptr;               // device copy of the observation (the kernel overwrites the caller's with the residual)
+    double* ea = nullptr;              // device buffer for a copy of the extra arguments
+    bool has_ea = false;               // ... which this observation had
+    std::vector<double> R;             // Z x Z, host
+  };
+
+  void release(Checkpoint& c) {
+    (void)hipFree(c.x); (void)hipFree(c.P); (void)hipFree(c.z); (void)hipFree(c.ea);
+    c = Checkpoint();
+  }
+
+  Checkpoint slot() {
+    if (!spare_.empty()) { Checkpoint c = spare_.back(); spare_.pop_back(); return c; }
+    Checkpoint c;
+    hip(hipMalloc((void**)&c.x, sizeof(double) * n_ * D_), "hipMalloc ring x");
+    hip(hipMalloc((void**)&c.P, sizeof(double) * n_ * E_ * E_), "hipMalloc ring P");
+    hip(hipMalloc((void**)&c.z, sizeof(double) * n_ * 64), "hipMalloc ring z");
+    hip(hipMalloc((void**)&c.ea, sizeof(double) * n_ * 4), "hipMalloc ring ea");
+    return c;
+  }
+
+  // predict + update + checkpoint (EKFSym::predict_and_update_batch's inner part, ekf_sym.cc:158-194)
+  void step(double t, int kind, int Z, double* z_dev, const double* R_host, uint8_t* flags_dev, const double* ea_dev) {
+    Checkpoint c;
+    const bool keep = rewind_to_keep_ > 0;
+    if (keep) {
+      c = slot();
+      c.obs_t = t; c.kind = kind; c.R.assign(R_host, R_host + Z * Z);
+      hip(hipMemcpyAsync(c.z, z_dev, sizeof(double) * n_ * Z, hipMemcpyDeviceToDevice, stream_), "ring z");
+      const int ead = sym<int (*)(int)>("kind_eadim")(kind);
+      c.has_ea = ea_dev != nullptr && ead > 0;
+      if (c.has_ea) hip(hipMemcpyAsync(c.ea, ea_dev, sizeof(double) * n_ * ead, hipMemcpyDeviceToDevice, stream_), "ring ea");
+    }
+    const double dt = advance(t);
+    hip(hipMemcpyAsync(R_, R_host, sizeof(double) * Z * Z, hipMemcpyHostToDevice, stream_), "copy R");
+    auto fn = sym<step_fn>("batch_predict_update_" + std::to_string(kind));
+    check(fn(x_, P_, Q_, nullptr, dt, z_dev, R_, 0, ea_dev, n_, norm_quats_, flags_dev, stream_), "batch_predict_update");
+    filter_time_ = t;
+    if (keep) {
+      hip(hipMemcpyAsync(c.x, x_, sizeof(double) * n_ * D_, hipMemcpyDeviceToDevice, stream_), "ring x");
+      hip(hipMemcpyAsync(c.P, P_, sizeof(double) * n_ * E_ * E_, hipMemcpyDeviceToDevice, stream_), "ring P");
+      c.t = t;
+      ring_.push_back(c);
+      while ((int)ring_.size() > rewind_to_keep_) { spare_.push_back(ring_.front()); ring_.pop_front(); }
+    }
+  }
+
+  // EKFSym::rewind (ekf_sym.cc:119-140): back to the last checkpoint at or before t; returns the observations to replay
+  std::vector<Checkpoint> rewind(double t) {
+    size_t idx = 0;
+    while (idx < ring_.size() && ring_[idx].t <= t) idx++;          // first checkpoint after t
+    const Checkpoint& at = ring_[idx - 1];
+    filter_time_ = at.t;
+    hip(hipMemcpyAsync(x_, at.x, sizeof(double) * n_ * D_, hipMemcpyDeviceToDevice, stream_), "rewind x");
+    hip(hipMemcpyAsync(P_, at.P, sizeof(double) * n_ * E_ * E_, hipMemcpyDeviceToDevice, stream_), "rewind P");
+    std::vector<Checkpoint> replay(ring_.begin() + idx, ring_.end());
+    ring_.erase(ring_.begin() + idx, ring_.end());
+    return replay;
+  }
+
   using predict_fn = int (*)(double*, double*, const double*, const double*, double, int64_t, int, void*);
   using step_fn = int (*)(double*, double*, const double*, const double*, double, double*, const double*, int, const double*,
                           int64_t, int, uint8_t*, void*);
@@ -178,6 +276,10 @@ class EKFSymBatch {
   predict_fn batch_predict_ = nullptr;
   double *x_ = nullptr, *P_ = nullptr, *Q_ = nullptr, *R_ = nullptr;
   double filter_time_ = NAN;
+  int rewind_to_keep_ = 0;
+  double max_rewind_age_ = 1.0;
+  std::deque<Checkpoint> ring_;
+  std::vector<Checkpoint> spare_;
 };
 
 }  // namespace rednose_amd

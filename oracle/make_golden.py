@@ -247,6 +247,18 @@ def kinematic9_goldens(T=60):
     est.append(f.predict_and_update_batch(t, k, np.array([z]), np.array([K9.obs_noise[k]])))
     kinds.append(k); zs.append(np.concatenate([z, np.zeros(3 - len(z))]))
   xs_s, Ps_s = f.rts_smooth(copy.deepcopy(est), norm_quats=False)
+  # "multiple forward and backwards passes of the data" (/root/reference/README.md:41-45) with the reference class: each further
+  # pass restarts the filter from the oldest smoothed estimate of the previous pass and runs the same observations again
+  ts_all = [e[4] for e in est]
+  passes = [(xs_s.copy(), Ps_s.copy())]
+  for _ in range(2):
+    f.init_state(passes[-1][0][0].copy(), passes[-1][1][0].copy(), None)
+    est_p = [f.predict_and_update_batch(tt, kk, np.array([zz[:K9.obs_noise[kk].shape[0]]]), np.array([K9.obs_noise[kk]]))
+             for tt, kk, zz in zip(ts_all, kinds, zs)]
+    xp, Pp = f.rts_smooth(copy.deepcopy(est_p), norm_quats=False)
+    passes.append((xp.copy(), Pp.copy()))
+  np.savez_compressed(os.path.join(GOLD, "kinematic9_multipass.npz"), xs_pass2=passes[1][0], Ps_pass2=passes[1][1],
+                      xs_pass3=passes[2][0], Ps_pass3=passes[2][1])
   np.savez_compressed(os.path.join(GOLD, "kinematic9_stream.npz"), kinds=np.array(kinds), zs=np.array(zs),
                       ts=np.array([e[4] for e in est]), xk_km1=np.array([e[0] for e in est]), xk_k=np.array([e[1] for e in est]),
                       Pk_km1=np.array([e[2] for e in est]), Pk_k=np.array([e[3] for e in est]),

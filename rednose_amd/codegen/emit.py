@@ -22,6 +22,7 @@ SMALL_MAX_E = 7    # lane-per-filter register budget: x, P and the update's temp
                    # wrong for single filters on some runs (tools/stress_run_trace.py); 8 goes to the lane-group kernels
 
 
+RTS_ONE_WAVE = set() # model names whose smoother spilled under the two-wavefronts-per-SIMD register budget: regenerated with the full file
 FORCE_WIDE = set()   # model names whose lane-per-filter build spilled registers: gen_code regenerates them in the lane-group family
 
 
@@ -179,7 +180,7 @@ def _emit(spec):
   static constexpr int OFF_X = SLOT_OFF_X;
   static constexpr int OFF_DT = SLOT_OFF_DT;
   static __device__ __forceinline__ void scal(const double* xin, double dt, double* sl, int norm) {{ scal_predict(xin, dt, sl, norm); }}
-  static constexpr int WAVES = {2 if M <= 22 else 1};       // wavefronts per SIMD the register budget is set for (see k_rts_group)
+  static constexpr int WAVES = {2 if (M <= 22 and spec.name not in RTS_ONE_WAVE) else 1};       // wavefronts per SIMD the register budget is set for (see k_rts_group)
   static __device__ __forceinline__ void mat_predict(const double (&row)[{M}], double* sB, const double* gQc, const double* sl, int cc, bool act,
                                                      double (&y)[{M}]) {{ mat_predict_rts(row, sB, gQc, sl, cc, act, y); }}""" if group_rts else ""
     src.append(f"""

@@ -78,6 +78,18 @@ def gen_code(folder, name, f_sym, dt_sym, x_sym, obs_eqs, dim_x, dim_err, eskf_p
       rn_build.compile_filter(folder, name, verbose=verbose)
       bad = rn_build.spilled_kernels(rn_build.compile_filter.last_usage)
     bad_rts = [k for k in bad if k.startswith("k_rts") and rn_build.compile_filter.last_usage[k]["scratch"] > 0]
+    if bad_rts and name not in rn_emit.RTS_ONE_WAVE and not os.environ.get("RN_ALLOW_SPILLS"):
+      if verbose:
+        print(f"{name}: the smoother spills under the two-wavefronts-per-SIMD register budget -> one wavefront per SIMD")
+      rn_emit.RTS_ONE_WAVE.add(name)
+      header, source = emit(spec)
+      with open(os.path.join(folder, f"{name}.h"), "w", encoding="utf-8") as f:
+        f.write(header)
+      with open(os.path.join(folder, f"{name}.hip"), "w", encoding="utf-8") as f:
+        f.write(source)
+      rn_build.compile_filter(folder, name, verbose=verbose)
+      bad = rn_build.spilled_kernels(rn_build.compile_filter.last_usage)
+      bad_rts = [k for k in bad if k.startswith("k_rts") and rn_build.compile_filter.last_usage[k]["scratch"] > 0]
     if bad_rts and not os.environ.get("RN_ALLOW_SPILLS"):
       raise RuntimeError(f"{name}: smoother kernel {bad_rts} spills registers (see {folder}/{name}.kernels.txt); "
                          "set RN_ALLOW_SPILLS=1 to build it anyway")

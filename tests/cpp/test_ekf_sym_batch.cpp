@@ -8,13 +8,57 @@
 
 #include "rednose_amd/ekf_sym_batch.hpp"
 
+// Rewind mode: the stream arrives out of order (test_compare.py swaps two samples); with the checkpoint ring the filter must
+// end where the reference's orchestrators end (tests/golden/compare_rewind.npz).  Prints the filter time and state after every
+// observation of filter 0 and the last filter.
+static int run_rewind(const char* dir, const char* stream, int64_t n) {
+  rednose_amd::EKFSymBatch kf(dir, "kinematic", {0.1 * 0.1, 0.0, 0.0, 2.0 * 2.0}, {0.5, 0.0}, {1.0, 0.0, 0.0, 1.0}, n, false, nullptr, 512, 1.0);
+  std::ifstream in(stream);
+  std::vector<double> zs(n);
+  double* z_dev = nullptr;
+  if (hipMalloc((void**)&z_dev, sizeof(double) * n) != hipSuccess) return 3;
+  const double R[1] = {0.1 * 0.1};
+  double t, z;
+  while (in >> t >> z) {
+    std::fill(zs.begin(), zs.end(), z);
+    if (hipMemcpy(z_dev, zs.data(), sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) return 3;
+    const bool applied = kf.predict_and_update_batch(t, 1, z_dev, R);
+    kf.synchronize();
+    const std::vector<double> x = kf.state();
+    std::printf("%d %.17g %.17g %.17g %.17g %.17g\n", applied ? 1 : 0, kf.get_filter_time(), x[0], x[1], x[(n - 1) * 2], x[(n - 1) * 2 + 1]);
+  }
+  // far older than max_rewind_age: dropped, state untouched
+  const std::vector<double> before = kf.state();
+  const bool dropped = !kf.predict_and_update_batch(kf.get_filter_time() - 5.0, 1, z_dev, R);
+  std::printf("too_old_dropped %d untouched %d\n", dropped ? 1 : 0, (int)(kf.state() == before));
+  (void)hipFree(z_dev);
+  return 0;
+}
+
+// Globals mode: set_global / get_extra_routine on a model generated with global_vars (tests/test_global_vars.py's gv_runtime)
+static int run_globals(const char* dir) {
+  rednose_amd::EKFSymBatch kf(dir, "gv_runtime", {0.01, 0.0, 0.0, 4.0}, {0.5, 0.3}, {1.0, 0.0, 0.0, 1.0}, 3);
+  kf.set_global("gain", 2.5);
+  kf.predict(0.0);
+  kf.predict(0.1);
+  kf.synchronize();
+  const std::vector<double> x = kf.state();
+  bool threw = false;
+  try { kf.set_global("nope", 1.0); } catch (const std::runtime_error&) { threw = true; }
+  auto f = kf.get_extra_routine("f_fun");          // any exported host-pointer routine resolves by name
+  std::printf("x %.17g %.17g unknown_global_threw %d routine %d\n", x[0], x[1], threw ? 1 : 0, f != nullptr);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 4) {
-    std::fprintf(stderr, "usage: %s <generated_dir> <stream.txt> <batch>\n", argv[0]);
+    std::fprintf(stderr, "usage: %s <generated_dir> <stream.txt> <batch> [rewind] | %s <generated_dir> - - globals\n", argv[0], argv[0]);
     return 2;
   }
   const int64_t n = std::atoll(argv[3]);
   try {
+    if (argc >= 5 && std::string(argv[4]) == "rewind") return run_rewind(argv[1], argv[2], n);
+    if (argc >= 5 && std::string(argv[4]) == "globals") return run_globals(argv[1]);
     rednose_amd::EKFSymBatch kf(argv[1], "kinematic", {0.1 * 0.1, 0.0, 0.0, 2.0 * 2.0}, {0.5, 0.0}, {1.0, 0.0, 0.0, 1.0}, n);
     std::ifstream in(argv[2]);
     std::vector<double> zs(n);

@@ -81,3 +81,39 @@ def test_plugin_known_answers_through_descriptor(tmp_path):
   got = (float(v[3]), float(v[6]), float(v[4]), float(v[7]))
   for a, want in zip(got, g["literals"]):
     assert round(abs(a - want), 7) == 0
+
+
+@pytest.mark.gpu
+def test_cpp_orchestrator_rewind_ring(tmp_path):
+  """/root/reference/examples/test_compare.py:103-120 through the C++ class: samples 20 and 40 arrive swapped; the checkpoint
+  ring (rewind_to_keep = 512) rewinds the batch, applies the late observation and replays -- states after every arrival as the
+  reference's orchestrators produce them (tests/golden/compare_rewind.npz)."""
+  from examples import ensure_generated
+  gen = ensure_generated(["kinematic"])
+  g = golden("compare_rewind.npz")
+  stream = tmp_path / "stream.txt"
+  with open(stream, "w", encoding="utf-8") as f:
+    for t, z in zip(g["ts"], g["zs"]):
+      f.write(f"{float(t)!r} {float(z)!r}\n")
+  out = subprocess.run([_build(), gen, str(stream), "70", "rewind"], check=True, capture_output=True, text=True).stdout.strip().split("\n")
+  assert out[-1] == "too_old_dropped 1 untouched 1"
+  rows = np.array([[float(v) for v in line.split()] for line in out[:-1]])
+  assert rows.shape[0] == len(g["ts"]) and (rows[:, 0] == 1).all()
+  assert np.abs(rows[:, 1] - g["filter_times"]).max() < 1e-12
+  for col in (2, 4):
+    assert np.abs(rows[:, col:col + 2] - g["xs"]).max() < 1e-9
+  assert (np.diff(g["ts"]) < 0).any(), "the stream must contain a late observation"
+
+
+@pytest.mark.gpu
+def test_cpp_set_global_and_extra_routine():
+  import sympy as sp
+  from rednose_amd.helpers.ekf_sym import gen_code
+  import test_global_vars as tg
+  folder = os.path.join(REPO, "generated")
+  gsym = sp.Symbol('gain')
+  gen_code(folder, "gv_runtime", global_vars=[gsym], **tg._model(gsym))
+  out = subprocess.run([_build(), folder, "-", "3", "globals"], check=True, capture_output=True, text=True).stdout.strip().split()
+  # x0 + dt * gain * x1 with gain = 2.5, dt = 0.1
+  assert abs(float(out[1]) - (0.5 + 0.1 * 2.5 * 0.3)) < 1e-14 and abs(float(out[2]) - 0.3) < 1e-15
+  assert out[4] == "1" and out[6] == "1"

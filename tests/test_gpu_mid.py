@@ -114,6 +114,37 @@ def test_stream_and_smoother_vs_reference(env):
     assert_close(Ps[:, j].reshape(T, -1), g["Ps_smooth"].reshape(T, -1), rtol=1e-7, floor=1e-9, what="smoothed P")
 
 
+@pytest.mark.parametrize("chunk", [None, 4])
+def test_multipass_smoothing_vs_reference_class(env, chunk):
+  """BatchedEKF.smooth(passes=k): forward filter + RTS backward pass, repeated from the oldest smoothed estimate -- "multiple
+  forward and backwards passes of the data" (/root/reference/README.md:41-45) -- against the same loop run with the reference's
+  own class (tests/golden/kinematic9_multipass.npz, oracle/make_golden.py); whole batch in one sweep and in chunks of 4 filters."""
+  torch, gen, K9 = env
+  g, gm = golden("kinematic9_stream.npz"), golden("kinematic9_multipass.npz")
+  n = 10
+  kinds, ts = g["kinds"].astype(np.int32), g["ts"]
+  T = len(kinds)
+  zs = np.tile(g["zs"][:, None, :], (1, n, 1))
+  Rs = {k: K9.obs_noise[k] for k in (1, 2, 3)}
+  for passes, wx, wP in ((1, g["xs_smooth"], g["Ps_smooth"]), (2, gm["xs_pass2"], gm["Ps_pass2"]), (3, gm["xs_pass3"], gm["Ps_pass3"])):
+    f = _filter(env, n)
+    got = {}
+    if chunk is None:
+      xs, Ps = f.smooth(ts, kinds, zs, Rs, passes=passes)
+      got = {j: (xs[:, j].cpu().numpy(), Ps[:, j].cpu().numpy()) for j in (0, n - 1)}
+    else:
+      def on_chunk(lo, hi, xs, Ps, ys, fl):
+        for j in (0, n - 1):
+          if lo <= j < hi:
+            got[j] = (xs[:, j - lo].cpu().numpy(), Ps[:, j - lo].cpu().numpy())
+      assert f.smooth(ts, kinds, zs, Rs, passes=passes, chunk=chunk, on_chunk=on_chunk) is None
+    torch.cuda.synchronize()
+    for j in (0, n - 1):
+      assert_close(got[j][0], wx, rtol=1e-7, floor=1e-9, what=f"{passes} passes, smoothed x")
+      assert_close(got[j][1].reshape(T, -1), wP.reshape(T, -1), rtol=1e-6, floor=1e-8, what=f"{passes} passes, smoothed P")
+    assert f.get_filter_time() == float(ts[-1])
+
+
 def test_maha_distance_vs_numpy(env):
   torch, gen, K9 = env
   from oracle_lib import OracleLib

@@ -47,6 +47,30 @@ def test_known_answer_scalar_abi_on_gpu(gen_dir, torch_cuda):
   assert_close(kf.P.reshape(-1), g["Ps"][-1].reshape(-1), rtol=1e-10, floor=1e-12)
 
 
+def test_stream_fast_path_known_answers(gen_dir, torch_cuda):
+  """KalmanFilter.predict_and_observe_stream: the reference's known-answer stream in ONE fused launch for a batch of identical
+  filters (the default path for streams: a launch per step cannot feed a 2-state model), and the per-step fallback of the
+  single host-pointer filter."""
+  from examples.kinematic_kf import KinematicKalman
+  g = golden("kinematic_stream.npz")
+  n = 200
+  kf = KinematicKalman(gen_dir, batch=n)
+  T = len(g["ts"])
+  ys = kf.predict_and_observe_stream(g["ts"], np.ones(T, dtype=np.int32), np.tile(g["zs"].reshape(T, 1, 1), (1, n, 1)))
+  assert tuple(ys.shape) == (T, n, 1)
+  X, P = kf.x, kf.P
+  for j in (0, n - 1):
+    std = np.sqrt(np.diag(P[j]))
+    for got, want in zip((X[j, 0], std[0], X[j, 1], std[1]), g["literals"]):
+      assert round(abs(got - want), 7) == 0
+    assert_close(X[j], g["xs"][-1], rtol=1e-10, floor=1e-12)
+  assert kf.t == float(g["ts"][-1])
+  one = KinematicKalman(gen_dir)
+  res = one.predict_and_observe_stream(g["ts"][:30], np.ones(30, dtype=np.int32), g["zs"][:30].reshape(30, 1, 1))
+  assert len(res) == 30 and len(res[0]) == 9
+  assert_close(one.x, g["xs"][29], rtol=1e-10, floor=1e-12)
+
+
 def test_pyx_named_class_is_the_same_orchestrator(gen_dir, torch_cuda):
   """Models written for the reference construct `EKF_sym_pyx(gen_dir, name, Q, x0, P0, dim, dim_err, ...)`
   (/root/reference/examples/kinematic_kf.py:69, ekf_sym_pyx.pyx:87-90)."""
