@@ -89,41 +89,31 @@ def _emit(spec):
   if E > 64:
     raise NotImplementedError(f"{E} error states: the lane-group kernels hold one row of P per lane of a wavefront (<= 64)")
   has_run = E <= 32        # fused multi-step run: rows of P stay in VGPRs, 32-lane groups
+  import types
+  from rednose_amd.codegen import tuning
   if fam == "wide":
-    import types
-    from rednose_amd.codegen import emit_wide, emit_wide2, tuning
+    from rednose_amd.codegen import emit_wide, emit_wide2
     if not has_run:
       fam_mod = types.SimpleNamespace(
         kernels=lambda sp_: emit_wide2.kernels(sp_) + "\n" + emit_wide2.maha_kernels(sp_),
         launch_predict=emit_wide2.launch_predict, launch_step=emit_wide2.launch_step, launch_run=None,
         launch_maha=emit_wide2.launch_maha)
-    elif tuning.current().wide_struct == 1:
-      fam_mod = emit_wide                 # first structure for every kernel (kept for A/B runs)
     else:
       # step-granular kernels: three-phase structure (emit_wide2); fused multi-step run: state-resident structure (emit_wide)
       fam_mod = types.SimpleNamespace(
-        kernels=lambda sp_: emit_wide.kernels(sp_, step_kernels=False) + "\n" + emit_wide2.kernels(sp_) + "\n" + emit_wide2.maha_kernels(sp_),
+        kernels=lambda sp_: emit_wide.kernels(sp_) + "\n" + emit_wide2.kernels(sp_) + "\n" + emit_wide2.maha_kernels(sp_),
         launch_predict=emit_wide2.launch_predict, launch_step=emit_wide2.launch_step, launch_run=emit_wide.launch_run,
         launch_maha=emit_wide2.launch_maha)
   else:
-    import types
-    from rednose_amd.codegen import emit_small2, tuning
-    if tuning.current().small_lpf == 2 and E % 2 == 0:
-      # step-granular kernels: lane pair per filter (emit_small2); fused multi-step run: lane per filter (emit_small)
-      fam_mod = types.SimpleNamespace(
-        kernels=lambda sp_: emit_small.kernels(sp_, step_kernels=False) + "\n" + emit_small2.kernels(sp_) + "\n" + emit_small.maha_kernels(sp_),
-        launch_predict=emit_small2.launch_predict, launch_step=emit_small2.launch_step, launch_run=emit_small.launch_run,
-        launch_maha=emit_small.launch_maha)
-    else:
-      fam_mod = types.SimpleNamespace(
-        kernels=lambda sp_: emit_small.kernels(sp_) + "\n" + emit_small.maha_kernels(sp_),
-        launch_predict=emit_small.launch_predict, launch_step=emit_small.launch_step, launch_run=emit_small.launch_run,
-        launch_maha=emit_small.launch_maha)
+    fam_mod = types.SimpleNamespace(
+      kernels=lambda sp_: emit_small.kernels(sp_) + "\n" + emit_small.maha_kernels(sp_),
+      launch_predict=emit_small.launch_predict, launch_step=emit_small.launch_step, launch_run=emit_small.launch_run,
+      launch_maha=emit_small.launch_maha)
 
   hdr = ["#pragma once", "#include <stdint.h>", "#ifdef __cplusplus", 'extern "C" {', "#endif"]
   src = [f"// GENERATED by rednose_amd.helpers.ekf_sym.gen_code for filter '{name}' -- do not edit.",
          f"// DIM={D} EDIM={E} MEDIM={M} kinds={[k.kind for k in spec.kinds]} family={fam}",
-         *(["#define RN_RTS_TL 1"] if (fam == "wide" and __import__("rednose_amd.codegen.tuning", fromlist=["x"]).current().wide_timeline) else []),
+         *(["#define RN_RTS_TL 1"] if (fam == "wide" and tuning.current().wide_timeline) else []),
          '#include "ekf_hip_rt.h"', '#include "ekf_hip_rts.h"', "", "namespace {",
          f"constexpr int DIM = {D};", f"constexpr int EDIM = {E};", f"constexpr int MEDIM = {M};", ""]
 
@@ -167,8 +157,7 @@ def _emit(spec):
   src.append(fam_mod.kernels(spec))
   # smoother.  Lane-per-filter models: rn::k_rts (state and covariance of a filter in one lane's registers).  Lane-group
   # models, MSCKF ones included (their main block is smoothed, ekf_sym.py:675-686): rn::k_rts_group.
-  from rednose_amd.codegen import tuning as _tuning
-  group_rts = fam == "wide" and _tuning.current().wide_struct != 1
+  group_rts = fam == "wide"
   has_rts = group_rts or (fam == "small" and spec.dim_main == spec.dim_x and spec.dim_main_err == spec.dim_err)
   if has_rts:
     quat = "".join(f" rn::normalize_quat<{D}>(x, {q});" for q in spec.quaternion_idxs)

@@ -254,8 +254,8 @@ def launch_maha(kind):
                      x, P, z, R, r_per_filter, n, d2);"""
 
 
-def kernels(spec, step_kernels=True):
-  """Device functions + __global__ kernels of family S for every kind (step_kernels=False: only what k_run needs)."""
+def kernels(spec):
+  """Device functions + __global__ kernels of family S for every kind."""
   waves = tuning.current().small_waves
   kattr = f" __attribute__((amdgpu_waves_per_eu({waves}, {waves})))" if waves else ""
   D, E = spec.dim_x, spec.dim_err
@@ -269,8 +269,7 @@ def kernels(spec, step_kernels=True):
   quat = "".join(f" rn::normalize_quat<{D}>(x, {q});" for q in spec.quaternion_idxs)
   norm = f"if (norm_quats) {{{quat} }}" if spec.quaternion_idxs else "(void)norm_quats;"
 
-  if step_kernels:
-   out.append(f"""
+  out.append(f"""
 // ---- predict only: one launch propagates n filters by dt -------------------------------------------
 __global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double* __restrict__ gP,
     const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
@@ -304,7 +303,7 @@ __global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double*
   }}
 }}
 """)
-  for k in (spec.kinds if step_kernels else []):
+  for k in spec.kinds:
     Z = k.zdim
     ZZ = Z * Z
     # extra arguments are per observation, i.e. per filter of the batch: (n, len(ea)) row-major

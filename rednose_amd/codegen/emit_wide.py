@@ -3,8 +3,8 @@ lane c owns row c of P, the nominal state x replicated in every lane of the grou
 
 Used when the covariance does not fit one lane's registers (live: D=23, E=22 -> P is 484 doubles).  This structure
 is what the FUSED MULTI-STEP kernel `k_run` uses: P rows and x stay in VGPRs for T steps, only z / y and the optional
-trace cross HBM.  (It also provides step-granular kernels, kept for A/B runs -- tuning knob wide_struct=1; the
-default step-granular kernels are the three-phase ones of emit_wide2.py, 2.6x faster.)
+trace cross HBM.  (The step-granular kernels are the three-phase ones of emit_wide2.py; step kernels in this structure
+were the first version, 2.6x slower, and are gone.)
 
   predict (ekf_c.c:8-33)    A = P F^T   row-local sparse mat-vec (F has ~33 non-trivial entries of 484)
                             --LDS transpose-->  column c of A;  P' = F A + dt Q  column-local
@@ -169,11 +169,9 @@ def run_kinds(spec):
   return [k for k in spec.kinds if k.ea_sym is None]
 
 
-def kernels(spec, step_kernels=True):
+def kernels(spec):
+  """Device functions + the fused multi-step kernel of the state-resident structure."""
   D, E = spec.dim_x, spec.dim_err
-  EE = E * E
-  DP = _even(D)
-  zmax = max(k.zdim for k in spec.kinds)
   out = [f"constexpr int GL = {G_LANES};    // lanes per filter", f"constexpr int FPW = {FPW};   // filters per wavefront", ""]
   out.append(predict_fn(spec))
   for k in run_kinds(spec):
@@ -181,122 +179,6 @@ def kernels(spec, step_kernels=True):
     out.append(utxt)
   quat = "".join(f" rn::normalize_quat<{D}>(x, {q});" for q in spec.quaternion_idxs)
   norm = f"if (norm_quats) {{{quat} }}" if spec.quaternion_idxs else "(void)norm_quats;"
-
-  common_decl = f"""  __shared__ __attribute__((aligned(16))) double s_P[FPW * {EE}];
-  __shared__ __attribute__((aligned(16))) double s_Q[{EE}];
-  __shared__ __attribute__((aligned(16))) double s_x[FPW * {DP}];
-  const int lane = threadIdx.x;
-  const int g = lane / GL;
-  const int c = lane % GL;
-  const bool act = c < {E};
-  const int cc = act ? c : 0;
-  if (gQ != nullptr) rn::copy_g2l<{EE}>(gQ, {EE}, s_Q, lane);
-  const int64_t tiles = (n + FPW - 1) / FPW;"""
-
-  if step_kernels:
-   out.append(f"""
-// ---- predict only ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double* __restrict__ gP,
-    const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
-    const int norm_quats) {{
-{common_decl}
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
-    const int64_t base = tile * FPW;
-    const int cnt = (n - base) < FPW ? (int)(n - base) : FPW;
-    const int gg = g < cnt ? g : 0;
-    rn::copy_g2l<FPW * {EE}>(gP + base * {EE}, cnt * {EE}, s_P, lane);
-    rn::copy_g2l<FPW * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);
-    const double dt = gdt != nullptr ? gdt[base + gg] : dt_scalar;
-    rn::wave_lds_sync();
-    double x[{D}], row[{E}], col[{E}];
-#pragma unroll
-    for (int i = 0; i < {D}; i++) x[i] = s_x[gg * {D} + i];
-#pragma unroll
-    for (int j = 0; j < {E}; j++) row[j] = s_P[gg * {EE} + cc * {E} + j];
-    predict_wide<false>(x, row, col, s_P + gg * {EE}, s_Q, dt, cc, act && g < cnt);
-    {norm}
-    if (c == 0 && g < cnt) {{
-#pragma unroll
-      for (int i = 0; i < {D}; i++) s_x[g * {D} + i] = x[i];
-    }}
-    rn::wave_lds_sync();
-    rn::copy_l2g<FPW * {EE}>(gP + base * {EE}, cnt * {EE}, s_P, lane);
-    rn::copy_l2g<FPW * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);
-    rn::wave_lds_sync();
-  }}
-}}
-""")
-  for k in (spec.kinds if step_kernels else []):
-    Z = k.zdim
-    ZZ = Z * Z
-    out.append(f"""
-// ---- kind {k.kind}: [predict +] update ---------------------------------------------------------------------
-template <bool DO_PREDICT>
-__global__ __launch_bounds__(64) void k_step_{k.kind}(double* __restrict__ gx, double* __restrict__ gP,
-    double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const double* __restrict__ gea,
-    const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
-    const int norm_quats, uint8_t* __restrict__ flags) {{
-  __shared__ __attribute__((aligned(16))) double s_z[FPW * {Z} + 2];
-  __shared__ __attribute__((aligned(16))) double s_G[FPW * {Z * E}];
-  __shared__ __attribute__((aligned(16))) double s_K[FPW * {Z * E}];
-  __shared__ __attribute__((aligned(16))) double s_dx[FPW * {E}];
-{common_decl}
-  (void)gea;
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
-    const int64_t base = tile * FPW;
-    const int cnt = (n - base) < FPW ? (int)(n - base) : FPW;
-    const int gg = g < cnt ? g : 0;
-    const bool on = act && g < cnt;
-    rn::copy_g2l<FPW * {EE}>(gP + base * {EE}, cnt * {EE}, s_P, lane);
-    rn::copy_g2l<FPW * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);
-    rn::copy_g2l<FPW * {Z}>(gz + base * {Z}, cnt * {Z}, s_z, lane);
-    double dt = dt_scalar;
-    if (DO_PREDICT && gdt != nullptr) dt = gdt[base + gg];
-    double R[{ZZ}];
-#pragma unroll
-    for (int i = 0; i < {ZZ}; i++) R[i] = r_per_filter ? gR[(base + gg) * {ZZ} + i] : gR[i];
-    rn::wave_lds_sync();
-    double x[{D}], row[{E}], col[{E}], z[{Z}];
-#pragma unroll
-    for (int i = 0; i < {D}; i++) x[i] = s_x[gg * {D} + i];
-#pragma unroll
-    for (int i = 0; i < {Z}; i++) z[i] = s_z[gg * {Z} + i];
-#pragma unroll
-    for (int j = 0; j < {E}; j++) row[j] = s_P[gg * {EE} + cc * {E} + j];
-    if (DO_PREDICT) {{
-      predict_wide<true>(x, row, col, s_P + gg * {EE}, s_Q, dt, cc, on);
-      {norm}
-    }} else {{
-#pragma unroll
-      for (int k = 0; k < {E}; k++) col[k] = s_P[gg * {EE} + k * {E} + cc];
-    }}
-    int fl = update_{k.kind}_wide(x, row, col, z, R, s_G + gg * {Z * E}, s_K + gg * {Z * E}, s_dx + gg * {E}, cc, on);
-    {norm}
-    if (on) {{
-#pragma unroll
-      for (int j = 0; j < {E}; j++) s_P[g * {EE} + c * {E} + j] = row[j];
-    }}
-    if (c == 0 && g < cnt) {{
-#pragma unroll
-      for (int i = 0; i < {D}; i++) s_x[g * {D} + i] = x[i];
-#pragma unroll
-      for (int i = 0; i < {Z}; i++) s_z[g * {Z} + i] = z[i];
-      if (flags != nullptr) {{
-        double acc = 0.0;
-#pragma unroll
-        for (int i = 0; i < {D}; i++) acc += x[i];
-        if (!(acc - acc == 0.0)) fl |= 2;
-        flags[base + g] = (uint8_t)fl;
-      }}
-    }}
-    rn::wave_lds_sync();
-    rn::copy_l2g<FPW * {EE}>(gP + base * {EE}, cnt * {EE}, s_P, lane);
-    rn::copy_l2g<FPW * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);
-    rn::copy_l2g<FPW * {Z}>(gz + base * {Z}, cnt * {Z}, s_z, lane);
-    rn::wave_lds_sync();
-  }}
-}}
-""")
   out.append(run_kernel(spec, norm))
   return "\n".join(out)
 
@@ -428,21 +310,3 @@ def launch_run():
   return """  const int64_t tiles = (n + 1) / 2;
   hipLaunchKernelGGL(k_run, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
                      x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P);"""
-
-
-def launch_predict():
-  return """  const int64_t tiles = (n + 1) / 2;
-  hipLaunchKernelGGL(k_predict, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
-                     x, P, Q, dt_vec, dt, n, norm_quats);"""
-
-
-def launch_step(kind, do_predict):
-  tf = "true" if do_predict else "false"
-  # Q is staged into LDS by every kernel of this family, so update-only launches need a valid pointer too
-  if do_predict:
-    args = "x, P, z, R, r_per_filter, ea, Q, dt_vec, dt, n, norm_quats, flags"
-  else:
-    args = "x, P, z, R, r_per_filter, ea, nullptr, nullptr, 0.0, n, norm_quats, flags"
-  return f"""  const int64_t tiles = (n + 1) / 2;
-  hipLaunchKernelGGL(k_step_{kind}<{tf}>, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
-                     {args});"""

@@ -12,7 +12,7 @@ On a GPU that turns a memory-bound filter step into a transcendental-bound one, 
   * entries that are structurally 0 / 1 / numeric constants are reported as such so the kernel
     emitters can skip or fold them (sparsity is resolved at generation time, never at run time).
 
-Rounding differs from the reference's expression order by a few ulp; tests bound it (tests/test_codegen.py).
+Rounding differs from the reference's expression order by a few ulp; tests bound it (tests/test_oracle.py::test_port_flavour_equals_ref_flavour on the CPU, tests/test_gpu_parity.py::test_scalar_sympy_routines_on_gpu on the device).
 """
 import sympy as sp
 from sympy.printing.c import C99CodePrinter

@@ -5,7 +5,6 @@ environment variable RN_TUNE, e.g.  RN_TUNE="wide_ft=8,wide_lb=2" python bench.p
 (bench.py regenerates into RN_GEN_DIR when set, so variants do not overwrite generated/).
 
   knob          default  measured alternatives (live = 23/22-state ESKF, batch 16 384; k6 = kinematic6, batch 65 536)
-  wide_struct   2        1 = scalars evaluated redundantly in all 32 lanes of a group: live 122 us/launch vs 47 us
   wide_ft       0 (auto) filters per wavefront tile; auto = 8 above 40 error states (LDS budget), 16 above 16 error states (live: 8 -> 52.8 us, 32 -> LDS allows only
                          3 waves per CU), two groups below (kinematic9, 7 filters per group: 14 -> 25.5-26.3 us with a single
                          buffer, 7 -> 31.2, 21 -> 28.6, 28 -> 28.3; with the double buffer 16 -> 30.5, 42 -> 36.4, 63 -> 47.7)
@@ -30,9 +29,6 @@ environment variable RN_TUNE, e.g.  RN_TUNE="wide_ft=8,wide_lb=2" python bench.p
   small_waves   0        amdgpu_waves_per_eu(n, n) on the lane-per-filter step kernels: 1 -> k6 35 us/launch vs 9.5 us
   small_max_e   7        largest error-state count served lane-per-filter (8 spills, see emit.py); below it the lane-group family also works (k6 with
                          small_max_e=4: 13.9-15.7 us/launch, parity-green, against 9.1 us lane-per-filter)
-  small_lpf     1        lanes per filter in the family-S step kernels: 2 = lane PAIR per filter (emit_small2.py: half the
-                         rows per lane, DPP exchanges, 2 waves per SIMD): k6 9.8-10.0 us/launch vs 9.4 us -- parity-green but
-                         not faster, the two waves of a SIMD still move in lockstep through load / compute / store
 Also measured, not kept: SOFTWARE PIPELINING over the tiles of a wavefront (double-buffered LDS image, the next tile's
 global_load_lds issued before the current tile is computed, counted s_waitcnt vmcnt(23) so that the previous tile's stores stay
 in flight, two tiles per wavefront): k6 at 65 536 filters 10.7 us per launch against 9.2 us (half as many wavefronts, 53 KB of
@@ -64,7 +60,6 @@ from dataclasses import dataclass, fields
 
 @dataclass(frozen=True)
 class Tuning:
-  wide_struct: int = 2
   wide_ft: int = 0
   wide_lb: int = 0
   wide_db: int = -1
@@ -75,7 +70,6 @@ class Tuning:
   wide_lean_q: int = 0
   small_waves: int = 0
   small_max_e: int = 7
-  small_lpf: int = 1
   wide_timeline: int = 0     # debug: lane 0 of the first 256 workgroups stamps s_memtime / the 100 MHz wall clock at every phase boundary of
                              # the three-phase step kernels into a device buffer read back by {name}_debug_timeline (tools/timeline.py)
 

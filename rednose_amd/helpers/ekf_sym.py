@@ -815,7 +815,7 @@ class BatchedEKF:
       bx, bP = (tx, tP) if m == step else (tx[:, :m].contiguous(), tP[:, :m].contiguous())
       for p in range(passes):
         self.filter_time = t_init
-        zc = zs[:, lo:hi].contiguous()          # run() consumes its observations (overwrites them with the residuals)
+        zc = zs[:, lo:hi].clone()               # run() consumes its observations (overwrites them with the residuals)
         ys, _, _, fl = self.run(ts, kinds, zc, Rs, flags=flags, out=(bx, bP), filters=(lo, hi))
         # the smoother works on the trace of this chunk only: a view of the orchestrator restricted to its filters
         xs, Ps = self._rts_on(bx, bP, ts, m, norm_quats)
