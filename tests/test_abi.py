@@ -100,3 +100,31 @@ def test_step_kernels_do_not_spill(gen_dir, name):
     # (gen_code regenerates a model in the general structure beyond that: rednose_amd/helpers/ekf_sym.py)
     assert v["scratch"] <= 32 and v["spills"] <= 8, f"{name}: {k} spills ({v})"
     assert v["lds"] <= 65536
+
+
+def test_loader_backends(gen_dir):
+  """load_code binds the same prototypes through either backend: cffi when importable (what the reference uses), ctypes
+  otherwise or on request.  BatchedEKF always asks for ctypes (it passes ctypes pointers); a forced "cffi" without cffi
+  installed must raise instead of silently switching."""
+  from rednose_amd.helpers import load_code, CtypesFFI
+  ffi, lib = load_code(gen_dir, "kinematic", backend="ctypes")
+  assert isinstance(ffi, CtypesFFI)
+  d = (ctypes.c_int * 3)()
+  lib.kinematic_dims(ctypes.cast(d, ctypes.c_void_p))
+  assert tuple(d) == (2, 2, 2)
+  assert ffi.string(lib.kinematic_last_error_string()) == b""
+  assert "kinematic_h_1" in dir(lib) and "kinematic_batch_run" in dir(lib)
+  try:
+    import cffi  # noqa: F401
+    have_cffi = hasattr(cffi, "FFI") and hasattr(cffi.FFI, "cdef")
+  except ImportError:
+    have_cffi = False
+  if have_cffi:
+    ffi2, lib2 = load_code(gen_dir, "kinematic", backend="cffi")
+    dd = ffi2.new("int[3]")
+    lib2.kinematic_dims(dd)
+    assert tuple(dd) == (2, 2, 2)
+  else:
+    with pytest.raises(ImportError):
+      load_code(gen_dir, "kinematic", backend="cffi")
+    assert isinstance(load_code(gen_dir, "kinematic")[0], CtypesFFI)

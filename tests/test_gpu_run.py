@@ -124,6 +124,9 @@ def test_degenerate_sizes(env):
   assert lib.kinematic6_batch_run(p(f.x), p(f.P), p(f.Q), p(kd), p(dd), 1, p(zz), p(Rd), 0, 0, None, None, None, None) == 0     # n = 0
   torch.cuda.synchronize()
   assert np.array_equal(f.state(), x_before)
+  # the Python wrapper treats an empty schedule the same way (no IndexError on ts[0] / ts[-1])
+  ys, tx0, tP0, fl0 = f.run(np.zeros(0), np.zeros(0, dtype=np.int32), np.zeros((0, 5, 3)), {1: K6.obs_noise[1]}, trace=True)
+  assert tuple(ys.shape) == (0, 5, 3) and tx0 is None and np.array_equal(f.state(), x_before)
   # single-estimate smoothing: nothing to smooth, the filtered pair comes back
   tx = torch.randn((1, 5, 6), dtype=torch.float64, device=f.device); tP = torch.eye(6, dtype=torch.float64, device=f.device).repeat(1, 5, 1, 1)
   xs, Ps = f.rts_smooth(tx, tP, np.array([0.0]))
