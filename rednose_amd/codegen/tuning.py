@@ -93,6 +93,14 @@ def model_defaults(spec):
   msckf = any(k.He_sym is not None for k in spec.kinds)
   if not msckf and 22 <= spec.dim_err <= 24:
     return dict(wide_lean=1, wide_lean_q=1, wide_ft=8, wide_lb=2, wide_db=0)
+  if spec.dim_err > 32:
+    # One filter per wavefront pass (33 .. 64 error states, e.g. the 36-state MSCKF example).  Measured on feature36, 16 384
+    # filters, fused predict + feature-track update (tools/msckf_time.py, one call): general structure with tiles of 16 filters
+    # 156.7 us per launch (28 % of the HBM roofline), tiles of 8 106.7, tiles of 4 118.4 / 109.9 (double / single buffer);
+    # register-lean structure at two wavefronts per SIMD: tiles of 8 113.3, of 4 **84.2 us (52 %)**, of 3 92.0, of 2 96.0.
+    # With one filter per pass the scalar phase is short relative to the covariance passes, so small tiles (more wavefronts,
+    # 8 per CU at 19 KB of LDS each) win; below 4 the scalar phase, repeated per tile at 4 active lanes, takes over.
+    return dict(wide_lean=1, wide_lean_q=1, wide_ft=4, wide_lb=2, wide_db=0)
   return {}
 
 
