@@ -490,7 +490,6 @@ class BatchedEKF:
     self.x = self._dev(state, (self.batch, self.dim_x)).clone()
     self.P = self._dev(covs, (self.batch, self.dim_err, self.dim_err)).clone()
     if filter_time is not None and not np.isscalar(filter_time):
-      assert self.rewind_to_keep == 0, "per-filter filter times and the rewind ring are mutually exclusive"
       filter_time = self._dev(filter_time, (self.batch,)).clone()     # (N,) per-filter times until the first step
     self.filter_time = filter_time
     self.reset_rewind()
@@ -629,7 +628,13 @@ class BatchedEKF:
     observation older than the filter time rewinds every filter to the last checkpoint at or before t, is applied,
     and the overtaken observations are replayed; anything older than max_rewind_age (or than the ring) is dropped."""
     replay = []
-    if self.filter_time is not None and t < self.filter_time:
+    if isinstance(self.filter_time, self._torch.Tensor):
+      # per-filter times exist only between init_state and the first step, when the ring is still empty: an observation
+      # older than ANY filter's time cannot be reordered and is dropped for the whole batch (ekf_sym.cc:87-94)
+      if bool((t < self.filter_time).any()):
+        self.logger.error(f"observation too old at {t:.3f} for a filter of the batch, ignoring")
+        return None
+    elif self.filter_time is not None and t < self.filter_time:
       if len(self.rewind_t) == 0 or t < self.rewind_t[0] or t < self.rewind_t[-1] - self.max_rewind_age:
         self.logger.error(f"observation too old at {t:.3f} with filter at {self.filter_time:.3f}, ignoring")
         return None

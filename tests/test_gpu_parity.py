@@ -346,3 +346,36 @@ def test_per_filter_filter_times(gen_dir, torch_cuda):
   f.init_state(x0, P0, ft)
   with pytest.raises(AssertionError):
     f.predict(0.5)                     # some filters are already past 0.5
+
+
+def test_per_filter_times_with_rewind_ring(gen_dir, torch_cuda):
+  """Per-filter initial times and the late-observation ring together: the first step brings every filter to a common time
+  with its own dt and is checkpointed; from then on a late observation rewinds the batch, and one that is older than a
+  filter's own start is dropped (returns None, state untouched) -- against the oracle stepping the same reordered stream."""
+  torch = torch_cuda
+  from oracle_lib import OracleLib
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  from examples.kinematic6_kf import Kinematic6Kalman as K6
+  o = OracleLib("kinematic6")
+  n = 90
+  rng = np.random.default_rng(33)
+  x0 = rng.normal(size=(n, 6)); P0 = _rand_spd(rng, n, 6)
+  ft = rng.uniform(0.0, 0.4, size=n)
+  R = K6.obs_noise[1]
+  f = BatchedEKF(gen_dir, "kinematic6", K6.Q, x0[0], P0[0], 6, 6, batch=n, rewind_to_keep=16)
+  f.init_state(x0, P0, ft)
+  assert f.predict_and_update_batch(0.2, 1, rng.normal(size=(n, 3)), R) is None        # older than some filters' start time
+  assert np.array_equal(f.state(), x0)
+  zs = {t: rng.normal(size=(n, 3)) for t in (0.5, 0.6, 0.7, 0.65)}
+  for t in (0.5, 0.6, 0.7, 0.65):                                                         # 0.65 arrives late
+    assert f.predict_and_update_batch(t, 1, zs[t].copy(), R) is not None
+  torch.cuda.synchronize()
+  assert abs(f.get_filter_time() - 0.7) < 1e-15
+  xr, Pr = x0.copy(), P0.copy()
+  prev = ft.copy()
+  for t in (0.5, 0.6, 0.65, 0.7):                                                         # time order
+    zr = zs[t].copy()
+    o.batch_step(1, xr, Pr, zr, R, K6.Q, t - prev)
+    prev = np.full(n, t)
+  assert_close(f.state(), xr, rtol=1e-11, floor=1e-13)
+  assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-11, floor=1e-13)
