@@ -60,7 +60,7 @@ int live_batch_maha_19(const double *x, const double *P, const double *z, const 
 void live_msckf_dims(int *dims);
 int live_kind_eadim(int kind);
 int live_zmax(void);
-int live_batch_run(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts, int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, double *trace_x, double *trace_P, void *stream);
+int live_batch_run(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts, int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, double *trace_x, double *trace_P, const double *ea, const int32_t *augment, void *stream);
 int live_batch_rts(const double *xf, const double *Pf, const double *ts, int64_t T, const double *Q, int64_t n, int norm_quats, double *xs, double *Ps, const double *x_last, const double *P_last, void *stream);
 void live_predict(double *in_x, double *in_P, double *in_Q, double dt);
 void live_update_3(double *in_x, double *in_P, double *in_z, double *in_R, double *in_ea);

@@ -84,10 +84,14 @@ extern "C" {
    * R (T, zmax*zmax; the leading Z*Z entries of row t are that step's row-major R) and z (T, n, zmax; in: z,   \
    * out: y) are DEVICE arrays; the schedule is shared by all filters.  flags (T, n), trace_x (T, n, D) and      \
    * trace_P (T, n, E, E) -- the FILTERED pair after each step, i.e. Estimate.xk/Pk of ekf_sym.h:32-42 -- may be  \
-   * NULL.  Replaces T calls of EKFSym::predict_and_update_batch (ekf_sym.cc:158-194). */                         \
+   * NULL.  ea (T, n, EA) DEVICE array or NULL: per filter and step extra arguments of the kinds that take them (EA = the   \
+   * largest kind_eadim; MSCKF feature tracks: the landmark); augment (T) int32 DEVICE array or NULL: non-zero = MSCKF window \
+   * shift after that step (EKF_sym.augment, ekf_sym.py:365-391,527-528).  Replaces T calls of                              \
+   * EKFSym::predict_and_update_batch (ekf_sym.cc:158-194). */                                                              \
   int RN_FN(name, batch_run)(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts,       \
                              int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags,    \
-                             double *trace_x, double *trace_P, void *stream);                                     \
+                             double *trace_x, double *trace_P, const double *ea, const int32_t *augment,          \
+                             void *stream);                                                                       \
   /* Rauch-Tung-Striebel backward pass over a filtered trace; replaces the Python-only EKF_sym.rts_smooth        \
    * (/root/reference/rednose/helpers/ekf_sym.py:651-690).  xs/Ps may alias xf/Pf.  norm_quats: bit 0 = renormalise the   \
    * recomputed predicted states (as the forward pass did), bit 1 = the reference's norm_quats (smoothed states).       \

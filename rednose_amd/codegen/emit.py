@@ -323,15 +323,15 @@ int {name}_batch_predict_update_{k.kind}(double *x, double *P, const double *Q, 
   zmax = max(k.zdim for k in spec.kinds)
   abi.append(f"int {name}_zmax(void) {{ return {zmax}; }}")
   hdr.append(f"int {name}_zmax(void);")
-  abi.append(f"""int {name}_batch_run(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts, int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, double *trace_x, double *trace_P, void *stream) {{
+  abi.append(f"""int {name}_batch_run(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts, int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, double *trace_x, double *trace_P, const double *ea, const int32_t *augment, void *stream) {{
   RN_REQUIRE(n >= 0 && T >= 0 && x && P && Q && kinds && dts && z && R, rn::ERR_ARG);
   if (n == 0 || T == 0) return rn::OK;
   RN_REQUIRE(rn::aligned16(x) && rn::aligned16(P) && rn::aligned16(z) && rn::aligned16(trace_x) && rn::aligned16(trace_P), rn::ERR_ALIGN);
-{fam_mod.launch_run() if has_run else '  (void)norm_quats; (void)flags; (void)stream; return rn::fail(rn::ERR_UNSUPPORTED, 0, "batch_run: not generated above 32 error states", __LINE__);'}
+{fam_mod.launch_run() if has_run else '  (void)norm_quats; (void)flags; (void)stream; (void)ea; (void)augment; return rn::fail(rn::ERR_UNSUPPORTED, 0, "batch_run: not generated above 32 error states", __LINE__);'}
   {'RN_HIP(hipGetLastError());' if has_run else ''}
   return rn::OK;
 }}""")
-  hdr.append(f"int {name}_batch_run(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts, int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, double *trace_x, double *trace_P, void *stream);")
+  hdr.append(f"int {name}_batch_run(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts, int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, double *trace_x, double *trace_P, const double *ea, const int32_t *augment, void *stream);")
 
   if has_rts:
     if group_rts:

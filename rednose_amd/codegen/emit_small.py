@@ -381,13 +381,15 @@ def run_kernel(spec, norm):
   EE = E * E
   zmax = max(k.zdim for k in spec.kinds)
   cases = []
+  EAM = max([int(sp.Matrix(k.ea_sym).shape[0]) for k in spec.kinds if k.ea_sym is not None] + [0])
   for k in spec.kinds:
     Z = k.zdim
-    if k.ea_sym is not None:
-      continue       # kinds with per-observation extra arguments are not served by the fused run: `default` reports flag 8
-    ea = ""
+    ea, guard = "", ""
+    if k.ea_sym is not None:      # per-filter, per-step extra arguments: the (T, n, EA) array of the entry point (flag 8 without it)
+      ea = f", gea + ((int64_t)t * n + base + (lane < cnt ? lane : 0)) * {EAM}"
+      guard = "          if (gea == nullptr) { fl = 8; break; }\n"
     cases.append(f"""        case {k.kind}: {{
-          double zk[{Z}], Rk[{Z * Z}];
+{guard}          double zk[{Z}], Rk[{Z * Z}];
 #pragma unroll
           for (int i = 0; i < {Z}; i++) zk[i] = z[i];
 #pragma unroll
@@ -402,7 +404,8 @@ def run_kernel(spec, norm):
 __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __restrict__ gP, const double* __restrict__ gQ,
     const int32_t* __restrict__ kinds, const double* __restrict__ dts, const int64_t T, double* __restrict__ gz,
     const double* __restrict__ gR, const int64_t n, const int norm_quats, uint8_t* __restrict__ flags,
-    double* __restrict__ tx, double* __restrict__ tP) {{
+    double* __restrict__ tx, double* __restrict__ tP, const double* __restrict__ gea, const int32_t* __restrict__ augs) {{
+  (void)gea; (void)augs;      // lane-per-filter models are never MSCKF models (those use the lane-group family): no window shift here
   __shared__ __attribute__((aligned(16))) double s_x[64 * {D | 1}];
   __shared__ __attribute__((aligned(16))) double s_P[64 * {EE | 1}];
   __shared__ __attribute__((aligned(16))) double s_z[64 * {zmax | 1}];
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
 def launch_run():
   return """  const int64_t tiles = (n + 63) >> 6;
   hipLaunchKernelGGL(k_run, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
-                     x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P);"""
+                     x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P, ea, augment);"""
 
 
 def launch_predict():

@@ -81,34 +81,81 @@ def predict_fn(spec):
   return "\n".join([head] + _ind(b) + ["}"])
 
 
+EADIM = 3        # extra-argument dimension of feature-track kinds, hard-coded in the reference (ekf_sym.py:151)
+
+
+def ea_dim(k):
+  return 0 if k.ea_sym is None else int(sp.Matrix(k.ea_sym).shape[0])
+
+
 def update_fn(spec, k):
-  D, E, Z = spec.dim_x, spec.dim_err, k.zdim
+  """update_{kind}_wide.  Feature-track kinds of MSCKF models (k.He_sym): residual, H and R go to the left null space of the
+  extra-argument Jacobian (ekf_c.c:66-76) exactly as in the step kernels (emit_wide2._lean_update): Householder reflectors of
+  Hea, applied to y, to the columns of G / Gt and to the rows of He P He^T; everything after that is the ordinary update with
+  Z - EADIM rows.  Here every lane of the group evaluates the scalars (state replicated), so it builds the reflectors itself."""
+  D, E, Zf = spec.dim_x, spec.dim_err, k.zdim
+  feat = k.He_sym is not None
+  Z = Zf - EADIM if feat else Zf
+  EA = ea_dim(k)
   names = dict(vector_names(spec.x_sym, 'x'))
+  names.update(vector_names(k.ea_sym, 'ea'))
   Herr = sp.Matrix(k.H_sym) * sp.Matrix(spec.H_mod_sym)
   blk = Block(names, tmp_prefix="ut")
-  for i in range(Z):
+  for i in range(Zf):
     blk.add(f"hx_{i}", k.h_sym[i])
   fmtH = lambda i, j: f"He_{i}_{j}"  # noqa: E731
-  for i in range(Z):
+  for i in range(Zf):
     for j in range(E):
       blk.add(fmtH(i, j), Herr[i, j])
+  if feat:
+    assert tuple(k.He_sym.shape) == (Zf, EADIM), "feature-track kinds take EADIM = 3 extra arguments (ekf_sym.py:151)"
+    for i in range(Zf):
+      for j in range(EADIM):
+        blk.add(f"Hea_{i}_{j}", k.He_sym[i, j])
   stmts, st = blk.lower()
-  He = SMat.from_structure(Z, E, st, fmtH)
+  He = SMat.from_structure(Zf, E, st, fmtH)
+  val = lambda nm: nm if st[nm][0] == 'expr' else repr(float(st[nm][1] or 0.0))  # noqa: E731
   b = list(stmts)
-  for i in range(Z):
-    kind, val = st[f"hx_{i}"]
-    hx = f"hx_{i}" if kind == 'expr' else repr(float(val))
-    b.append(f"const double y_{i} = z[{i}] - {hx};")
-  for zi in range(Z):
-    nz = He.row_nz(zi)
-    b.append(f"const double G_{zi} = {sum_terms(term(cf, f'col[{kk}]') for kk, cf in nz)};")
-    b.append(f"const double Gt_{zi} = {sum_terms(term(cf, f'row[{kk}]') for kk, cf in nz)};")
+  if feat:
+    b.append(f"double yf[{Zf}] = {{{', '.join(f'z[{i}] - ' + val(f'hx_{i}') for i in range(Zf))}}};")
+    hea = ", ".join(("0.0" if st[f"Hea_{i}_{j}"][0] == 'zero' else ("1.0" if st[f"Hea_{i}_{j}"][0] == 'one' else val(f"Hea_{i}_{j}")))
+                    for i in range(Zf) for j in range(EADIM))
+    b += [f"double Hea[{Zf * EADIM}] = {{{hea}}};", f"double u[{EADIM * Zf}], beta[{EADIM}];",
+          f"const bool ok = rn::householder_qr<{Zf}, {EADIM}>(Hea, u, beta);",
+          f"rn::apply_reflectors<{Zf}, {EADIM}>(u, beta, yf);"]
+    for i in range(Z):
+      b.append(f"const double y_{i} = ok ? yf[{EADIM + i}] : 0.0;")
+    b += [f"double Rm[{Zf * Zf}];", "#pragma unroll", f"for (int i = 0; i < {Zf * Zf}; i++) Rm[i] = Rin[i];",
+          f"rn::project_noise<{Zf}, {EADIM}>(u, beta, Rm);", f"double R[{Z * Z}];"]
+    for a in range(Z):
+      for c in range(Z):
+        b.append(f"R[{a * Z + c}] = Rm[{(EADIM + a) * Zf + EADIM + c}];")
+    b.append(f"double G0[{Zf}] = {{" + ", ".join(sum_terms(term(cf, f'col[{kk}]') for kk, cf in He.row_nz(zi)) for zi in range(Zf)) + "};")
+    b.append(f"double Gt0[{Zf}] = {{" + ", ".join(sum_terms(term(cf, f'row[{kk}]') for kk, cf in He.row_nz(zi)) for zi in range(Zf)) + "};")
+    b.append(f"rn::apply_reflectors<{Zf}, {EADIM}>(u, beta, G0);")
+    b.append(f"rn::apply_reflectors<{Zf}, {EADIM}>(u, beta, Gt0);")
+    for zi in range(Z):
+      b.append(f"const double G_{zi} = G0[{EADIM + zi}], Gt_{zi} = Gt0[{EADIM + zi}];")
+  else:
+    for i in range(Z):
+      b.append(f"const double y_{i} = z[{i}] - {val(f'hx_{i}')};")
+    for zi in range(Z):
+      nz = He.row_nz(zi)
+      b.append(f"const double G_{zi} = {sum_terms(term(cf, f'col[{kk}]') for kk, cf in nz)};")
+      b.append(f"const double Gt_{zi} = {sum_terms(term(cf, f'row[{kk}]') for kk, cf in nz)};")
   b.append("if (act) { " + " ".join(f"sG[{zi} * {E} + cc] = G_{zi};" for zi in range(Z)) + " }")
   b.append("rn::wave_lds_sync();")
   b.append(f"double HPH[{Z * Z}], Rl[{Z * Z}], S[{Z * Z}], L[{Z * Z}], iL[{Z}];")
-  for zi in range(Z):
-    for w in range(Z):
-      b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in He.row_nz(w))};")
+  if feat:
+    for zi in range(Z):
+      b.append("{")
+      b.append(f"  double m[{Zf}] = {{" + ", ".join(sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in He.row_nz(w)) for w in range(Zf)) + "};")
+      b.append(f"  rn::apply_reflectors<{Zf}, {EADIM}>(u, beta, m);")
+      b += ["#pragma unroll", f"  for (int w = 0; w < {Z}; w++) HPH[{zi * Z} + w] = m[{EADIM} + w];", "}"]
+  else:
+    for zi in range(Z):
+      for w in range(Z):
+        b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in He.row_nz(w))};")
   b.append("#pragma unroll")
   b.append(f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}")
   b.append(f"rn::spd_factor<{Z}>(S, L, iL);")
@@ -127,14 +174,19 @@ def update_fn(spec, k):
     b.append("}")
   b.append(f"double kk[{Z}] = {{{', '.join(f'Gt_{zi}' for zi in range(Z))}}};")
   b.append(f"rn::spd_solve<{Z}>(L, iL, kk);                       // K[c][:]")
+  if feat:     # the reference's numpy path ignores a measurement whose null-space projection failed (ekf_sym.py:589-591)
+    b += ["if (!ok) {", "#pragma unroll", f"  for (int i = 0; i < {Z}; i++) kk[i] = 0.0;", "}"]
   b.append("const double dxc = " + " + ".join(f"kk[{zi}]*y_{zi}" for zi in range(Z)) + ";")
   # B row
   b.append("#pragma unroll")
   b.append(f"for (int j = 0; j < {E}; j++) row[j] -= " + " + ".join(f"kk[{zi}]*sG[{zi} * {E} + j]" for zi in range(Z)) + ";")
+  if feat:      # C[c][:] = (B He^T) projected: reflect the Zf-vector of row-local dot products, keep the last Z entries
+    b.append(f"double Cf[{Zf}] = {{" + ", ".join(sum_terms(term(cf, f'row[{j}]') for j, cf in He.row_nz(w)) for w in range(Zf)) + "};")
+    b.append(f"rn::apply_reflectors<{Zf}, {EADIM}>(u, beta, Cf);")
   for zi in range(Z):
-    c = sum_terms(term(cf, f"row[{j}]") for j, cf in He.row_nz(zi))
+    c = f"Cf[{EADIM + zi}]" if feat else sum_terms(term(cf, f"row[{j}]") for j, cf in He.row_nz(zi))
     kr = " + ".join(f"kk[{w}]*Rl[{w * Z + zi}]" for w in range(Z))
-    b.append(f"const double Dm_{zi} = ({kr}) - ({c});")
+    b.append(f"const double Dm_{zi} = " + ("!ok ? 0.0 : " if feat else "") + f"({kr}) - ({c});")
   b.append("if (act) { " + " ".join(f"sK[{zi} * {E} + cc] = kk[{zi}];" for zi in range(Z)) + " sdx[cc] = dxc; }")
   b.append("rn::wave_lds_sync();")
   b.append("#pragma unroll")
@@ -152,21 +204,28 @@ def update_fn(spec, k):
   estmts, est = eblk.lower()
   b += estmts
   for i in range(D):
-    kind, val = est[f"xi_{i}"]
-    b.append(f"x[{i}] = xi_{i};" if kind == 'expr' else f"x[{i}] = {float(val)!r};")
+    kind, v_ = est[f"xi_{i}"]
+    b.append(f"x[{i}] = xi_{i};" if kind == 'expr' else f"x[{i}] = {float(v_)!r};")
   for i in range(Z):
-    b.append(f"z[{i}] = y_{i};")
+    b.append(f"z[{i}] = y_{i};")        # feature kinds: Z - EADIM residual rows, the tail of z is left alone (ekf_c.c:120)
   b.append("rn::wave_lds_sync();      // broadcast buffers are free again")
-  b.append("return gated;")
+  b.append("return gated" + (" | (ok ? 0 : 4);" if feat else ";"))
+  ea_arg = f", const double (&ea)[{EA}]" if EA else ""
+  r_arg = f"const double (&Rin)[{Zf * Zf}]" if feat else f"const double (&R)[{Z * Z}]"
   head = (f"__device__ __forceinline__ int update_{k.kind}_wide(double (&x)[{D}], double (&row)[{E}], const double (&col)[{E}], "
-          f"double (&z)[{Z}], const double (&R)[{Z * Z}], double* sG, double* sK, double* sdx, const int cc, const bool act) {{")
+          f"double (&z)[{Zf}], {r_arg}{ea_arg}, double* sG, double* sK, double* sdx, const int cc, const bool act) {{")
   return "\n".join([head] + _ind(b) + ["}"]), He
 
 
 def run_kinds(spec):
-  """Kinds the fused multi-step run serves: its schedule (kinds[t], dts[t], R[t]) is shared by all filters and carries no
-  per-filter extra arguments, so kinds that take them (MSCKF feature tracks) stay step-granular (flag bit 8 if asked for)."""
-  return [k for k in spec.kinds if k.ea_sym is None]
+  """Kinds the fused multi-step run serves: all of them.  The schedule (kinds[t], dts[t], R[t], augment[t]) is shared by all
+  filters; kinds that take extra arguments (MSCKF feature tracks: the landmark) read them per filter and step from the
+  (T, n, EA) array `ea` of the entry point (flag bit 8 when that array is missing)."""
+  return list(spec.kinds)
+
+
+def ea_max(spec):
+  return max([ea_dim(k) for k in spec.kinds] + [0])
 
 
 def kernels(spec):
@@ -189,20 +248,58 @@ def run_kernel(spec, norm):
   EE = E * E
   DP = _even(D)
   zmax = max(k.zdim for k in spec.kinds)
+  EAM = ea_max(spec)
   cases = []
   for k in run_kinds(spec):
-    Z = k.zdim
+    Zf = k.zdim
+    EA = ea_dim(k)
+    ea_load = ""
+    ea_arg = ""
+    if EA:
+      ea_load = f"""          if (gea == nullptr) {{ fl = 8; break; }}
+          double eak[{EA}];
+#pragma unroll
+          for (int i = 0; i < {EA}; i++) eak[i] = gea[((int64_t)t * n + base + gg) * {EAM} + i];
+"""
+      ea_arg = ", eak"
     cases.append(f"""        case {k.kind}: {{
-          double zk[{Z}], Rk[{Z * Z}];
+{ea_load}          double zk[{Zf}], Rk[{Zf * Zf}];
 #pragma unroll
-          for (int i = 0; i < {Z}; i++) zk[i] = z[i];
+          for (int i = 0; i < {Zf}; i++) zk[i] = z[i];
 #pragma unroll
-          for (int i = 0; i < {Z * Z}; i++) Rk[i] = gR[t * {zmax * zmax} + i];
-          fl = update_{k.kind}_wide(x, row, col, zk, Rk, s_G + gg * {zmax * E}, s_K + gg * {zmax * E}, s_dx + gg * {E}, cc, on);
+          for (int i = 0; i < {Zf * Zf}; i++) Rk[i] = gR[t * {zmax * zmax} + i];
+          fl = update_{k.kind}_wide(x, row, col, zk, Rk{ea_arg}, s_G + gg * {zmax * E}, s_K + gg * {zmax * E}, s_dx + gg * {E}, cc, on);
 #pragma unroll
-          for (int i = 0; i < {Z}; i++) z[i] = zk[i];
+          for (int i = 0; i < {Zf}; i++) z[i] = zk[i];
           break;
         }}""")
+  aug = ""
+  if spec.N > 0:
+    d1, d2, d3, d4 = spec.dim_main, spec.dim_main_err, spec.dim_augment, spec.dim_augment_err
+    src_x = [i if i < d1 else (i + d3 if i < D - d3 else i - (D - d3)) for i in range(D)]
+
+    def se(i):
+      r = i if i < E - d4 else i - (E - d4)
+      return r if r < d2 else r + d4
+    aug = f"""
+      // MSCKF window shift after this step (EKF_sym.augment, ekf_sym.py:365-391; the schedule's augment[t]): a fixed permutation
+      // of the replicated state, and of the rows / columns of P through LDS (the trace above holds the estimate BEFORE the shift,
+      // like the reference's Estimate)
+      if (augs != nullptr && augs[t] != 0) {{
+        double xo[{D}];
+#pragma unroll
+        for (int i = 0; i < {D}; i++) xo[i] = x[i];
+{chr(10).join(f"        x[{i}] = xo[{src_x[i]}];" for i in range(D) if src_x[i] != i)}
+        if (on) {{
+#pragma unroll
+          for (int j = 0; j < {E}; j++) s_P[g * {EE} + c * {E} + j] = row[j];
+        }}
+        rn::wave_lds_sync();
+        const int sr = (cc < {E - d4} ? cc : cc - {E - d4});
+        const int srow = sr < {d2} ? sr : sr + {d4};
+{chr(10).join(f"        row[{j}] = s_P[gg * {EE} + srow * {E} + {se(j)}];" for j in range(E))}
+        rn::wave_lds_sync();
+      }}"""
   # the dt == 0 shortcut below is only emitted for models whose predict(dt = 0) is symbolically the identity
   id0_guard = "" if spec.identity_at_dt0() else "true || "
   return f"""
@@ -210,7 +307,8 @@ def run_kernel(spec, norm):
 __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __restrict__ gP, const double* __restrict__ gQ,
     const int32_t* __restrict__ kinds, const double* __restrict__ dts, const int64_t T, double* __restrict__ gz,
     const double* __restrict__ gR, const int64_t n, const int norm_quats, uint8_t* __restrict__ flags,
-    double* __restrict__ tx, double* __restrict__ tP) {{
+    double* __restrict__ tx, double* __restrict__ tP, const double* __restrict__ gea, const int32_t* __restrict__ augs) {{
+  (void)gea; (void)augs;
   __shared__ __attribute__((aligned(16))) double s_P[FPW * {EE}];
   __shared__ __attribute__((aligned(16))) double s_Q[{EE}];
   __shared__ __attribute__((aligned(16))) double s_x[FPW * {DP}];
@@ -287,7 +385,7 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       if (tP != nullptr) rn::copy_l2g<FPW * {EE}>(tP + (t * n + base) * {EE}, cnt * {EE}, s_P, lane);
       rn::wave_lds_sync();
       if (lane < cnt * {zmax}) s_z[lane] = zn;
-      rn::wave_lds_sync();
+      rn::wave_lds_sync();{aug}
     }}
     if (on) {{
 #pragma unroll
@@ -309,4 +407,4 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
 def launch_run():
   return """  const int64_t tiles = (n + 1) / 2;
   hipLaunchKernelGGL(k_run, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
-                     x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P);"""
+                     x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P, ea, augment);"""

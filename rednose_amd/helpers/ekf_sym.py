@@ -723,7 +723,7 @@ class BatchedEKF:
     return ~(self.maha_dist(kind, z, R, extra_args) > chi2_ppf(maha_thresh, self.zdims[kind]))
 
   # -- fused multi-step run -------------------------------------------------------------------------
-  def run(self, ts, kinds, zs, Rs=None, trace=False, flags=False, out=None, filters=None):
+  def run(self, ts, kinds, zs, Rs=None, trace=False, flags=False, out=None, filters=None, extra_args=None, augment=None):
     """T predict+update steps in ONE launch; x and P stay on chip between steps.
 
     ts (T,) observation times, kinds (T,) observation kinds -- the schedule is shared by all filters;
@@ -734,7 +734,9 @@ class BatchedEKF:
     out = (trace_x, trace_P): preallocated contiguous float64 device tensors for the trace (implies trace=True; a 16 384 x
     210-step live trace is 14 GB -- callers that repeat a run reuse one allocation instead of paying a fresh one each time).
     filters = (lo, hi): run only filters lo .. hi-1 of the batch (their x / P records are contiguous); N above is then
-    hi - lo.  Returns (ys, trace_x, trace_P, flags) with None for outputs not requested.
+    hi - lo.  extra_args (T, N, EA): per filter and step extra arguments for the kinds that take them (MSCKF feature tracks:
+    the landmark; rows of other kinds are ignored); augment (T,) bool: MSCKF window shift after that step.
+    Returns (ys, trace_x, trace_P, flags) with None for outputs not requested.
     """
     torch = self._torch
     ts = np.asarray(ts, dtype=np.float64)
@@ -747,9 +749,8 @@ class BatchedEKF:
     for k in set(kinds.tolist()):
       if k not in self.zdims:
         raise KeyError(k)
-      if self.eadims.get(k, 0):
-        raise KalmanError(f"kind {k} takes per-observation extra arguments: use predict_and_update_batch (the fused run's "
-                          "schedule is shared by all filters)")
+      if self.eadims.get(k, 0) and extra_args is None:
+        raise KalmanError(f"kind {k} takes per-observation extra arguments: pass extra_args (T, N, {self.eadims[k]})")
     assert not isinstance(self.filter_time, torch.Tensor), "bring the filters to a common time first (predict(t))"
     t0 = self.filter_time if self.filter_time is not None else ts[0]
     dts = np.diff(np.concatenate([[t0], ts]))
@@ -779,10 +780,20 @@ class BatchedEKF:
     if nb == 0:
       return zs, tx, tP, fl
     xv, Pv = self.x[lo:hi], self.P[lo:hi]          # contiguous views: record lo starts 16-byte aligned whenever record 0 does
+    ead = max(list(self.eadims.values()) + [0])
+    ea = None if extra_args is None else self._dev(extra_args, (T, nb, ead))
+    ag = None
+    if augment is not None:
+      assert self.msckf, "augment: MSCKF models only"
+      ag = torch.as_tensor(np.asarray(augment, dtype=np.int32).reshape(T), device=self.device)
     self._call("batch_run", self._p(xv), self._p(Pv), self._p(self.Q), self._p(kd), self._p(dd), T, self._p(zs),
-               self._p(Rd), nb, self.norm_quats, self._p(fl), self._p(tx), self._p(tP), self._stream())
+               self._p(Rd), nb, self.norm_quats, self._p(fl), self._p(tx), self._p(tP), self._p(ea), self._p(ag), self._stream())
+    if ag is not None and self.msckf:
+      for t_, a_ in zip(ts, np.asarray(augment).reshape(T)):
+        if a_:
+          self.augment_times = self.augment_times[1:] + [float(t_)]
     self.filter_time = float(ts[-1])
-    self._keepalive = (kd, dd, Rd)      # the launch is asynchronous: keep its inputs alive
+    self._keepalive = (kd, dd, Rd, ea, ag)      # the launch is asynchronous: keep its inputs alive
     return zs, tx, tP, fl
 
   # -- offline smoothing ----------------------------------------------------------------------------

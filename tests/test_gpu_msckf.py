@@ -142,11 +142,11 @@ def test_scalar_abi_feature_update(env):
 
 
 def test_unsupported_entry_points_fail_loudly(env):
-  """Feature-track kinds are step-granular only: the fused run must raise, not mis-compute."""
+  """A feature-track kind without its extra arguments must raise, not mis-compute."""
   torch, gen, FK = env
   from rednose_amd.helpers import KalmanError
   f = _filter(env, 4)
-  with pytest.raises(KalmanError):
+  with pytest.raises(KalmanError):          # the landmark is missing
     f.run(np.array([0.1]), np.array([2], dtype=np.int32), np.zeros((1, 4, 6)), {2: FK.obs_noise[2]})
   with pytest.raises(KalmanError):
     f.update(2, np.zeros((4, 6)), FK.obs_noise[2])              # extra arguments missing
@@ -178,3 +178,45 @@ def test_smoother_main_block_vs_reference(env, inplace):
   d1 = 6
   assert np.array_equal(X[:-1, 0, d1:], g["xk_k"][:-1, d1:])
   assert np.array_equal(P[:-1, 0, d1:, :], g["Pk_k"][:-1, d1:, :]) and np.array_equal(P[:-1, 0, :, d1:], g["Pk_k"][:-1, :, d1:])
+
+
+def test_fused_run_with_landmarks_and_window_shifts(env):
+  """The whole MSCKF stream of the reference's numpy path -- POSITION fixes followed by a window shift, FEATURE tracks with their
+  per-observation landmark -- in ONE {name}_batch_run launch: extra arguments per filter and step, augment flags in the
+  schedule.  Filtered trace (the estimate before each shift, like the reference's Estimate), final state after the last shift,
+  projected residual norms.  Above 32 error states the library has no fused run: status 4."""
+  torch, gen, FK = env
+  from rednose_amd.helpers import KalmanError
+  g = _gold(env)
+  n = 9
+  f = _filter(env, n)
+  kinds, ts = g["kinds"].astype(np.int32), g["ts"]
+  T = len(kinds)
+  zs = np.tile(g["zs"][:, None, :], (1, n, 1))
+  eas = np.tile(g["eas"][:, None, :], (1, n, 1))
+  Rs = {1: FK.obs_noise[1], 2: FK.obs_noise[2]}
+  if FK.dim_state > 32:
+    with pytest.raises(KalmanError):
+      f.run(ts, kinds, zs.copy(), Rs, extra_args=eas, augment=g["augment"])
+    return
+  ys, tx, tP, fl = f.run(ts, kinds, zs.copy(), Rs, trace=True, flags=True, extra_args=eas, augment=g["augment"])
+  torch.cuda.synchronize()
+  X, P, Y = tx.cpu().numpy(), tP.cpu().numpy(), ys.cpu().numpy()
+  assert not fl.cpu().numpy().any()
+  for j in (0, n - 1):
+    assert_close(X[:, j], g["xk_k"], rtol=1e-8, floor=1e-10, what="fused MSCKF run, filtered states")
+    assert_close(P[:, j].reshape(T, -1), g["Pk_k"].reshape(T, -1), rtol=1e-7, floor=1e-9, what="fused MSCKF run, filtered covariances")
+    assert_close(f.state()[j], g["x_after"][-1], rtol=1e-8, floor=1e-10, what="state after the last window shift")
+    assert_close(f.covs()[j].reshape(1, -1), g["P_after"][-1].reshape(1, -1), rtol=1e-7, floor=1e-9)
+  feat = kinds == 2
+  assert_close(np.linalg.norm(Y[feat, 0, :3], axis=1), np.linalg.norm(g["ys"][feat, :3], axis=1), rtol=1e-7, what="|projected residual|")
+  assert_close(Y[~feat, 0, :3], g["ys"][~feat, :3], rtol=1e-8, atol=1e-10)
+  assert f.get_augment_times()[-1] == float(ts[np.where(g["augment"])[0][-1]])
+  # and the same schedule step by step gives the same estimates
+  s = _filter(env, n)
+  for t in range(T):
+    s.predict_and_update_batch(float(ts[t]), int(kinds[t]), zs[t, :, :FK.obs_noise[int(kinds[t])].shape[0]].copy(), Rs[int(kinds[t])],
+                               extra_args=eas[t] if kinds[t] == 2 else None, augment=bool(g["augment"][t]))
+  torch.cuda.synchronize()
+  assert_close(s.state(), f.state(), rtol=1e-9, floor=1e-11)
+  assert_close(s.covs().reshape(n, -1), f.covs().reshape(n, -1), rtol=1e-8, floor=1e-10)

@@ -120,8 +120,8 @@ def test_degenerate_sizes(env):
   kd = torch.ones(1, dtype=torch.int32, device=f.device); dd = torch.zeros(1, dtype=torch.float64, device=f.device)
   zz = torch.zeros((1, 5, 3), dtype=torch.float64, device=f.device); Rd = torch.eye(3, dtype=torch.float64, device=f.device).reshape(1, 9).contiguous()
   x_before = f.state().copy()
-  assert lib.kinematic6_batch_run(p(f.x), p(f.P), p(f.Q), p(kd), p(dd), 0, p(zz), p(Rd), 5, 0, None, None, None, None) == 0     # T = 0
-  assert lib.kinematic6_batch_run(p(f.x), p(f.P), p(f.Q), p(kd), p(dd), 1, p(zz), p(Rd), 0, 0, None, None, None, None) == 0     # n = 0
+  assert lib.kinematic6_batch_run(p(f.x), p(f.P), p(f.Q), p(kd), p(dd), 0, p(zz), p(Rd), 5, 0, None, None, None, None, None, None) == 0     # T = 0
+  assert lib.kinematic6_batch_run(p(f.x), p(f.P), p(f.Q), p(kd), p(dd), 1, p(zz), p(Rd), 0, 0, None, None, None, None, None, None) == 0     # n = 0
   torch.cuda.synchronize()
   assert np.array_equal(f.state(), x_before)
   # the Python wrapper treats an empty schedule the same way (no IndexError on ts[0] / ts[-1])
