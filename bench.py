@@ -322,10 +322,10 @@ def fused_run_extra(torch, model, n, T, dev):
                   "the count is every v_*_f64 instruction of the kernel (llvm-objdump), an upper bound of the per-step loop body"}
 
 
-def config4_extra(torch, dev, rank, nb=16384, T=2100, chunk=4096):
+def config4_extra(torch, dev, rank, nb=16384, T=2100, chunk=8192):
   """BASELINE config 4 at its stated size: live with the Mahalanobis gate on ECEF_POS, 2 % GNSS outliers, forward pass keeping
   the filtered trace, RTS backward pass -- swept in chunks of `chunk` filters (the trace of a chunk is T x chunk x 4 056 B:
-  35 GB at 4 096 -- 2 048 tiles, two wavefronts on every SIMD; filters are independent, the result is that of one sweep).  The trace buffers are allocated once, outside
+  70 GB at 8 192 -- 1 024 wavefronts of 8 filters, one on every SIMD; filters are independent, the result is that of one sweep).  The trace buffers are allocated once, outside
   the timed region; forward and backward times are the sums of per-chunk HIP-event intervals."""
   from examples.live_kf import LiveKalman as L
   from rednose_amd.helpers.ekf_sym import BatchedEKF

@@ -92,17 +92,18 @@ def _emit(spec):
   import types
   from rednose_amd.codegen import tuning
   if fam == "wide":
-    from rednose_amd.codegen import emit_wide, emit_wide2
+    from rednose_amd.codegen import emit_wide2, emit_wide3
     if not has_run:
       fam_mod = types.SimpleNamespace(
         kernels=lambda sp_: emit_wide2.kernels(sp_) + "\n" + emit_wide2.maha_kernels(sp_),
         launch_predict=emit_wide2.launch_predict, launch_step=emit_wide2.launch_step, launch_run=None,
         launch_maha=emit_wide2.launch_maha)
     else:
-      # step-granular kernels: three-phase structure (emit_wide2); fused multi-step run: state-resident structure (emit_wide)
+      # step-granular kernels: three-phase structure (emit_wide2); fused multi-step run: state resident in registers, several
+      # rows of P per lane (emit_wide3)
       fam_mod = types.SimpleNamespace(
-        kernels=lambda sp_: emit_wide.kernels(sp_) + "\n" + emit_wide2.kernels(sp_) + "\n" + emit_wide2.maha_kernels(sp_),
-        launch_predict=emit_wide2.launch_predict, launch_step=emit_wide2.launch_step, launch_run=emit_wide.launch_run,
+        kernels=lambda sp_: emit_wide2.kernels(sp_) + "\n" + emit_wide3.kernels(sp_) + "\n" + emit_wide2.maha_kernels(sp_),
+        launch_predict=emit_wide2.launch_predict, launch_step=emit_wide2.launch_step, launch_run=emit_wide3.launch_run,
         launch_maha=emit_wide2.launch_maha)
   else:
     fam_mod = types.SimpleNamespace(

@@ -20,6 +20,8 @@ The algebra and its order are unchanged (see emit_wide.py / emit_small.py docstr
 scalars changed.  Results agree with the first structure to rounding (different instruction streams contract
 FMAs differently), which tests/test_gpu_run.py bounds.
 """
+import re
+
 import sympy as sp
 
 from rednose_amd.codegen import tuning
@@ -241,12 +243,14 @@ def _lean_update(k, Hs, lay, E, rows_in_regs=False):
   return b
 
 
-def device_functions(spec):
+def device_functions(spec, lay_cls=None, sfx=""):
+  """Phase functions of the three-phase kernels -> (text, slot layout).  With `lay_cls` / `sfx` only the scalar phases are
+  emitted, against another slot layout and under suffixed names (the fused run keeps a more compact slot, emit_wide3)."""
   D, E = spec.dim_x, spec.dim_err
   INL = "__forceinline__" if tuning.current().wide_inline else "__noinline__"
   pst, pstruct, F, f_vars = _lowered_predict(spec)
   obs = {k.kind: _lowered_obs(spec, k) for k in spec.kinds}
-  lay = Layout(spec, f_vars, {kk: v[3] for kk, v in obs.items()})
+  lay = (lay_cls or Layout)(spec, f_vars, {kk: v[3] for kk, v in obs.items()})
   out = []
 
   # ---- phase 1: scalars of predict ---------------------------------------------------------------
@@ -256,20 +260,31 @@ def device_functions(spec):
   quat = "".join(f" rn::normalize_quat<{D}>(x, {q});" for q in spec.quaternion_idxs)
   normq = f"if (norm_quats) {{{quat} }}" if spec.quaternion_idxs else "(void)norm_quats;"
   b = [f"double x[{D}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = xin[i];"]
-  b += list(pst)
+  # every non-trivial entry of F goes to the slot as soon as it exists (short live ranges: a dense F is hundreds of values)
+  f_at = {v: i for i, v in enumerate(f_vars)}
+  stored = set()
+  for st_ in pst:
+    b.append(st_)
+    mm = re.match(r"\s*const double (\w+) =", st_)
+    if mm and mm.group(1) in f_at:
+      b.append(f"sl[{lay.OFF_F + f_at[mm.group(1)]}] = {mm.group(1)};")
+      stored.add(mm.group(1))
+      if len(stored) % 32 == 0:
+        b.append("rn::wave_lds_sync();      // (a scheduling boundary: keeps hipcc from computing everything before storing anything)")
   for i, v in enumerate(f_vars):
-    b.append(f"sl[{lay.OFF_F + i}] = {v};")
+    if v not in stored:
+      b.append(f"sl[{lay.OFF_F + i}] = {v};")
   for i in range(D):
     kind, val = pstruct[f"xn_{i}"]
     b.append(f"x[{i}] = xn_{i};" if kind == 'expr' else f"x[{i}] = {float(val)!r};")
   b.append(normq)
   b.append(f"sl[{lay.OFF_DT}] = dt;")
   b += ["#pragma unroll", f"for (int i = 0; i < {D}; i++) sl[{lay.OFF_X} + i] = x[i];"]
-  out.append("\n".join(["__device__ {INL} void scal_predict(const double* xin, const double dt, double* sl, const int norm_quats) {"] + _ind(b) + ["}"]))
+  out.append("\n".join(["__device__ {INL} void scal_predict" + sfx + "(const double* xin, const double dt, double* sl, const int norm_quats) {"] + _ind(b) + ["}"]))
 
   b = [f"double x[{D}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = xin[i];", normq,
        "#pragma unroll", f"for (int i = 0; i < {D}; i++) sl[{lay.OFF_X} + i] = x[i];"]
-  out.append("\n".join(["__device__ {INL} void scal_keep(const double* xin, double* sl, const int norm_quats) {"] + _ind(b) + ["}"]))
+  out.append("\n".join(["__device__ {INL} void scal_keep" + sfx + "(const double* xin, double* sl, const int norm_quats) {"] + _ind(b) + ["}"]))
 
   # ---- phase 1: scalars of each observation kind ---------------------------------------------------
   for k in spec.kinds:
@@ -310,7 +325,7 @@ def device_functions(spec):
             "} else {", "#pragma unroll", f"  for (int i = 0; i < {Z}; i++) sl[{lay.OFF_Y} + i] = y[i];", "}"]
     tmpl = "template <bool PROJECT>\n" if feat else ""
     sig = "double* sl, const double* zin" + (", const double* eain" if EA else "") + (", const double* gRf" if feat else "")
-    out.append("\n".join([f"{tmpl}__device__ {{INL}} void scal_obs_{k.kind}({sig}) {{"] + _ind(b) + ["}"]))
+    out.append("\n".join([f"{tmpl}__device__ {{INL}} void scal_obs_{k.kind}{sfx}({sig}) {{"] + _ind(b) + ["}"]))
 
   # ---- phase 3: error injection ----------------------------------------------------------------------
   nom, delta = spec.err_eqs[1], spec.err_eqs[2]
@@ -328,7 +343,9 @@ def device_functions(spec):
   b.append(normq)
   b += ["#pragma unroll", f"for (int i = 0; i < {D}; i++) xout[i] = x[i];", "double acc = 0.0;", "#pragma unroll",
         f"for (int i = 0; i < {D}; i++) acc += x[i];", "return (acc - acc == 0.0) ? 0 : 2;"]
-  out.append("\n".join(["__device__ {INL} int scal_inject(const double* sl, double* xout, const int norm_quats) {"] + _ind(b) + ["}"]))
+  out.append("\n".join(["__device__ {INL} int scal_inject" + sfx + "(const double* sl, double* xout, const int norm_quats) {"] + _ind(b) + ["}"]))
+  if lay_cls is not None:
+    return "\n\n".join(out).replace("{INL}", INL), lay
 
   # ---- phase 2: predict, matrix part (P in sP -> P' in sP) ------------------------------------------------
   Fs = _slotted(F, f_vars, lay.OFF_F)

@@ -1,0 +1,418 @@
+"""Kernel family W, fused multi-step run `k_run`: state resident in registers, SEVERAL ROWS PER LANE.
+
+The first version of this kernel (round 1) gave every filter a 32-lane group, one row of P per lane, and evaluated the
+x-dependent scalars (f, F, h, H.H_mod, err_fun: ~1 600 instructions for live's accelerometer kind) in every lane of the
+group -- per wavefront that is the same instruction count whether 2 or 8 filters share it, so with 2 filters per
+wavefront the scalars alone cost 3 us per step, the rank-Z passes ran at 22 busy lanes of 32, each FMA fetched one
+broadcast operand from LDS, and the kernel needed 256 + 166 registers with a thousand AGPR moves: 343 M steps/s on
+live, SLOWER per step than one launch per step.
+
+Here a filter gets GL = 8 lanes (16 above 22 error states) and lane c owns rows c, c + GL, c + 2 GL ... of P
+(R = ceil(E / GL) rows per lane), so a wavefront carries 8 (4) filters:
+  * the scalar block is amortised over 4x as many filters;
+  * every broadcast operand of the rank-Z passes (a row of G or K^T from LDS) feeds R FMAs instead of one;
+  * live: 22 of 24 row slots busy instead of 22 of 32 lanes.
+P lives in registers as rows only (R x E doubles per lane: 132 VGPRs for live); LDS holds one E x E image per filter
+that serves the two transpositions of predict, the column entries G needs, the window shift of MSCKF models and the
+trace output, plus one Z x E buffer shared by G and K^T.
+
+  predict (ekf_c.c:8-33)   a = F row (row-local, straight to the LDS image) -> column view -> P' = F a + dt Q written back in
+                           place (a lane rewrites only its own columns) -> rows re-read
+  update  (ekf_c.c:37-121) as in emit_wide2 / emit_small (Joseph form with its rank-Z structure), per row slot; S is factored
+                           redundantly per lane; feature-track kinds project on the null space of the extra-argument Jacobian
+                           with Householder reflectors (ekf_c.c:66-76)
+The arithmetic and its order per entry are those of the other kernels of the family (same generated sums), so results agree
+with the step-granular path to rounding; tests/test_gpu_run.py, test_gpu_random.py, test_gpu_msckf.py bound it.
+"""
+import sympy as sp
+
+from rednose_amd.codegen.emit_common import term, sum_terms
+
+EADIM = 3        # extra-argument dimension of feature-track kinds, hard-coded in the reference (ekf_sym.py:151)
+
+
+def _ind(lines, n=2):
+  pad = " " * n
+  return [pad + s for s in lines]
+
+
+def _even(n):
+  return n + (n & 1)
+
+
+def ea_dim(k):
+  return 0 if k.ea_sym is None else int(sp.Matrix(k.ea_sym).shape[0])
+
+
+def ea_max(spec):
+  return max([ea_dim(k) for k in spec.kinds] + [0])
+
+
+def layout(spec):
+  """-> (GL lanes per filter, R rows per lane, FPW filters per wavefront).  8 lanes while 8 covariance images fit the LDS
+  budget of a wavefront (E <= 22), 16 above."""
+  E = spec.dim_err
+  GL = 8 if E <= 22 else 16
+  return GL, -(-E // GL), 64 // GL
+
+
+def _rank_pass(E, Z, R, src, op, coef, JB=2):
+  """Straight-line rank-Z pass over the register rows: row_s[j] op= sum_z coef_s[z] * src[z][j] for all j, in blocks of JB
+  columns.  The broadcast operands of block b + 1 are loaded before the FMAs of block b and a compiler fence closes every
+  block, so one block of loads is in flight under the arithmetic and no more: left to itself hipcc issues all Z*E LDS loads
+  first (2*Z*E registers on top of the rows -> hundreds of spills)."""
+  out = []
+  blocks = [list(range(j, min(j + JB, E))) for j in range(0, E, JB)]
+
+  def loads(bl):
+    return [f"const double q_{zi}_{j} = {src}[{zi} * {E} + {j}];" for j in bl for zi in range(Z)]
+  out += loads(blocks[0])
+  for bi, bl in enumerate(blocks):
+    if bi + 1 < len(blocks):
+      out += loads(blocks[bi + 1])
+    for j in bl:
+      for s in range(R):
+        out.append(f"row{s}[{j}] {op} " + " + ".join(f"{coef}{s}[{zi}]*q_{zi}_{j}" for zi in range(Z)) + f"; rn::pin(row{s}[{j}]);")
+    out.append("rn::wave_lds_sync();")
+  return ["{"] + _ind(out) + ["}"]
+
+
+class RunLayout:
+  """Per-filter scalar slot of the fused run (doubles).  Same fields as emit_wide2.Layout, packed by lifetime so that eight
+  filters of a 22-state model, their covariance images and the G / K^T buffers stay under 40 KB (4 wavefronts per CU):
+  the non-trivial entries of F (dead once predict's matrix phase is through), those of He = H H_mod (written after that, dead
+  once the Joseph-form coefficients exist) and dx (written after that) share one region; x lives ONLY here (no separate
+  copy), and z comes in / y goes out through the Y field."""
+
+  def __init__(self, spec, f_vars, he_vars_by_kind):
+    D, E = spec.dim_x, spec.dim_err
+    self.zmax = max(k.zdim for k in spec.kinds)
+    self.nf = len(f_vars)
+    self.nh = max([len(v) for v in he_vars_by_kind.values()] + [0])
+    self.OFF_X = 0
+    self.OFF_F = self.OFF_HE = self.OFF_DX = D
+    self.OFF_Y = D + max(self.nf, self.nh, E)
+    self.OFF_DT = self.OFF_Y + self.zmax
+    self.OFF_FL = self.OFF_DT + 1
+    feat = [k for k in spec.kinds if k.He_sym is not None]
+    self.zf = max([k.zdim for k in feat] + [0])
+    self.OFF_RF = self.OFF_FL + 1
+    self.OFF_RP = self.OFF_RF + (EADIM * self.zf + EADIM if feat else 0)
+    n = self.OFF_RP + ((self.zf - EADIM) ** 2 if feat else 0)
+    self.SLOT = n + 1 - (n & 1)      # odd stride, as in the step kernels
+
+
+def _tables(spec):
+  """Slot layout and slot-addressed coefficient matrices; the phase-1 / phase-3 functions are emit_wide2's, instantiated
+  against RunLayout under the suffix _r."""
+  from rednose_amd.codegen import emit_wide2 as w2
+  _, _, F, f_vars = w2._lowered_predict(spec)                  # pylint: disable=protected-access
+  obs = {k.kind: w2._lowered_obs(spec, k) for k in spec.kinds}  # pylint: disable=protected-access
+  lay = RunLayout(spec, f_vars, {kk: v[3] for kk, v in obs.items()})
+  Fs = w2._slotted(F, f_vars, lay.OFF_F)                        # pylint: disable=protected-access
+  Hs = {kk: w2._slotted(v[2], v[3], lay.OFF_HE) for kk, v in obs.items()}   # pylint: disable=protected-access
+  return lay, Fs, Hs
+
+
+def predict_fn(spec):
+  """Matrix part of predict on register rows; F's non-trivial entries are broadcast reads of the filter's slot."""
+  E = spec.dim_err
+  GL, R, _ = layout(spec)
+  lay, Fs, _ = _tables(spec)
+  b = [f"const double dt = sl[{lay.OFF_DT}];"]
+  # a = F row, row-local, each entry straight to the LDS image (row rr of P F^T)
+  for s in range(R):
+    b.append(f"if (ok{s}) {{")
+    for i in range(E):
+      b.append(f"  sP[rr{s} * {E} + {i}] = {sum_terms(term(cf, f'row{s}[{k}]') for k, cf in Fs.row_nz(i))};")
+    b.append("}")
+  b.append("rn::wave_lds_sync();")
+  # column view: this lane's columns of P F^T; P' = F (P F^T) + dt Q, written back in place (own columns only)
+  for s in range(R):
+    b.append("{")
+    b.append(f"  double a[{E}];")
+    b.append("#pragma unroll")
+    b.append(f"  for (int k = 0; k < {E}; k++) a[k] = sP[k * {E} + rc{s}];")
+    for i in range(E):
+      b.append(f"  {{ const double v = {sum_terms(term(cf, f'a[{k}]') for k, cf in Fs.row_nz(i))} + dt*gQ[{i * E} + rc{s}]; if (ok{s}) sP[{i * E} + rr{s}] = v; }}")
+    b.append("}")
+  b.append("rn::wave_lds_sync();")
+  for s in range(R):
+    b += ["#pragma unroll", f"for (int j = 0; j < {E}; j++) row{s}[j] = sP[rc{s} * {E} + j];"]
+  rows = ", ".join(f"double (&row{s})[{E}]" for s in range(R))
+  idx = ", ".join(f"const int rr{s}, const int rc{s}, const bool ok{s}" for s in range(R))
+  head = (f"__device__ __forceinline__ void predict_rows({rows}, double* sP, const double* __restrict__ gQ, const double* sl, {idx}) {{")
+  return "\n".join([head] + _ind(b) + ["}"])
+
+
+def update_fn(spec, k):
+  """Matrix part of the update of kind k on register rows.  y, the non-trivial entries of He = H H_mod and, for feature-track
+  kinds, the Householder reflectors and the projected noise are read from the filter's slot (phase 1 put them there); dx and
+  the gate / rank flags go back to it."""
+  E, Zf = spec.dim_err, k.zdim
+  GL, R, _ = layout(spec)
+  lay, _, Hss = _tables(spec)
+  Hs = Hss[k.kind]
+  feat = k.He_sym is not None
+  Z = Zf - EADIM if feat else Zf
+  used = sorted({kk for zi in range(Zf) for kk, _ in Hs.row_nz(zi)})
+  RF, RB = lay.OFF_RF, lay.OFF_RF + EADIM * Zf
+  b = [f"double R[{Z * Z}];"]
+  if feat:
+    b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) R[i] = sl[{lay.OFF_RP} + i];      // A^T R A (phase 1)", "(void)gR;",
+          f"const double rank_deficient = sl[{lay.OFF_FL}];      // 4.0 when phase 1 found Hea rank deficient"]
+  else:
+    b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) R[i] = gR[i];"]
+  # G (this lane's columns, from the LDS image of P) per row slot, straight to the broadcast buffer; the row view Gt = rows . He^T
+  # is formed after the factorisation, right before it is solved into K
+  for s in range(R):
+    b.append("{")
+    b += [f"  const double c_{kk} = sP[{kk} * {E} + rc{s}];" for kk in used]
+    if feat:
+      b.append(f"  double g0[{Zf}] = {{" + ", ".join(sum_terms(term(cf, f'c_{kk}') for kk, cf in Hs.row_nz(zi)) for zi in range(Zf)) + "};")
+      b.append(f"  rn::apply_reflectors<{Zf}, {EADIM}>(sl + {RF}, sl + {RB}, g0);")
+      b.append(f"  if (ok{s}) {{ " + " ".join(f"sG[{zi} * {E} + rr{s}] = g0[{EADIM + zi}];" for zi in range(Z)) + " }")
+    else:
+      b.append(f"  if (ok{s}) {{")
+      for zi in range(Z):
+        b.append(f"    sG[{zi} * {E} + rr{s}] = {sum_terms(term(cf, f'c_{kk}') for kk, cf in Hs.row_nz(zi))};")
+      b.append("  }")
+    b.append("}")
+  b.append("rn::wave_lds_sync();")
+  b.append(f"double HPH[{Z * Z}], Rl[{Z * Z}], S[{Z * Z}], L[{Z * Z}], iL[{Z}];")
+  if feat:
+    for zi in range(Z):
+      b.append("{")
+      b.append(f"  double m[{Zf}] = {{" + ", ".join(sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w)) for w in range(Zf)) + "};")
+      b.append(f"  rn::apply_reflectors<{Zf}, {EADIM}>(sl + {RF}, sl + {RB}, m);")
+      b += ["#pragma unroll", f"  for (int w = 0; w < {Z}; w++) HPH[{zi * Z} + w] = m[{EADIM} + w];", "}"]
+  else:
+    for zi in range(Z):
+      for w in range(Z):
+        b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))};")
+  b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}", f"rn::spd_factor<{Z}>(S, L, iL);",
+        "int gated = 0;"]
+  if k.maha_test:
+    b += ["{", f"  double v[{Z}] = {{{', '.join(f'sl[{lay.OFF_Y + i}]' for i in range(Z))}}};", f"  rn::spd_forward<{Z}>(L, iL, v);",
+          "  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";", f"  if (d2 > {k.maha_thresh!r}) {{", "    gated = 1;",
+          "#pragma unroll", f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}",
+          f"    rn::spd_factor<{Z}>(S, L, iL);", "  }", "}"]
+  for s in range(R):
+    if feat:
+      b.append(f"double t0_{s}[{Zf}] = {{" + ", ".join(sum_terms(term(cf, f'row{s}[{kk}]') for kk, cf in Hs.row_nz(zi)) for zi in range(Zf)) + "};")
+      b.append(f"rn::apply_reflectors<{Zf}, {EADIM}>(sl + {RF}, sl + {RB}, t0_{s});")
+      b.append(f"double kk{s}[{Z}] = {{{', '.join(f't0_{s}[{EADIM + zi}]' for zi in range(Z))}}};")
+    else:
+      b.append(f"double kk{s}[{Z}] = {{" + ", ".join(sum_terms(term(cf, f'row{s}[{kk}]') for kk, cf in Hs.row_nz(zi)) for zi in range(Z)) + "};")
+    b.append(f"rn::spd_solve<{Z}>(L, iL, kk{s});                       // K[row][:]")
+    if feat:     # the reference's numpy path ignores a measurement whose null-space projection failed (ekf_sym.py:589-591)
+      b += ["if (rank_deficient != 0.0) {", "#pragma unroll", f"  for (int i = 0; i < {Z}; i++) kk{s}[i] = 0.0;", "}"]
+    b.append(f"const double dx{s} = " + " + ".join(f"kk{s}[{zi}]*sl[{lay.OFF_Y + zi}]" for zi in range(Z)) + ";")
+  # B = P - K G: every broadcast row of G feeds all R row slots
+  b += _rank_pass(E, Z, R, "sG", "-=", "kk")
+  for s in range(R):
+    if feat:
+      b.append(f"double Cf{s}[{Zf}] = {{" + ", ".join(sum_terms(term(cf, f'row{s}[{j}]') for j, cf in Hs.row_nz(w)) for w in range(Zf)) + "};")
+      b.append(f"rn::apply_reflectors<{Zf}, {EADIM}>(sl + {RF}, sl + {RB}, Cf{s});")
+    b.append(f"double Dm{s}[{Z}];")
+    for zi in range(Z):
+      c = f"Cf{s}[{EADIM + zi}]" if feat else sum_terms(term(cf, f"row{s}[{j}]") for j, cf in Hs.row_nz(zi))
+      kr = " + ".join(f"kk{s}[{w}]*Rl[{w * Z + zi}]" for w in range(Z))
+      b.append(f"Dm{s}[{zi}] = " + ("rank_deficient != 0.0 ? 0.0 : " if feat else "") + f"({kr}) - ({c});")
+  b.append("rn::wave_lds_sync();      // every lane has taken G (and y): the buffer takes K^T, the slot takes dx and the flags")
+  fl = "(double)gated + rank_deficient" if feat else "(double)gated"
+  for s in range(R):
+    b.append(f"if (ok{s}) {{ " + " ".join(f"sG[{zi} * {E} + rr{s}] = kk{s}[{zi}];" for zi in range(Z)) + f" sw[{lay.OFF_DX} + rr{s}] = dx{s};" +
+             (f" if (rr{s} == 0) sw[{lay.OFF_FL}] = {fl};" if s == 0 else "") + " }")
+  b.append("rn::wave_lds_sync();")
+  b += _rank_pass(E, Z, R, "sG", "+=", "Dm")
+  # the LDS image follows the registers (column reads of the next update, trace, window shift)
+  for s in range(R):
+    b += [f"if (ok{s}) {{", "#pragma unroll", f"  for (int j = 0; j < {E}; j++) sP[rr{s} * {E} + j] = row{s}[j];", "}"]
+  b.append("rn::wave_lds_sync();      // the image is complete, the broadcast buffer is free again")
+  rows = ", ".join(f"double (&row{s})[{E}]" for s in range(R))
+  idx = ", ".join(f"const int rr{s}, const int rc{s}, const bool ok{s}" for s in range(R))
+  head = (f"__device__ __forceinline__ void update_{k.kind}_rows({rows}, const double* __restrict__ gR, double* sP, double* sG, const double* sl, "
+          f"double* sw, {idx}) {{")
+  return "\n".join([head] + _ind(b) + ["}"])
+
+
+def kernels(spec):
+  """Matrix-phase device functions + the fused multi-step kernel (the phase-1 / phase-3 functions are emit_wide2's, which must
+  precede this text in the generated file)."""
+  from rednose_amd.codegen import emit_wide2 as w2
+  GL, R, FPW = layout(spec)
+  scal_text, lay = w2.device_functions(spec, lay_cls=RunLayout, sfx="_r")
+  out = [f"constexpr int GLR = {GL};    // fused run: lanes per filter", f"constexpr int RPL = {R};    // rows of P per lane",
+         f"constexpr int FPWR = {FPW};   // filters per wavefront", f"constexpr int SLOT_R = {lay.SLOT};   // fused run: doubles per scalar slot",
+         "", scal_text, "", predict_fn(spec)]
+  for k in spec.kinds:
+    out.append(update_fn(spec, k))
+  out.append(run_kernel(spec))
+  return "\n".join(out)
+
+
+def run_kernel(spec):
+  D, E = spec.dim_x, spec.dim_err
+  EE = E * E
+  GL, R, FPW = layout(spec)
+  lay, _, _ = _tables(spec)
+  zmax = max(k.zdim for k in spec.kinds)
+  assert FPW * zmax <= 64, "the observation prefetch of the fused run takes one value per lane"
+  EAM = ea_max(spec)
+  rows = ", ".join(f"row{s}" for s in range(R))
+  idx = ", ".join(f"rr{s}, rc{s}, ok{s}" for s in range(R))
+  scal_cases, mat_cases = [], []
+  for k in spec.kinds:
+    EA = ea_dim(k)
+    feat = k.He_sym is not None
+    args = f"sl, sl + {lay.OFF_Y}"
+    guard = ""
+    if EA:
+      args += f", gea + ((int64_t)t * n + base + g) * {EAM}"
+      guard = "if (gea == nullptr) { bad = 8; break; } "
+    if feat:
+      args += f", gR + t * {zmax * zmax}"
+    scal_cases.append(f"          case {k.kind}: {{ {guard}scal_obs_{k.kind}_r{'<true>' if feat else ''}({args}); break; }}")
+    mat_cases.append(f"        case {k.kind}: update_{k.kind}_rows({rows}, gR + t * {zmax * zmax}, sP, s_G + gg * {zmax * E}, sl, sl, {idx}); break;")
+  aug = ""
+  if spec.N > 0:
+    d1, d2, d3, d4 = spec.dim_main, spec.dim_main_err, spec.dim_augment, spec.dim_augment_err
+    src_x = [i if i < d1 else (i + d3 if i < D - d3 else i - (D - d3)) for i in range(D)]
+
+    def se(i):
+      r = i if i < E - d4 else i - (E - d4)
+      return r if r < d2 else r + d4
+    shift = []
+    for s in range(R):
+      shift.append(f"        {{ const int sr = (rc{s} < {E - d4} ? rc{s} : rc{s} - {E - d4}); const int srow = sr < {d2} ? sr : sr + {d4};")
+      shift += [f"          row{s}[{j}] = sP[srow * {E} + {se(j)}];" for j in range(E)]
+      shift.append("        }")
+    back = []
+    for s in range(R):
+      back += [f"        if (ok{s}) {{", "#pragma unroll", f"          for (int j = 0; j < {E}; j++) sP[rr{s} * {E} + j] = row{s}[j];", "        }"]
+    nl = chr(10)
+    aug = f"""
+      // MSCKF window shift after this step (EKF_sym.augment, ekf_sym.py:365-391; the schedule's augment[t]): a fixed permutation
+      // of the state (one lane per filter) and of the rows / columns of P, read out of the LDS image (the trace above holds the
+      // estimate BEFORE the shift, like the reference's Estimate)
+      if (augs != nullptr && augs[t] != 0) {{
+        if (c == 0 && live) {{
+          double xo[{D}];
+#pragma unroll
+          for (int i = 0; i < {D}; i++) xo[i] = sl[{lay.OFF_X} + i];
+{nl.join(f"          sl[{lay.OFF_X + i}] = xo[{src_x[i]}];" for i in range(D) if src_x[i] != i)}
+        }}
+{nl.join(shift)}
+        rn::wave_lds_sync();
+{nl.join(back)}
+        rn::wave_lds_sync();
+      }}"""
+  # predict(dt = 0) is skipped only for models where it is symbolically the identity (FilterSpec.identity_at_dt0)
+  id0_guard = "true" if not spec.identity_at_dt0() else "dt != 0.0"
+  decl_rows = "\n".join(f"    double row{s}[{E}];" for s in range(R))
+  decl_idx = "\n".join(f"    const int rr{s} = c + {GL * s}; const bool ok{s} = live && rr{s} < {E}; const int rc{s} = rr{s} < {E} ? rr{s} : 0;" for s in range(R))
+  load_rows = "\n".join(f"#pragma unroll\n    for (int j = 0; j < {E}; j++) row{s}[j] = sP[rc{s} * {E} + j];" for s in range(R))
+  nlc = chr(10)
+  return f"""
+// ---- fused multi-step run: kinds[t], dts[t] shared by all filters; z is (T, n, {zmax}) in: z, out: y -----------
+// Per step, with P in registers: (1a) one lane per filter evaluates f and the non-trivial entries of F into the filter's LDS
+// slot, (2a) all lanes run predict's covariance algebra on their rows, (1b) one lane per filter evaluates h and He for the
+// observation kind, (2b) all lanes run the update's covariance algebra, (3) one lane per filter injects the error state.
+// x lives in the slot between the phases.
+__global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __restrict__ gP, const double* __restrict__ gQ,
+    const int32_t* __restrict__ kinds, const double* __restrict__ dts, const int64_t T, double* __restrict__ gz,
+    const double* __restrict__ gR, const int64_t n, const int norm_quats, uint8_t* __restrict__ flags,
+    double* __restrict__ tx, double* __restrict__ tP, const double* __restrict__ gea, const int32_t* __restrict__ augs) {{
+  (void)gea; (void)augs;
+  __shared__ __attribute__((aligned(16))) double s_P[FPWR * {EE} + 2];      // one image of P per filter (see emit_wide3.py)
+  __shared__ __attribute__((aligned(16))) double s_G[FPWR * {zmax * E}];     // G, then K^T
+  __shared__ __attribute__((aligned(16))) double s_sl[FPWR * SLOT_R];
+  const int lane = threadIdx.x;
+  const int g = lane / GLR;
+  const int c = lane % GLR;
+  const int zf = lane / {zmax}, zc = lane % {zmax};                // observation entry this lane carries between HBM and the slots
+  const int64_t tiles = (n + FPWR - 1) / FPWR;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
+    const int64_t base = tile * FPWR;
+    const int cnt = (n - base) < FPWR ? (int)(n - base) : FPWR;
+    const int gg = g < cnt ? g : 0;
+    const bool live = g < cnt;
+    const bool zlive = zf < cnt;
+    double* sP = s_P + gg * {EE};
+    double* sl = s_sl + gg * SLOT_R;
+    double* slz = s_sl + (zlive ? zf : 0) * SLOT_R + {lay.OFF_Y} + zc;
+{decl_idx}
+    int lb = lane;
+    asm volatile("" : "+v"(lb));         // opaque copy of the lane index: the copies' index arithmetic stays inside the tile
+    rn::copy_g2l<FPWR * {EE}>(gP + base * {EE}, cnt * {EE}, s_P, lb);
+    for (int i = lane; i < cnt * {D}; i += 64) s_sl[(i / {D}) * SLOT_R + {lay.OFF_X} + i % {D}] = gx[base * {D} + i];
+    if (zlive) *slz = gz[base * {zmax} + lane];
+    rn::wave_lds_sync();
+{decl_rows}
+{load_rows}
+    for (int64_t t = 0; t < T; t++) {{
+      double zn = 0.0;                                 // next step's observation, in flight during this step
+      if (t + 1 < T && zlive) zn = gz[((t + 1) * n + base) * {zmax} + lane];
+      const int kind = kinds[t];
+      const double dt = dts[t];
+      const bool do_pred = {id0_guard};
+      // ---- phase 1a / 2a: predict ----
+      if (c == 0 && live) {{
+        if (do_pred) scal_predict_r(sl + {lay.OFF_X}, dt, sl, norm_quats);
+        else scal_keep_r(sl + {lay.OFF_X}, sl, norm_quats);                 // predict(dt = 0) still renormalises
+      }}
+      rn::wave_lds_sync();
+      if (do_pred) {{
+        int qz = 0;
+        asm volatile("" : "+v"(qz));                   // Q behind an opaque zero: its addresses are not worth registers across the step loop
+        predict_rows({rows}, sP, gQ + qz, sl, {idx});
+      }}
+      // ---- phase 1b / 2b: update ----
+      int bad = 0;
+      if (c == 0 && live) {{
+        switch (kind) {{
+{nlc.join(scal_cases)}
+          default: bad = 8; break;      // unknown kind
+        }}
+      }}
+      bad = __builtin_amdgcn_readfirstlane(__any(bad) ? 8 : 0);
+      rn::wave_lds_sync();
+      if (!bad) {{
+        switch (kind) {{
+{nlc.join(mat_cases)}
+          default: break;
+        }}
+      }}
+      // ---- phase 3: lane 0 of each group injects the error state ----
+      if (c == 0 && live) {{
+        int fl = bad;
+        if (!bad) fl = scal_inject_r(sl, sl + {lay.OFF_X}, norm_quats) | (int)sl[{lay.OFF_FL}];
+        if (flags != nullptr) flags[t * n + base + g] = (uint8_t)fl;
+      }}
+      rn::wave_lds_sync();
+      if (zlive) gz[(t * n + base) * {zmax} + lane] = *slz;          // y (the observation itself after an unknown kind)
+      int lz = lane;
+      asm volatile("" : "+v"(lz));       // the copies' per-iteration indices are not worth registers across the step loop
+      if (tx != nullptr) {{
+        for (int i = lz; i < cnt * {D}; i += 64) tx[(t * n + base) * {D} + i] = s_sl[(i / {D}) * SLOT_R + {lay.OFF_X} + i % {D}];
+      }}
+      if (tP != nullptr) rn::copy_l2g<FPWR * {EE}>(tP + (t * n + base) * {EE}, cnt * {EE}, s_P, lz);
+      rn::wave_lds_sync();
+      if (zlive) *slz = zn;
+      rn::wave_lds_sync();{aug}
+    }}
+    int le = lane;
+    asm volatile("" : "+v"(le));         // (same: nothing of the first copy's index arithmetic is kept alive across the step loop)
+    rn::copy_l2g<FPWR * {EE}>(gP + base * {EE}, cnt * {EE}, s_P, le);
+    for (int i = le; i < cnt * {D}; i += 64) gx[base * {D} + i] = s_sl[(i / {D}) * SLOT_R + {lay.OFF_X} + i % {D}];
+    rn::wave_lds_sync();
+  }}
+}}
+"""
+
+
+def launch_run():
+  return """  const int64_t tiles = (n + FPWR - 1) / FPWR;
+  hipLaunchKernelGGL(k_run, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P, ea, augment);"""

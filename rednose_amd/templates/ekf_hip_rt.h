@@ -92,6 +92,10 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Forces `v` to exist in registers at this point of the instruction stream (an empty volatile asm that "modifies" it):
+// arithmetic producing v cannot sink below, arithmetic consuming it cannot rise above.  No instruction is emitted.
+__device__ __forceinline__ void pin(double& v) { asm volatile("" : "+v"(v)); }
+
 // LDS image of a tile: filter f's record starts at f * lds_stride<EPF>() doubles.  An ODD stride makes the
 // lane-per-filter ds_read_b64 / ds_write_b64 accesses conflict-free (the linear layout costs 4-way conflicts on P,
 // 864 cycles per wave in the round-1 PMC run), but the index arithmetic of the padded copy cost more than the

@@ -283,9 +283,6 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
 //   scal(xin, dt, sl, norm)                      one filter's f / F non-zeros -> slot (x' = f(x) [normalised] at sl[OFF_X..])
 //   mat_predict(row, sB, gQc, sl, cc, act, y)    row c of Pk_k, gQc = column cc of Q -> y = column c of M = F Pk_k^T, sB <- Pk1_k (EM x EM)
 //   inv_err, err, normalize                      as for k_rts
-// Forces `v` to exist in registers at this point of the instruction stream (an empty volatile asm that "modifies" it):
-// arithmetic producing v cannot sink below, arithmetic consuming it cannot rise above.  No instruction is emitted.
-__device__ __forceinline__ void pin(double& v) { asm volatile("" : "+v"(v)); }
 
 template <int E, int EM>
 __device__ __forceinline__ void rts_load_row(const double* __restrict__ p, double (&r)[EM]) {

@@ -224,7 +224,7 @@ def test_zero_dt_shortcut_is_guarded_symbolically():
       assert not spec.identity_at_dt0()
     with open(os.path.join(d, "randaff11.hip"), encoding="utf-8") as f:
       src = f.read()
-    assert "dt_scalar == 0.0" not in src and "if (true || dt != 0.0)" in src
+    assert "dt_scalar == 0.0" not in src and "const bool do_pred = true;" in src
     with open(os.path.join(d, "rand11.hip"), encoding="utf-8") as f:
       src = f.read()
-    assert "dt_scalar == 0.0" in src
+    assert "dt_scalar == 0.0" in src and "const bool do_pred = dt != 0.0;" in src
