@@ -56,7 +56,23 @@ def layout(spec):
   return GL, -(-E // GL), 64 // GL
 
 
-def _rank_pass(E, Z, R, src, op, coef, JB=2):
+def _tl(ph):
+  """Debug stamp inside the matrix phases (tuning knob wide_timeline): slot 20 * (t % 3) + ph of the workgroup's timeline."""
+  from rednose_amd.codegen import tuning
+  if not tuning.current().wide_timeline:
+    return []
+  return [f"if (threadIdx.x == 0 && blockIdx.x < 256) {{ const int ti_ = tl_t * 20 + {ph}; g_tl[(blockIdx.x * 64 + ti_) * 2] = "
+          "__builtin_readcyclecounter(); g_tl[(blockIdx.x * 64 + ti_) * 2 + 1] = wall_clock64(); }"]
+
+
+def _tl_arg(call=False):
+  from rednose_amd.codegen import tuning
+  if not tuning.current().wide_timeline:
+    return ""
+  return ", (int)(t % 3)" if call else ", const int tl_t"
+
+
+def _rank_pass(E, Z, R, src, op, coef, JB=4):
   """Straight-line rank-Z pass over the register rows: row_s[j] op= sum_z coef_s[z] * src[z][j] for all j, in blocks of JB
   columns.  The broadcast operands of block b + 1 are loaded before the FMAs of block b and a compiler fence closes every
   block, so one block of loads is in flight under the arithmetic and no more: left to itself hipcc issues all Z*E LDS loads
@@ -72,7 +88,9 @@ def _rank_pass(E, Z, R, src, op, coef, JB=2):
       out += loads(blocks[bi + 1])
     for j in bl:
       for s in range(R):
-        out.append(f"row{s}[{j}] {op} " + " + ".join(f"{coef}{s}[{zi}]*q_{zi}_{j}" for zi in range(Z)) + f"; rn::pin(row{s}[{j}]);")
+        # one FMA per term, accumulated on the entry itself (a sum formed first costs an extra instruction per entry)
+        sg = "-" if op == "-=" else "+"
+        out.append(f"row{s}[{j}] = row{s}[{j}] " + " ".join(f"{sg} {coef}{s}[{zi}]*q_{zi}_{j}" for zi in range(Z)) + f"; rn::pin(row{s}[{j}]);")
     out.append("rn::wave_lds_sync();")
   return ["{"] + _ind(out) + ["}"]
 
@@ -115,33 +133,46 @@ def _tables(spec):
 
 
 def predict_fn(spec):
-  """Matrix part of predict on register rows; F's non-trivial entries are broadcast reads of the filter's slot."""
+  """Matrix part of predict on register rows; F's non-trivial entries are broadcast reads of the filter's slot.
+
+  P' = F P F^T + dt Q with ONE transposition through LDS: rows of A = P F^T are row-local; under P = P^T the columns of A are the
+  rows of B = F P (B[r][m] = sum_k F[r][k] P[k][m] = sum_k F[r][k] P[m][k] = A[m][r]), and P'[r][:] = B[r][:] F^T + dt Q[r][:] is
+  row-local again, so the new rows land in the registers that hold them for the next step.  (P is symmetric up to the rounding
+  of the Joseph form, in the reference as here; the reference multiplies F P F^T out entry by entry, ekf_c.c:8-33.)"""
   E = spec.dim_err
   GL, R, _ = layout(spec)
   lay, Fs, _ = _tables(spec)
   b = [f"const double dt = sl[{lay.OFF_DT}];"]
-  # a = F row, row-local, each entry straight to the LDS image (row rr of P F^T)
-  for s in range(R):
-    b.append(f"if (ok{s}) {{")
-    for i in range(E):
-      b.append(f"  sP[rr{s} * {E} + {i}] = {sum_terms(term(cf, f'row{s}[{k}]') for k, cf in Fs.row_nz(i))};")
-    b.append("}")
-  b.append("rn::wave_lds_sync();")
-  # column view: this lane's columns of P F^T; P' = F (P F^T) + dt Q, written back in place (own columns only)
+  # rows of A, whole rows at a time: 16-byte LDS stores of a lane's contiguous row (entry-wise 8-byte stores at a row stride
+  # collide on banks)
   for s in range(R):
     b.append("{")
     b.append(f"  double a[{E}];")
-    b.append("#pragma unroll")
-    b.append(f"  for (int k = 0; k < {E}; k++) a[k] = sP[k * {E} + rc{s}];")
     for i in range(E):
-      b.append(f"  {{ const double v = {sum_terms(term(cf, f'a[{k}]') for k, cf in Fs.row_nz(i))} + dt*gQ[{i * E} + rc{s}]; if (ok{s}) sP[{i * E} + rr{s}] = v; }}")
+      b.append(f"  a[{i}] = {sum_terms(term(cf, f'row{s}[{k}]') for k, cf in Fs.row_nz(i))};")
+    b += [f"  if (ok{s}) {{", "#pragma unroll", f"    for (int i = 0; i < {E}; i++) sP[rr{s} * {E} + i] = a[i];", "  }"]
     b.append("}")
   b.append("rn::wave_lds_sync();")
+  b += _tl(8)
+  # Q is read from HBM / L2 (no LDS left for it): slot s's row of Q is requested one slot ahead of its use
+  b.append(f"double q0[{E}];")
+  b += ["#pragma unroll", f"for (int j = 0; j < {E}; j++) q0[j] = gQ[rc0 * {E} + j];"]
   for s in range(R):
-    b += ["#pragma unroll", f"for (int j = 0; j < {E}; j++) row{s}[j] = sP[rc{s} * {E} + j];"]
+    if s + 1 < R:
+      b.append(f"double q{s + 1}[{E}];")
+    b.append("{")
+    b.append(f"  double a[{E}];")
+    b += ["#pragma unroll", f"  for (int m = 0; m < {E}; m++) a[m] = sP[m * {E} + rc{s}];      // column of A = row of B"]
+    if s + 1 < R:
+      b += ["#pragma unroll", f"  for (int j = 0; j < {E}; j++) q{s + 1}[j] = gQ[rc{s + 1} * {E} + j];"]
+    for j in range(E):
+      b.append(f"  row{s}[{j}] = {sum_terms(term(cf, f'a[{m}]') for m, cf in Fs.row_nz(j))} + dt*q{s}[{j}];")
+    b.append("}")
+  b.append("rn::wave_lds_sync();      // the image is free again")
+  b += _tl(9)
   rows = ", ".join(f"double (&row{s})[{E}]" for s in range(R))
   idx = ", ".join(f"const int rr{s}, const int rc{s}, const bool ok{s}" for s in range(R))
-  head = (f"__device__ __forceinline__ void predict_rows({rows}, double* sP, const double* __restrict__ gQ, const double* sl, {idx}) {{")
+  head = (f"__device__ __forceinline__ void predict_rows({rows}, double* sP, const double* __restrict__ gQ, const double* sl, {idx}{_tl_arg()}) {{")
   return "\n".join([head] + _ind(b) + ["}"])
 
 
@@ -155,30 +186,26 @@ def update_fn(spec, k):
   Hs = Hss[k.kind]
   feat = k.He_sym is not None
   Z = Zf - EADIM if feat else Zf
-  used = sorted({kk for zi in range(Zf) for kk, _ in Hs.row_nz(zi)})
   RF, RB = lay.OFF_RF, lay.OFF_RF + EADIM * Zf
-  b = [f"double R[{Z * Z}];"]
+  b = ["(void)sP;", f"double R[{Z * Z}];"]
   if feat:
     b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) R[i] = sl[{lay.OFF_RP} + i];      // A^T R A (phase 1)", "(void)gR;",
           f"const double rank_deficient = sl[{lay.OFF_FL}];      // 4.0 when phase 1 found Hea rank deficient"]
   else:
     b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) R[i] = gR[i];"]
-  # G (this lane's columns, from the LDS image of P) per row slot, straight to the broadcast buffer; the row view Gt = rows . He^T
-  # is formed after the factorisation, right before it is solved into K
+  # G = He P: G[z][j] = sum_k He[z][k] P[k][j]; with P = P^T (up to the Joseph form's rounding) that is row j of P against
+  # He[z][:] -- row-local, so the lane that owns row j has column j of G in registers; the same numbers are the row view
+  # P He^T that is solved into K below.  Nothing of the update reads the LDS image of P.
   for s in range(R):
-    b.append("{")
-    b += [f"  const double c_{kk} = sP[{kk} * {E} + rc{s}];" for kk in used]
     if feat:
-      b.append(f"  double g0[{Zf}] = {{" + ", ".join(sum_terms(term(cf, f'c_{kk}') for kk, cf in Hs.row_nz(zi)) for zi in range(Zf)) + "};")
-      b.append(f"  rn::apply_reflectors<{Zf}, {EADIM}>(sl + {RF}, sl + {RB}, g0);")
-      b.append(f"  if (ok{s}) {{ " + " ".join(f"sG[{zi} * {E} + rr{s}] = g0[{EADIM + zi}];" for zi in range(Z)) + " }")
+      b.append(f"double t0_{s}[{Zf}] = {{" + ", ".join(sum_terms(term(cf, f'row{s}[{kk}]') for kk, cf in Hs.row_nz(zi)) for zi in range(Zf)) + "};")
+      b.append(f"rn::apply_reflectors<{Zf}, {EADIM}>(sl + {RF}, sl + {RB}, t0_{s});")
+      b.append(f"double kk{s}[{Z}] = {{{', '.join(f't0_{s}[{EADIM + zi}]' for zi in range(Z))}}};")
     else:
-      b.append(f"  if (ok{s}) {{")
-      for zi in range(Z):
-        b.append(f"    sG[{zi} * {E} + rr{s}] = {sum_terms(term(cf, f'c_{kk}') for kk, cf in Hs.row_nz(zi))};")
-      b.append("  }")
-    b.append("}")
+      b.append(f"double kk{s}[{Z}] = {{" + ", ".join(sum_terms(term(cf, f'row{s}[{kk}]') for kk, cf in Hs.row_nz(zi)) for zi in range(Z)) + "};")
+    b.append(f"if (ok{s}) {{ " + " ".join(f"sG[{zi} * {E} + rr{s}] = kk{s}[{zi}];" for zi in range(Z)) + " }")
   b.append("rn::wave_lds_sync();")
+  b += _tl(10)
   b.append(f"double HPH[{Z * Z}], Rl[{Z * Z}], S[{Z * Z}], L[{Z * Z}], iL[{Z}];")
   if feat:
     for zi in range(Z):
@@ -197,19 +224,16 @@ def update_fn(spec, k):
           "  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";", f"  if (d2 > {k.maha_thresh!r}) {{", "    gated = 1;",
           "#pragma unroll", f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}",
           f"    rn::spd_factor<{Z}>(S, L, iL);", "  }", "}"]
+  b += _tl(11)
   for s in range(R):
-    if feat:
-      b.append(f"double t0_{s}[{Zf}] = {{" + ", ".join(sum_terms(term(cf, f'row{s}[{kk}]') for kk, cf in Hs.row_nz(zi)) for zi in range(Zf)) + "};")
-      b.append(f"rn::apply_reflectors<{Zf}, {EADIM}>(sl + {RF}, sl + {RB}, t0_{s});")
-      b.append(f"double kk{s}[{Z}] = {{{', '.join(f't0_{s}[{EADIM + zi}]' for zi in range(Z))}}};")
-    else:
-      b.append(f"double kk{s}[{Z}] = {{" + ", ".join(sum_terms(term(cf, f'row{s}[{kk}]') for kk, cf in Hs.row_nz(zi)) for zi in range(Z)) + "};")
     b.append(f"rn::spd_solve<{Z}>(L, iL, kk{s});                       // K[row][:]")
     if feat:     # the reference's numpy path ignores a measurement whose null-space projection failed (ekf_sym.py:589-591)
       b += ["if (rank_deficient != 0.0) {", "#pragma unroll", f"  for (int i = 0; i < {Z}; i++) kk{s}[i] = 0.0;", "}"]
     b.append(f"const double dx{s} = " + " + ".join(f"kk{s}[{zi}]*sl[{lay.OFF_Y + zi}]" for zi in range(Z)) + ";")
   # B = P - K G: every broadcast row of G feeds all R row slots
+  b += _tl(12)
   b += _rank_pass(E, Z, R, "sG", "-=", "kk")
+  b += _tl(13)
   for s in range(R):
     if feat:
       b.append(f"double Cf{s}[{Zf}] = {{" + ", ".join(sum_terms(term(cf, f'row{s}[{j}]') for j, cf in Hs.row_nz(w)) for w in range(Zf)) + "};")
@@ -225,15 +249,14 @@ def update_fn(spec, k):
     b.append(f"if (ok{s}) {{ " + " ".join(f"sG[{zi} * {E} + rr{s}] = kk{s}[{zi}];" for zi in range(Z)) + f" sw[{lay.OFF_DX} + rr{s}] = dx{s};" +
              (f" if (rr{s} == 0) sw[{lay.OFF_FL}] = {fl};" if s == 0 else "") + " }")
   b.append("rn::wave_lds_sync();")
+  b += _tl(14)
   b += _rank_pass(E, Z, R, "sG", "+=", "Dm")
-  # the LDS image follows the registers (column reads of the next update, trace, window shift)
-  for s in range(R):
-    b += [f"if (ok{s}) {{", "#pragma unroll", f"  for (int j = 0; j < {E}; j++) sP[rr{s} * {E} + j] = row{s}[j];", "}"]
-  b.append("rn::wave_lds_sync();      // the image is complete, the broadcast buffer is free again")
+  b += _tl(15)
+  b.append("rn::wave_lds_sync();      // the broadcast buffer is free again")
   rows = ", ".join(f"double (&row{s})[{E}]" for s in range(R))
   idx = ", ".join(f"const int rr{s}, const int rc{s}, const bool ok{s}" for s in range(R))
   head = (f"__device__ __forceinline__ void update_{k.kind}_rows({rows}, const double* __restrict__ gR, double* sP, double* sG, const double* sl, "
-          f"double* sw, {idx}) {{")
+          f"double* sw, {idx}{_tl_arg()}) {{")
   return "\n".join([head] + _ind(b) + ["}"])
 
 
@@ -274,7 +297,9 @@ def run_kernel(spec):
     if feat:
       args += f", gR + t * {zmax * zmax}"
     scal_cases.append(f"          case {k.kind}: {{ {guard}scal_obs_{k.kind}_r{'<true>' if feat else ''}({args}); break; }}")
-    mat_cases.append(f"        case {k.kind}: update_{k.kind}_rows({rows}, gR + t * {zmax * zmax}, sP, s_G + gg * {zmax * E}, sl, sl, {idx}); break;")
+    mat_cases.append(f"        case {k.kind}: update_{k.kind}_rows({rows}, gR + t * {zmax * zmax}, sP, s_G + gg * {zmax * E}, sl, sl, {idx}{_tl_arg(True)}); break;")
+  # rows -> LDS image (only where something reads the image: trace, window shift, the final store)
+  img = "\n".join(f"        if (ok{s}) {{\n#pragma unroll\n          for (int j = 0; j < {E}; j++) sP[rr{s} * {E} + j] = row{s}[j];\n        }}" for s in range(R))
   aug = ""
   if spec.N > 0:
     d1, d2, d3, d4 = spec.dim_main, spec.dim_main_err, spec.dim_augment, spec.dim_augment_err
@@ -288,15 +313,14 @@ def run_kernel(spec):
       shift.append(f"        {{ const int sr = (rc{s} < {E - d4} ? rc{s} : rc{s} - {E - d4}); const int srow = sr < {d2} ? sr : sr + {d4};")
       shift += [f"          row{s}[{j}] = sP[srow * {E} + {se(j)}];" for j in range(E)]
       shift.append("        }")
-    back = []
-    for s in range(R):
-      back += [f"        if (ok{s}) {{", "#pragma unroll", f"          for (int j = 0; j < {E}; j++) sP[rr{s} * {E} + j] = row{s}[j];", "        }"]
     nl = chr(10)
     aug = f"""
       // MSCKF window shift after this step (EKF_sym.augment, ekf_sym.py:365-391; the schedule's augment[t]): a fixed permutation
       // of the state (one lane per filter) and of the rows / columns of P, read out of the LDS image (the trace above holds the
       // estimate BEFORE the shift, like the reference's Estimate)
       if (augs != nullptr && augs[t] != 0) {{
+{img}
+        rn::wave_lds_sync();
         if (c == 0 && live) {{
           double xo[{D}];
 #pragma unroll
@@ -305,8 +329,6 @@ def run_kernel(spec):
         }}
 {nl.join(shift)}
         rn::wave_lds_sync();
-{nl.join(back)}
-        rn::wave_lds_sync();
       }}"""
   # predict(dt = 0) is skipped only for models where it is symbolically the identity (FilterSpec.identity_at_dt0)
   id0_guard = "true" if not spec.identity_at_dt0() else "dt != 0.0"
@@ -314,6 +336,13 @@ def run_kernel(spec):
   decl_idx = "\n".join(f"    const int rr{s} = c + {GL * s}; const bool ok{s} = live && rr{s} < {E}; const int rc{s} = rr{s} < {E} ? rr{s} : 0;" for s in range(R))
   load_rows = "\n".join(f"#pragma unroll\n    for (int j = 0; j < {E}; j++) row{s}[j] = sP[rc{s} * {E} + j];" for s in range(R))
   nlc = chr(10)
+  from rednose_amd.codegen import tuning
+
+  def TL(ph):      # debug stamps (tuning knob wide_timeline; tools/timeline.py run): the last three steps, twenty stamps each
+    if not tuning.current().wide_timeline:
+      return ""
+    return (f"if (lane == 0 && blockIdx.x < 256) {{ const int ti_ = (int)(t % 3) * 20 + {ph}; "
+            "g_tl[(blockIdx.x * 64 + ti_) * 2] = __builtin_readcyclecounter(); g_tl[(blockIdx.x * 64 + ti_) * 2 + 1] = wall_clock64(); }")
   return f"""
 // ---- fused multi-step run: kinds[t], dts[t] shared by all filters; z is (T, n, {zmax}) in: z, out: y -----------
 // Per step, with P in registers: (1a) one lane per filter evaluates f and the non-trivial entries of F into the filter's LDS
@@ -357,17 +386,20 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       const int kind = kinds[t];
       const double dt = dts[t];
       const bool do_pred = {id0_guard};
+      {TL(0)}
       // ---- phase 1a / 2a: predict ----
       if (c == 0 && live) {{
         if (do_pred) scal_predict_r(sl + {lay.OFF_X}, dt, sl, norm_quats);
         else scal_keep_r(sl + {lay.OFF_X}, sl, norm_quats);                 // predict(dt = 0) still renormalises
       }}
       rn::wave_lds_sync();
+      {TL(1)}
       if (do_pred) {{
         int qz = 0;
         asm volatile("" : "+v"(qz));                   // Q behind an opaque zero: its addresses are not worth registers across the step loop
-        predict_rows({rows}, sP, gQ + qz, sl, {idx});
+        predict_rows({rows}, sP, gQ + qz, sl, {idx}{_tl_arg(True)});
       }}
+      {TL(2)}
       // ---- phase 1b / 2b: update ----
       int bad = 0;
       if (c == 0 && live) {{
@@ -378,12 +410,14 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       }}
       bad = __builtin_amdgcn_readfirstlane(__any(bad) ? 8 : 0);
       rn::wave_lds_sync();
+      {TL(3)}
       if (!bad) {{
         switch (kind) {{
 {nlc.join(mat_cases)}
           default: break;
         }}
       }}
+      {TL(4)}
       // ---- phase 3: lane 0 of each group injects the error state ----
       if (c == 0 && live) {{
         int fl = bad;
@@ -391,17 +425,26 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
         if (flags != nullptr) flags[t * n + base + g] = (uint8_t)fl;
       }}
       rn::wave_lds_sync();
+      {TL(5)}
       if (zlive) gz[(t * n + base) * {zmax} + lane] = *slz;          // y (the observation itself after an unknown kind)
       int lz = lane;
       asm volatile("" : "+v"(lz));       // the copies' per-iteration indices are not worth registers across the step loop
       if (tx != nullptr) {{
         for (int i = lz; i < cnt * {D}; i += 64) tx[(t * n + base) * {D} + i] = s_sl[(i / {D}) * SLOT_R + {lay.OFF_X} + i % {D}];
       }}
-      if (tP != nullptr) rn::copy_l2g<FPWR * {EE}>(tP + (t * n + base) * {EE}, cnt * {EE}, s_P, lz);
+      if (tP != nullptr) {{
+{img}
+        rn::wave_lds_sync();
+        rn::copy_l2g<FPWR * {EE}>(tP + (t * n + base) * {EE}, cnt * {EE}, s_P, lz);
+      }}
       rn::wave_lds_sync();
+      {TL(6)}
       if (zlive) *slz = zn;
-      rn::wave_lds_sync();{aug}
+      rn::wave_lds_sync();
+      {TL(7)}{aug}
     }}
+{img}
+    rn::wave_lds_sync();
     int le = lane;
     asm volatile("" : "+v"(le));         // (same: nothing of the first copy's index arithmetic is kept alive across the step loop)
     rn::copy_l2g<FPWR * {EE}>(gP + base * {EE}, cnt * {EE}, s_P, le);

@@ -111,8 +111,60 @@ def rts():
     prev = m
 
 
+def run():
+  """Phase timeline of the fused multi-step run (k_run of the lane-group family): the last three steps of a live IMU / GNSS
+  schedule, averaged over the first 256 workgroups (one wavefront each)."""
+  import torch
+  from examples import ensure_generated, GENERATED_DIR
+  from examples.live_kf import LiveKalman as L
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+  trace = len(sys.argv) > 3 and sys.argv[3] == "trace"
+  gen = ensure_generated(["live"], folder=GENERATED_DIR)
+  f = BatchedEKF(gen, "live", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22, batch=n, quaternion_idxs=[3])
+  T = 126
+  kinds = np.tile(np.array([4, 10, 12], dtype=np.int32), T // 3)
+  ts = np.repeat(np.arange(1, T // 3 + 1) * 0.01, 3)
+  rng = np.random.default_rng(0)
+  zs = torch.as_tensor(rng.normal(size=(T, n, 3)) * 0.02, device=f.device)
+  Rs = {k: np.atleast_2d(L.obs_noise[k]) for k in (4, 10, 12)}
+  f.init_state(np.tile(L.initial_x, (n, 1)), np.diag(L.initial_P_diag), 0.0)
+  for _ in range(2):
+    f.filter_time = 0.0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    f.run(ts, kinds, zs.clone(), Rs, trace=trace)
+    e1.record()
+    torch.cuda.synchronize()
+  print(f"--- fused run, live, {n} filters x {T} steps{' with trace' if trace else ''}: {e0.elapsed_time(e1) * 1e3 / T:.2f} us per step")
+  buf = (ctypes.c_ulonglong * (256 * 64 * 2))()
+  assert getattr(f._lib, "live_debug_timeline")(ctypes.cast(buf, ctypes.c_void_p)) == 0
+  a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 64, 2).astype(np.float64)[:min(256, (n + 7) // 8)]
+  wall = a[:, :60, 1].reshape(-1, 3, 20) / 100.0
+  names = {0: "step start", 1: "scalars of predict (f, F)", 8: "  predict: P F^T rows -> image", 9: "  predict: F (P F^T) + dt Q, columns -> image",
+           2: "predict, covariance (rows re-read)", 3: "scalars of the kind (h, He)", 10: "  update: G -> buffer", 11: "  update: S, Cholesky, gate",
+           12: "  update: K rows solved", 13: "  update: P - K G", 14: "  update: Joseph coefficients, K^T -> buffer",
+           15: "  update: + D K^T", 4: "update, covariance (image written)", 5: "injection", 6: "y / trace out", 7: "next z in the slot"}
+  order = [0, 1, 8, 9, 2, 3, 10, 11, 12, 13, 14, 15, 4, 5, 6, 7]
+  for s in range(3):
+    t = T - 3 + s
+    rel = wall[:, t % 3, :] - wall[:, t % 3, :1]
+    dtv = ts[t] - (ts[t - 1] if t else 0.0)
+    print(f"  step {t}: kind {kinds[t]} dt {dtv:.2f}")
+    prev = 0.0
+    for i in order:
+      if i in (8, 9) and dtv == 0.0:
+        continue
+      m = rel[:, i].mean()
+      print(f"    {names[i]:48s} {m:8.2f} us (+{m - prev:6.2f})  min {rel[:, i].min():7.2f} max {rel[:, i].max():7.2f}")
+      prev = m
+
+
 if __name__ == "__main__":
   if len(sys.argv) > 1 and sys.argv[1] == "rts":
     rts()
+    sys.exit(0)
+  if len(sys.argv) > 1 and sys.argv[1] == "run":
+    run()
     sys.exit(0)
   main()
