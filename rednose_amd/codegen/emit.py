@@ -88,7 +88,7 @@ def _emit(spec):
   fam = family(spec)
   if E > 64:
     raise NotImplementedError(f"{E} error states: the lane-group kernels hold one row of P per lane of a wavefront (<= 64)")
-  has_run = E <= 32        # fused multi-step run: rows of P stay in VGPRs, 32-lane groups
+  has_run = E <= 32        # fused multi-step run: rows of P stay in VGPRs (emit_wide3); above 32 error states it spills (feature36: 120 VGPRs)
   import types
   from rednose_amd.codegen import tuning
   if fam == "wide":
