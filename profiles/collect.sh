@@ -48,4 +48,9 @@ for c in SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
   rocprofv3 --pmc $c --kernel-trace -d /tmp/ps_$c -o r -- python tools/rts_time.py > /tmp/ps_$c.log 2>&1
   sum pmc "$(db /tmp/ps_$c)" k_rts
 done > $out/${tag}_sq_counters_smoother.txt 2>&1
+# phase timeline of the fused run (needs the library built with the timeline knob: RN_TUNE=wide_timeline=1 RN_GEN_DIR=generated_tl)
+if [ -f generated_tl/liblive.so ]; then
+  { RN_TUNE=wide_timeline=1 RN_GEN_DIR=$PWD/generated_tl python tools/timeline.py run 8192;
+    RN_TUNE=wide_timeline=1 RN_GEN_DIR=$PWD/generated_tl python tools/timeline.py run 8192 trace; } 2>&1 | grep -v amdgpu.ids > $out/${tag}_fused_run_timeline.txt
+fi
 ls -la $out

@@ -74,11 +74,16 @@ def _tl_arg(call=False):
 
 def _rank_pass(E, Z, R, src, op, coef, JB=4):
   """Straight-line rank-Z pass over the register rows: row_s[j] op= sum_z coef_s[z] * src[z][j] for all j, in blocks of JB
-  columns.  The broadcast operands of block b + 1 are loaded before the FMAs of block b and a compiler fence closes every
-  block, so one block of loads is in flight under the arithmetic and no more: left to itself hipcc issues all Z*E LDS loads
-  first (2*Z*E registers on top of the rows -> hundreds of spills)."""
+  columns.  Two things hipcc does not do by itself here:
+    * the broadcast operands of block b + 1 are loaded before the FMAs of block b and a compiler fence closes every block, so
+      one block of loads is in flight under the arithmetic and no more (left alone it issues all Z*E LDS loads first: 2*Z*E
+      registers on top of the rows -> hundreds of spills);
+    * inside a block the FMAs are emitted term by term ACROSS the block's JB * R entries, so consecutive instructions belong to
+      different accumulation chains: a dependent fp64 FMA issues ~40 cycles after its predecessor with one wavefront per SIMD
+      (tools/fp64_ilp.hip), entry-by-entry order made every FMA wait for the one before it."""
   out = []
   blocks = [list(range(j, min(j + JB, E))) for j in range(0, E, JB)]
+  sg = "-=" if op == "-=" else "+="
 
   def loads(bl):
     return [f"const double q_{zi}_{j} = {src}[{zi} * {E} + {j}];" for j in bl for zi in range(Z)]
@@ -86,11 +91,11 @@ def _rank_pass(E, Z, R, src, op, coef, JB=4):
   for bi, bl in enumerate(blocks):
     if bi + 1 < len(blocks):
       out += loads(blocks[bi + 1])
-    for j in bl:
-      for s in range(R):
-        # one FMA per term, accumulated on the entry itself (a sum formed first costs an extra instruction per entry)
-        sg = "-" if op == "-=" else "+"
-        out.append(f"row{s}[{j}] = row{s}[{j}] " + " ".join(f"{sg} {coef}{s}[{zi}]*q_{zi}_{j}" for zi in range(Z)) + f"; rn::pin(row{s}[{j}]);")
+    for zi in range(Z):
+      for j in bl:
+        for s in range(R):
+          out.append(f"row{s}[{j}] {sg} {coef}{s}[{zi}]*q_{zi}_{j};")
+    out.append(" ".join(f"rn::pin(row{s}[{j}]);" for j in bl for s in range(R)))
     out.append("rn::wave_lds_sync();")
   return ["{"] + _ind(out) + ["}"]
 
