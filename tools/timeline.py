@@ -141,10 +141,10 @@ def run():
   assert getattr(f._lib, "live_debug_timeline")(ctypes.cast(buf, ctypes.c_void_p)) == 0
   a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 64, 2).astype(np.float64)[:min(256, (n + 7) // 8)]
   wall = a[:, :60, 1].reshape(-1, 3, 20) / 100.0
-  names = {0: "step start", 1: "scalars of predict (f, F)", 8: "  predict: P F^T rows -> image", 9: "  predict: F (P F^T) + dt Q, columns -> image",
-           2: "predict, covariance (rows re-read)", 3: "scalars of the kind (h, He)", 10: "  update: G -> buffer", 11: "  update: S, Cholesky, gate",
+  names = {0: "step start", 1: "scalars of predict (f, F)", 8: "  predict: rows of A = P F^T -> image", 9: "  predict: columns of A read, rows of P' formed",
+           2: "predict, covariance (end)", 3: "scalars of the kind (h, He)", 10: "  update: G -> buffer", 11: "  update: S, Cholesky, gate",
            12: "  update: K rows solved", 13: "  update: P - K G", 14: "  update: Joseph coefficients, K^T -> buffer",
-           15: "  update: + D K^T", 4: "update, covariance (image written)", 5: "injection", 6: "y / trace out", 7: "next z in the slot"}
+           15: "  update: + D K^T", 4: "update, covariance (end)", 5: "injection", 6: "y / trace out", 7: "next z in the slot"}
   order = [0, 1, 8, 9, 2, 3, 10, 11, 12, 13, 14, 15, 4, 5, 6, 7]
   for s in range(3):
     t = T - 3 + s
