@@ -53,31 +53,37 @@ class KalmanFilter:
       R = self.get_R(kind, len(data))
     return self.filter.predict_and_update_batch(t, kind, data, R)
 
-  def predict_and_observe_stream(self, ts, kinds, data, Rs=None):
+  def predict_and_observe_stream(self, ts, kinds, data, Rs=None, extra_args=None, augment=None):
     """A whole schedule of observations: ts (T,), kinds (T,), data (T, N, zmax) -- one observation per filter and step
     (rows of kinds with Z < zmax padded).  With a batched filter whose library has the fused multi-step entry point this is ONE
     launch: x and P stay on chip for all T steps and only z / y cross HBM ({name}_batch_run).  That is the default path for
     streams because a launch per step cannot feed small models: the 2-state kinematic filter moves 112 B per filter-step,
     8 MB per launch at 65 536 filters -- 1.3 us of HBM time under a 4.5 us launch (14 G steps/s, 20 % of the HBM roofline),
-    against 48 G steps/s for the fused run (round-2 bench, "kinematic_fused").  Kinds that take per-observation extra
-    arguments, a single (host-pointer) filter, or a library without the entry point fall back to one call per step.
-    Returns the residuals (T, N, zmax) for the fused path, a list of per-step results otherwise."""
+    against 48 G steps/s for the fused run (round-2 bench, "kinematic_fused").
+    extra_args (T, N, 3): per filter and step extra arguments of the kinds that take them (MSCKF feature tracks: the landmark);
+    augment (T,) bool: MSCKF window shift after that step (EKF_sym.augment) -- both ride in the fused schedule.
+    A single (host-pointer) filter, or a library without the entry point (more than 32 error states), falls back to one call per
+    step.  Returns the residuals (T, N, zmax) for the fused path, a list of per-step results otherwise."""
     ts = np.asarray(ts, dtype=np.float64)
     kinds = np.asarray(kinds, dtype=np.int32)
     if Rs is None:
       Rs = {int(k): np.atleast_2d(self.obs_noise[int(k)]) for k in set(kinds.tolist())}
     f = self.filter
-    fused = hasattr(f, "run") and not any(getattr(f, "eadims", {}).get(int(k), 0) for k in set(kinds.tolist()))
-    if fused:
+    if hasattr(f, "run"):
       from rednose_amd.helpers import KalmanError
       try:
-        return f.run(ts, kinds, data, Rs)[0]
+        return f.run(ts, kinds, data, Rs, extra_args=extra_args, augment=augment)[0]
       except KalmanError as e:
         if "-> 4" not in str(e):      # status 4: this library has no fused run (more than 32 error states)
           raise
     out = []
-    for t, k, z in zip(ts, kinds, data):
+    for i, (t, k, z) in enumerate(zip(ts, kinds, data)):
       Z = np.atleast_2d(Rs[int(k)]).shape[0]
       zk = z[..., :Z]
-      out.append(self.predict_and_observe(float(t), int(k), zk, Rs[int(k)] if hasattr(f, "run") else None))
+      if hasattr(f, "run"):
+        ea = None if extra_args is None or not getattr(f, "eadims", {}).get(int(k), 0) else extra_args[i]
+        out.append(f.predict_and_update_batch(float(t), int(k), zk, Rs[int(k)], extra_args=ea,
+                                              augment=bool(augment[i]) if augment is not None else False))
+      else:
+        out.append(self.predict_and_observe(float(t), int(k), zk, None))
     return out

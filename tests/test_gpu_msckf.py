@@ -220,3 +220,28 @@ def test_fused_run_with_landmarks_and_window_shifts(env):
   torch.cuda.synchronize()
   assert_close(s.state(), f.state(), rtol=1e-9, floor=1e-11)
   assert_close(s.covs().reshape(n, -1), f.covs().reshape(n, -1), rtol=1e-8, floor=1e-10)
+
+
+def test_kalmanfilter_stream_with_landmarks_and_window_shifts(env):
+  """KalmanFilter.predict_and_observe_stream with extra_args / augment: the fused run where the library has one (feature), one
+  call per step where it has not (feature36, status 4 -> fallback); both against the reference's numpy stream."""
+  torch, gen, FK = env
+  from rednose_amd.helpers.kalmanfilter import KalmanFilter
+  g = _gold(env)
+  n = 5
+  kinds, ts = g["kinds"].astype(np.int32), g["ts"]
+
+  class KF(KalmanFilter):
+    name = FK.name
+    obs_noise = FK.obs_noise
+  kf = KF()
+  kf.filter = _filter(env, n)
+  zs = np.tile(g["zs"][:, None, :], (1, n, 1))
+  eas = np.tile(g["eas"][:, None, :], (1, n, 1))
+  res = kf.predict_and_observe_stream(ts, kinds, zs.copy(), extra_args=eas, augment=g["augment"])
+  torch.cuda.synchronize()
+  fused = FK.dim_state <= 32
+  assert isinstance(res, list) != fused
+  for j in (0, n - 1):
+    assert_close(kf.x[j], g["x_after"][-1], rtol=1e-8, floor=1e-10, what="stream API, state after the last window shift")
+    assert_close(kf.P[j].reshape(1, -1), g["P_after"][-1].reshape(1, -1), rtol=1e-7, floor=1e-9)
