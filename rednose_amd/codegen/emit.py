@@ -105,6 +105,10 @@ def _emit(spec):
         kernels=lambda sp_: emit_wide2.kernels(sp_) + "\n" + emit_wide3.kernels(sp_) + "\n" + emit_wide2.maha_kernels(sp_),
         launch_predict=emit_wide2.launch_predict, launch_step=emit_wide2.launch_step, launch_run=emit_wide3.launch_run,
         launch_maha=emit_wide2.launch_maha)
+      if tuning.current().wide_step3:     # experiment: step-granular kernels in the fused run's layout
+        fam_mod.kernels = lambda sp_: (emit_wide2.kernels(sp_) + "\n" + emit_wide3.kernels(sp_) + "\n" + emit_wide3.step_kernels(sp_) +
+                                       "\n" + emit_wide2.maha_kernels(sp_))
+        fam_mod.launch_step = emit_wide3.launch_step3
   else:
     fam_mod = types.SimpleNamespace(
       kernels=lambda sp_: emit_small.kernels(sp_) + "\n" + emit_small.maha_kernels(sp_),

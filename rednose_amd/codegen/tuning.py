@@ -70,6 +70,12 @@ class Tuning:
   wide_lean_q: int = 0
   small_waves: int = 0
   small_max_e: int = 7
+  wide_step3: int = 0        # EXPERIMENT (off): step-granular kernels in the fused run's layout (emit_wide3.step_kernels: 8 lanes x 3 rows per
+                             # filter, 8 filters per wavefront, the next tile's P prefetched into the LDS image during the update).
+                             # Parity-green (tests/test_gpu_live.py, 9 tests) and SLOWER on live at 16 384 filters: 44.8 us per launch
+                             # of the IMU / GNSS stream mix with 1 024 wavefronts x 2 tiles (=1), 48.5 us with 2 048 x 1 tile (=2),
+                             # against 38.1 us for the three-phase kernels: one wavefront per SIMD runs load -> compute -> store
+                             # serially and 1 024 of them do it in step, so HBM idles while they compute
   wide_timeline: int = 0     # debug: lane 0 of the first 256 workgroups stamps s_memtime / the 100 MHz wall clock at every phase boundary of
                              # the three-phase step kernels into a device buffer read back by {name}_debug_timeline (tools/timeline.py)
 
