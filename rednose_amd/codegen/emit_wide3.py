@@ -5,24 +5,28 @@ x-dependent scalars (f, F, h, H.H_mod, err_fun: ~1 600 instructions for live's a
 group -- per wavefront that is the same instruction count whether 2 or 8 filters share it, so with 2 filters per
 wavefront the scalars alone cost 3 us per step, the rank-Z passes ran at 22 busy lanes of 32, each FMA fetched one
 broadcast operand from LDS, and the kernel needed 256 + 166 registers with a thousand AGPR moves: 343 M steps/s on
-live, SLOWER per step than one launch per step.
+live's config-4 forward pass, SLOWER per step than one launch per step.
 
 Here a filter gets GL = 8 lanes (16 above 22 error states) and lane c owns rows c, c + GL, c + 2 GL ... of P
 (R = ceil(E / GL) rows per lane), so a wavefront carries 8 (4) filters:
-  * the scalar block is amortised over 4x as many filters;
+  * the scalar phases run ONCE per filter (one lane per filter, through an LDS slot -- the step kernels' generated functions,
+    instantiated against RunLayout), amortised over 4x as many filters per wavefront;
   * every broadcast operand of the rank-Z passes (a row of G or K^T from LDS) feeds R FMAs instead of one;
   * live: 22 of 24 row slots busy instead of 22 of 32 lanes.
-P lives in registers as rows only (R x E doubles per lane: 132 VGPRs for live); LDS holds one E x E image per filter
-that serves the two transpositions of predict, the column entries G needs, the window shift of MSCKF models and the
-trace output, plus one Z x E buffer shared by G and K^T.
+P lives in registers as rows only (R x E doubles per lane: 132 VGPRs for live).  LDS holds per filter one E x E image -- the
+scratch of predict's single transposition and the staging buffer of the trace / MSCKF window shift, written only then --, one
+Z x E buffer shared by G and K^T, and the scalar slot.  P = P^T (up to the Joseph form's rounding, as in the reference) is used
+twice: columns of A = P F^T are rows of F P (predict_fn), and column j of G = He P is row j of P against He (update_fn).
 
-  predict (ekf_c.c:8-33)   a = F row (row-local, straight to the LDS image) -> column view -> P' = F a + dt Q written back in
-                           place (a lane rewrites only its own columns) -> rows re-read
-  update  (ekf_c.c:37-121) as in emit_wide2 / emit_small (Joseph form with its rank-Z structure), per row slot; S is factored
-                           redundantly per lane; feature-track kinds project on the null space of the extra-argument Jacobian
-                           with Householder reflectors (ekf_c.c:66-76)
-The arithmetic and its order per entry are those of the other kernels of the family (same generated sums), so results agree
-with the step-granular path to rounding; tests/test_gpu_run.py, test_gpu_random.py, test_gpu_msckf.py bound it.
+  predict (ekf_c.c:8-33)   rows of A = P F^T (row-local) -> image -> columns of A -> P'[r] = (F P)[r] F^T + dt Q[r] (row-local)
+  update  (ekf_c.c:37-121) Joseph form with its rank-Z structure, per row slot; S is factored redundantly per lane;
+                           feature-track kinds project on the null space of the extra-argument Jacobian with Householder
+                           reflectors (ekf_c.c:66-76)
+Results agree with the step-granular path to rounding (different association of the same sums); tests/test_gpu_run.py,
+test_gpu_random.py, test_gpu_msckf.py, test_gpu_fullsize.py bound it.  Measurements and what hipcc needed: DESIGN.md section 3.
+
+`step_kernels` (tuning knob wide_step3, off): the same layout for the step-granular entry points -- measured slower than the
+three-phase kernels of emit_wide2 (one wavefront per SIMD cannot overlap its own HBM round trip), kept as an experiment.
 """
 import sympy as sp
 
@@ -34,10 +38,6 @@ EADIM = 3        # extra-argument dimension of feature-track kinds, hard-coded i
 def _ind(lines, n=2):
   pad = " " * n
   return [pad + s for s in lines]
-
-
-def _even(n):
-  return n + (n & 1)
 
 
 def ea_dim(k):
@@ -145,7 +145,7 @@ def predict_fn(spec):
   row-local again, so the new rows land in the registers that hold them for the next step.  (P is symmetric up to the rounding
   of the Joseph form, in the reference as here; the reference multiplies F P F^T out entry by entry, ekf_c.c:8-33.)"""
   E = spec.dim_err
-  GL, R, _ = layout(spec)
+  _, R, _ = layout(spec)
   lay, Fs, _ = _tables(spec)
   b = [f"const double dt = sl[{lay.OFF_DT}];"]
   # rows of A, whole rows at a time: 16-byte LDS stores of a lane's contiguous row (entry-wise 8-byte stores at a row stride
@@ -186,7 +186,7 @@ def update_fn(spec, k, prefetch=False):
   kinds, the Householder reflectors and the projected noise are read from the filter's slot (phase 1 put them there); dx and
   the gate / rank flags go back to it."""
   E, Zf = spec.dim_err, k.zdim
-  GL, R, _ = layout(spec)
+  _, R, _ = layout(spec)
   lay, _, Hss = _tables(spec)
   Hs = Hss[k.kind]
   feat = k.He_sym is not None
