@@ -406,6 +406,87 @@ def msckf_extra(torch, dev):
           "note": "fused predict + feature-track update (Z = 6 projected to 3), one filter per wavefront, per-filter landmarks"}
 
 
+def _free_port():
+  import socket
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def visible_gpus():
+  """Device count without importing torch into this (launcher) process: a forked HIP context must not leak into the ranks."""
+  res = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count() if torch.cuda.is_available() else 0)"],
+                       capture_output=True, text=True)
+  try:
+    return int(res.stdout.strip().split()[-1])
+  except (ValueError, IndexError):
+    return 0
+
+
+def rank_command(n, argv):
+  """The command line the driver itself uses for N > 1: one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1."""
+  return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+          "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(n, argv, capture=False):
+  """`python bench.py --gpus N` without a launcher: re-run this file under torch.distributed.run with N ranks (RCCL).  Fails
+  loudly when the node has fewer than N GPUs (RN_BENCH_BACKEND=gloo, the functional dry run of tests/test_sharding.py, may
+  oversubscribe one GPU; it is never a reported number)."""
+  have = visible_gpus()
+  if have < n and os.environ.get("RN_BENCH_BACKEND", "nccl") == "nccl":
+    raise SystemExit(f"bench.py: --gpus {n} asked, {have} GPU(s) visible on this node: not run")
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+  env.pop("WORLD_SIZE", None)
+  res = subprocess.run(rank_command(n, argv), env=env, cwd=REPO, capture_output=capture, text=True)
+  if capture:
+    return res
+  raise SystemExit(res.returncode)
+
+
+def sweep(args):
+  """--sweep 1,2,4,8: BASELINE.json configs[4] in one invocation.  Weak points keep `--batch` filters per GPU, strong points keep
+  the total of the largest count (524 288 at 8 x 65 536).  A count the node cannot run is reported as "not run" -- never
+  extrapolated.  Efficiency is not computed here (the driver does that from the per-count values)."""
+  counts = sorted({int(c) for c in args.sweep.split(",") if c.strip()})
+  have = visible_gpus()
+  oversub = os.environ.get("RN_BENCH_BACKEND", "nccl") != "nccl"
+  per_gpu = args.batch or (16384 if args.model == "live" else 65536)
+  total = args.global_batch or per_gpu * max(counts)
+  base = ["--steps", str(args.steps), "--warmup", str(args.warmup), "--model", args.model, "--no-extras", "--no-cpu-baseline"]
+  points = {"weak": [], "strong": []}
+  for mode, size in (("weak", ["--batch", str(per_gpu)]), ("strong", ["--global-batch", str(total)])):
+    for g in counts:
+      if g > have and not oversub:
+        points[mode].append({"n_gpus": g, "status": "not run", "reason": f"{have} GPU(s) visible"})
+        continue
+      argv = ["--gpus", str(g)] + base + size
+      if g == 1:
+        res = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True, cwd=REPO,
+                             env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+      else:
+        res = spawn_ranks(g, argv, capture=True)
+      lines = [ln for ln in res.stdout.split("\n") if ln.startswith("{")]
+      if res.returncode != 0 or len(lines) != 1:
+        points[mode].append({"n_gpus": g, "status": "failed", "rc": res.returncode, "stderr_tail": res.stderr[-400:]})
+        continue
+      o = json.loads(lines[0])
+      points[mode].append({"n_gpus": o["n_gpus"], "status": "ok", "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"],
+                           "global_batch": o["config"]["global_batch"], "batch_rank0": o["config"]["batch_per_gpu"],
+                           "roofline_frac_rank_max": o["roofline"]["frac"]})
+  ok = [p_ for p_ in points["weak"] if p_["status"] == "ok"]
+  head = ok[-1] if ok else {}
+  print(json.dumps({"metric": "EKF predict+update steps/sec at batch N", "value": head.get("value"), "unit": "steps/s",
+                    "n_gpus": head.get("n_gpus"), "steps": args.steps, "warmup": args.warmup, "ms_per_step": head.get("ms_per_step"),
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                    "config": {"workload": f"{args.model} sweep over GPU counts {counts}: weak = {per_gpu} filters per GPU, strong = {total} filters in total",
+                               "parallelism": "batch-sharded, no data-path collective (RCCL only for the barrier and the SUM/MAX of the timing)"},
+                    "sweep": points}))
+  return 0
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -416,7 +497,15 @@ def main():
   ap.add_argument("--model", default="kinematic6", choices=["kinematic6", "kinematic", "kinematic9", "live"])
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-extras", action="store_true", help="skip the additional configs reported under 'extra'")
+  ap.add_argument("--sweep", default=None, metavar="1,2,4,8",
+                  help="run every listed GPU count in this one invocation (weak: --batch per GPU; strong: --global-batch or "
+                       "batch x the largest count) and print ONE JSON line holding all points; counts this node cannot run are marked 'not run'")
   args = ap.parse_args()
+
+  if args.sweep:
+    return sweep(args)
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    return spawn_ranks(args.gpus, sys.argv[1:])
 
   import torch
   import torch.distributed as dist
@@ -425,10 +514,15 @@ def main():
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if world != args.gpus:
+    raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to report a line "
+                     "whose n_gpus differs from what was asked for")
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs a HIP device: rednose_amd has no CPU path")
   ndev = torch.cuda.device_count()
-  dev_index = local_rank % ndev                    # one rank per GPU; the modulo only matters for single-GPU dry runs
+  if world > ndev and os.environ.get("RN_BENCH_BACKEND", "nccl") == "nccl":
+    raise SystemExit(f"bench.py: {world} ranks but only {ndev} GPU(s) visible; one rank per GPU over RCCL is the only measured mode")
+  dev_index = local_rank % ndev                    # one rank per GPU; the modulo only matters for single-GPU gloo dry runs
   torch.cuda.set_device(dev_index)
   dev = torch.device(f"cuda:{dev_index}")
   if world > 1:
@@ -482,7 +576,7 @@ def main():
       "metric": "EKF predict+update steps/sec at batch N",
       "value": value,
       "unit": "steps/s",
-      "n_gpus": world,
+      "n_gpus": dist.get_world_size() if world > 1 else 1,        # the ranks that actually ran (the process group's own count)
       "steps": K,
       "warmup": W,
       "ms_per_step": wall_max * 1e3 / K,
@@ -519,4 +613,4 @@ def main():
 
 
 if __name__ == "__main__":
-  main()
+  sys.exit(main())

@@ -71,8 +71,9 @@ def test_two_rank_sharding_matches_single_process():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("launcher", ["driver", "self"])
 @pytest.mark.parametrize("mode", ["weak", "strong"])
-def test_bench_two_ranks_on_one_gpu(mode):
+def test_bench_two_ranks_on_one_gpu(mode, launcher):
   """bench.py's N > 1 path end to end: two ranks launched the way the driver launches them (torch.distributed.run,
   127.0.0.1 rendezvous), both on the ONE leased GPU over gloo (RCCL refuses two ranks per device; RN_BENCH_BACKEND exists for
   exactly this dry run).  Checks the aggregated JSON line: SUM of steps over ranks, one line, rank 0 only."""
@@ -81,9 +82,13 @@ def test_bench_two_ranks_on_one_gpu(mode):
   import sys
   env = dict(os.environ, RN_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
   size = ["--batch", "4096"] if mode == "weak" else ["--global-batch", "8190"]
-  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-         "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
-         "--no-cpu-baseline"] + size
+  tail = [os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5", "--no-cpu-baseline"] + size
+  if launcher == "driver":
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + tail
+  else:                      # `python bench.py --gpus 2` on its own: bench.py starts the two ranks itself
+    cmd = [sys.executable] + tail
+    env.pop("WORLD_SIZE", None)
   res = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=REPO, timeout=600)
   assert res.returncode == 0, res.stderr[-3000:]
   lines = [ln for ln in res.stdout.split("\n") if ln.startswith("{")]
@@ -94,3 +99,54 @@ def test_bench_two_ranks_on_one_gpu(mode):
   assert out["config"]["global_batch"] == total
   assert abs(out["value"] - total * 30 / (out["ms_per_step"] * 1e-3 * 30)) < 1e-6 * out["value"]
   assert 0 < out["roofline"]["frac"] < 1 and "extra" not in out
+
+
+def test_bench_gpus_flag_is_honoured_without_a_launcher():
+  """`python bench.py --gpus 2` must never silently measure one GPU: without enough devices it refuses (here: none)."""
+  import subprocess
+  import sys
+  env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RN_BENCH_BACKEND")}
+  res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2"], capture_output=True, text=True, env=env,
+                       cwd=REPO, timeout=300)
+  assert res.returncode != 0 and "not run" in (res.stderr + res.stdout)
+  # a launcher that started a different number of ranks than --gpus asks for is refused too
+  res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="2", RANK="0"), cwd=REPO, timeout=300)
+  assert res.returncode != 0 and "WORLD_SIZE" in (res.stderr + res.stdout)
+
+
+def test_bench_sweep_marks_missing_counts_not_run():
+  import json
+  import subprocess
+  import sys
+  env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RN_BENCH_BACKEND")}
+  env["HIP_VISIBLE_DEVICES"] = ""
+  env["CUDA_VISIBLE_DEVICES"] = ""
+  res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--sweep", "1,2,4,8", "--steps", "2"], capture_output=True, text=True,
+                       env=env, cwd=REPO, timeout=300)
+  assert res.returncode == 0, res.stderr[-2000:]
+  out = json.loads([ln for ln in res.stdout.split("\n") if ln.startswith("{")][0])
+  for mode in ("weak", "strong"):
+    assert [p["n_gpus"] for p in out["sweep"][mode]] == [1, 2, 4, 8]
+    assert all(p["status"] == "not run" for p in out["sweep"][mode])
+  assert out["value"] is None
+
+
+@pytest.mark.gpu
+def test_bench_sweep_on_the_leased_gpu():
+  """--sweep on the one leased GPU: the 1-GPU points run (weak and strong), the 2-GPU points are 'not run'."""
+  import json
+  import subprocess
+  import sys
+  env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RN_BENCH_BACKEND")}
+  res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--sweep", "1,2", "--steps", "30", "--warmup", "5", "--batch", "8192"],
+                       capture_output=True, text=True, env=env, cwd=REPO, timeout=900)
+  assert res.returncode == 0, res.stderr[-2000:]
+  out = json.loads([ln for ln in res.stdout.split("\n") if ln.startswith("{")][0])
+  import torch
+  have = torch.cuda.device_count()
+  for mode, total in (("weak", 8192), ("strong", 16384)):
+    p1, p2 = out["sweep"][mode]
+    assert p1["status"] == "ok" and p1["n_gpus"] == 1 and p1["global_batch"] == total and p1["value"] > 0
+    assert p2["status"] == ("ok" if have >= 2 else "not run")
+  assert out["n_gpus"] == (2 if have >= 2 else 1)
