@@ -52,14 +52,15 @@ def hbm_roofline(bytes_per_launch, launch_s, kernel, traffic=None, **more):
               algorithmic_bytes_per_launch=bytes_per_launch, launch_us=launch_s * 1e6, **more)
 
 
-def measured_traffic(name, n, gen):
-  """HBM bytes per launch from the committed PMC passes -- only if they were taken on the library that is being timed."""
+def measured_traffic(label, lib_name, gen):
+  """HBM bytes per launch of the section `label` of profiles/pmc_workload.py from the committed PMC passes -- only if they were
+  taken on the library that is being timed (digest of generated/{lib_name}.digest)."""
   tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
   if not os.path.exists(tf):
     return None
   with open(tf, encoding="utf-8") as fh:
-    rec = json.load(fh).get(f"{name}_b{n}")
-  dg = os.path.join(gen, f"{name}.digest")
+    rec = json.load(fh).get(label)
+  dg = os.path.join(gen, f"{lib_name}.digest")
   if rec is None or not os.path.exists(dg):
     return None
   with open(dg, encoding="utf-8") as fh:
@@ -313,7 +314,7 @@ def fused_run_extra(torch, model, n, T, dev):
   insts = fp64_valu_instructions(os.path.join(gen, f"lib{M.name}.so"))
   roof = {"bound": "fp64-valu", "achieved": None, "peak": FP64_VALU_LANE_OPS / 1e12, "unit": "T fp64 lane-instructions/s", "frac": None,
           "fp64_valu_instructions_per_filter_step": insts, "hbm_GBs": moved / (best * 1e-3) / 1e9, "hbm_frac": moved / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
-          "kernel": "k_run"}
+          "kernel": "k_run", "traffic": measured_traffic(f"{model}_fused_b{n}", M.name, gen)}
   if insts:
     roof["achieved"] = insts * rate / 1e12
     roof["frac"] = insts * rate / FP64_VALU_LANE_OPS
@@ -367,6 +368,11 @@ def config4_extra(torch, dev, rank, nb=16384, T=2100, chunk=8192):
     assert finite, "config 4: non-finite smoothed estimate"
     res = dict(fwd_ms=fwd, bwd_ms=bwd, gated=float(np.mean(gated)))
   del tx, tP
+  def chunk_traffic(label):
+    """PMC traffic of the 8 192 x 2 100 chunk launch (profiles/pmc_workload.py), times the chunks swept here (sum over launches, like the bytes)."""
+    per = measured_traffic(label, "live_maha", gen) if (chunk == 8192 and T == 2100) else None
+    return None if per is None else per * (nb / chunk)
+
   fwd_bytes = nb * T * 8.0 * ((23 + 484) + 2 * 3) + nb * T           # filtered trace written, z read, y written, flags
   bwd_bytes = nb * (T - 1) * 8.0 * 2 * (23 + 484)                     # filtered pair read, smoothed pair written
   return {"batch": nb, "T": T, "chunk_filters": chunk,
@@ -374,8 +380,8 @@ def config4_extra(torch, dev, rank, nb=16384, T=2100, chunk=8192):
           "combined_steps_per_s": nb * T / ((res["fwd_ms"] + res["bwd_ms"]) * 1e-3),
           "forward_ms": res["fwd_ms"], "backward_ms": res["bwd_ms"], "gated_fraction_of_gnss": res["gated"],
           "trace_bytes_per_chunk": int(T * chunk * (23 + 484) * 8),
-          "roofline_forward": hbm_roofline(fwd_bytes, res["fwd_ms"] * 1e-3, "k_run (trace + gate flags)"),
-          "roofline_backward": hbm_roofline(bwd_bytes, res["bwd_ms"] * 1e-3, "rn::k_rts_group"),
+          "roofline_forward": hbm_roofline(fwd_bytes, res["fwd_ms"] * 1e-3, "k_run (trace + gate flags)", traffic=chunk_traffic("config4_forward")),
+          "roofline_backward": hbm_roofline(bwd_bytes, res["bwd_ms"] * 1e-3, "rn::k_rts_group", traffic=chunk_traffic("config4_backward")),
           "note": "forward = fused batch_run writing the filtered trace + gate flags; backward = batch_rts recomputing the predicted pairs; "
                   "bytes: forward 4 104 B + 1 flag per filter-step, backward 8 112 B per filter-step"}
 
@@ -402,7 +408,7 @@ def msckf_extra(torch, dev):
   msf = e0.elapsed_time(e1) / Kf
   bf = 8.0 * (2 * (36 + 36 * 36) + 6 + 3 + 3)
   return {"batch": nf, "steps": Kf, "value": nf / (msf * 1e-3), "unit": "steps/s",
-          "roofline": hbm_roofline(bf * nf, msf * 1e-3, "k_step_2<true>"),
+          "roofline": hbm_roofline(bf * nf, msf * 1e-3, "k_step_2<true>", traffic=measured_traffic(f"feature36_b{nf}", FK.name, genf)),
           "note": "fused predict + feature-track update (Z = 6 projected to 3), one filter per wavefront, per-filter landmarks"}
 
 
@@ -553,7 +559,7 @@ def main():
       ls = o["dev_ms"] * 1e-3 / oK
       rec = {"batch": on, "steps": oK, "value": on * oK / o["wall"], "unit": "steps/s", "kinds": o["kinds"],
              "algorithmic_bytes_per_filter_step": o["bytes_per_step"],
-             "roofline": hbm_roofline(o["bytes_per_step"] * on, ls, kernel, traffic=measured_traffic(o["M"].name, on, o["gen"]))}
+             "roofline": hbm_roofline(o["bytes_per_step"] * on, ls, kernel, traffic=measured_traffic(f"{'kinematic6' if key == 'kinematic6_1M' else (key or om)}_b{on}", o["M"].name, o["gen"]))}
       if note:
         rec["note"] = note
       extra[key or om] = rec
@@ -588,7 +594,7 @@ def main():
       "config": {"workload": f"{M.name} (D={D}, E={E}, Z={r['Z']:g}) fused predict+update, step-granular (state round-trips HBM each step), "
                              f"batch {n} on rank 0, shared R, scalar dt", "batch_per_gpu": n,
                  "global_batch": int(round(steps_total / K)), "parallelism": f"batch-sharded x{world}, no data-path collective"},
-      "roofline": hbm_roofline(r["bytes_per_step"] * n, launch_s, kern, traffic=measured_traffic(M.name, n, r["gen"])),
+      "roofline": hbm_roofline(r["bytes_per_step"] * n, launch_s, kern, traffic=measured_traffic(f"{M.name}_b{n}", M.name, r["gen"])),
     }
     if not args.no_cpu_baseline and world == 1:
       kind = 1 if args.model != "live" else 10

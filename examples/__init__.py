@@ -26,6 +26,7 @@ def model_table():
     "live": lambda d: LiveKalman.generate_code(d),
     **{f"rand{n}": (lambda d, n=n: _random(n).generate_code(d)) for n in _random_sizes()},
     **{f"randaff{n}": (lambda d, n=n: _random(n, affine=True).generate_code(d)) for n in _affine_sizes()},
+    **{f"randz{n}": (lambda d, n=n: _random(n, wide_obs=True).generate_code(d)) for n, _ in _wide_obs()},
     "rand13_maha": lambda d: _renamed(_random(13), "rand13_maha", d, maha_test_kinds=[1, 3]),
     "live_maha": lambda d: LiveKalman.generate_code(d, name="live_maha", maha_test_kinds=[LK.ECEF_POS]),
   }
@@ -41,9 +42,14 @@ def _affine_sizes():
   return AFFINE_SIZES
 
 
-def _random(n, affine=False):
+def _wide_obs():
+  from examples.random_kf import WIDE_OBS
+  return WIDE_OBS
+
+
+def _random(n, affine=False, wide_obs=False):
   import examples.random_kf as R
-  return getattr(R, f"RandomAffine{n}Kalman" if affine else f"Random{n}Kalman")
+  return getattr(R, f"RandomWideObs{n}Kalman" if wide_obs else (f"RandomAffine{n}Kalman" if affine else f"Random{n}Kalman"))
 
 
 def _renamed(cls, name, folder, **kw):

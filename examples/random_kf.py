@@ -24,9 +24,15 @@ AFFINE_SIZES = (5, 11)     # "randaff{n}": f = A0 x + dt (...) with A0 != I, i.e
                            # model for the reference, which only asserts that F depends on dt, ekf_sym.py:82); one per kernel family
 
 
-def make(n, seed=None, affine=False):
+WIDE_OBS = ((10, 9),)      # "randz{n}": kind 1 is a zbig-dimensional observation (> 8: more than one observation entry per lane in
+                           # the fused run, an 81-entry innovation covariance in registers; the reference puts no limit on ZDIM)
+
+
+def make(n, seed=None, affine=False, zbig=None):
   """-> a KalmanFilter subclass for an n-state random model (seed defaults to 1000 + n)."""
   seed = (2000 if affine else 1000) + n if seed is None else seed
+  if zbig:
+    seed += 5000
   rng = np.random.default_rng(seed)
   A0 = np.eye(n)
   if affine:
@@ -35,7 +41,7 @@ def make(n, seed=None, affine=False):
     A0[n // 2, 1] = -0.03
   A = np.where(rng.random((n, n)) < min(0.5, 3.0 / n), np.round(rng.normal(size=(n, n)), 3), 0.0)
   kinds = {}
-  for k, z in ((1, 3), (2, 1), (3, 2)):
+  for k, z in ((1, zbig or 3), (2, 1), (3, 2)):
     H = np.where(rng.random((z, n)) < min(0.6, 4.0 / n), np.round(rng.normal(size=(z, n)), 3), 0.0)
     H[np.arange(z), rng.choice(n, size=z, replace=False)] = 1.0          # every row observes something
     kinds[k] = (H, int(rng.integers(0, n)), int(rng.integers(0, n)))
@@ -43,12 +49,12 @@ def make(n, seed=None, affine=False):
   sines = [(int(rng.integers(0, n)), int(rng.integers(0, n)), round(float(rng.normal()) * 0.5, 3)) for _ in range(2)]
 
   class RandomKalman(KalmanFilter):
-    name = f"randaff{n}" if affine else f"rand{n}"
+    name = f"randz{n}" if zbig else (f"randaff{n}" if affine else f"rand{n}")
     dim = n
     initial_x = np.round(rng.normal(size=n) * 0.5, 3)
     initial_P_diag = np.round(rng.uniform(0.5, 2.0, size=n), 3)
     Q = np.diag(np.round(rng.uniform(0.01, 0.5, size=n) ** 2, 6))
-    obs_noise = {1: np.eye(3) * 0.1**2, 2: np.eye(1) * 0.2**2, 3: np.diag([0.05**2, 0.3**2])}
+    obs_noise = {1: np.eye(zbig or 3) * 0.1**2, 2: np.eye(1) * 0.2**2, 3: np.diag([0.05**2, 0.3**2])}
 
     @classmethod
     def model(cls):
@@ -79,7 +85,7 @@ def make(n, seed=None, affine=False):
       else:
         self.filter = BatchedEKF(generated_dir, self.name, self.Q, self.initial_x, P0, n, n, batch=batch, device=device)
 
-  RandomKalman.__name__ = f"RandomAffine{n}Kalman" if affine else f"Random{n}Kalman"
+  RandomKalman.__name__ = f"RandomWideObs{n}Kalman" if zbig else (f"RandomAffine{n}Kalman" if affine else f"Random{n}Kalman")
   return RandomKalman
 
 
@@ -88,10 +94,14 @@ for _n in SIZES:
   globals()[f"Random{_n}Kalman"] = make(_n)
 for _n in AFFINE_SIZES:
   globals()[f"RandomAffine{_n}Kalman"] = make(_n, affine=True)
+for _n, _z in WIDE_OBS:
+  globals()[f"RandomWideObs{_n}Kalman"] = make(_n, zbig=_z)
 
 
 if __name__ == "__main__":
-  if sys.argv[1].startswith("randaff"):
+  if sys.argv[1].startswith("randz"):
+    globals()[f"RandomWideObs{int(sys.argv[1].replace('randz', ''))}Kalman"].generate_code(sys.argv[2])
+  elif sys.argv[1].startswith("randaff"):
     globals()[f"RandomAffine{int(sys.argv[1].replace('randaff', ''))}Kalman"].generate_code(sys.argv[2])
   else:
     globals()[f"Random{int(sys.argv[1].replace('rand', ''))}Kalman"].generate_code(sys.argv[2])

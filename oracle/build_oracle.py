@@ -47,6 +47,7 @@ MODELS = {
   "feature36": dict(model="examples.feature_kf:WideFeatureKalman"),
   **{f"rand{n}": dict(model=f"examples.random_kf:Random{n}Kalman") for n in (3, 5, 8, 11, 13, 17, 24, 32, 40, 56)},
   **{f"randaff{n}": dict(model=f"examples.random_kf:RandomAffine{n}Kalman") for n in (5, 11)},
+  "randz10": dict(model="examples.random_kf:RandomWideObs10Kalman"),
   "rand13_maha": dict(model="examples.random_kf:Random13Kalman", rename="rand13_maha", maha_test_kinds=[1, 3]),
   "kinematic6_maha": dict(model="examples.kinematic6_kf:Kinematic6Kalman", rename="kinematic6_maha",
                           maha_test_kinds=[1]),

@@ -1,51 +1,46 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_pmc_hbm_traffic.txt (profiles/collect.sh) -> the JSON bench.py reads for `roofline.traffic`.
+"""<tag>_pmc_FETCH_SIZE.json + <tag>_pmc_WRITE_SIZE.json (profiles/collect.sh, one section per timed kernel configuration)
+-> the JSON bench.py reads for `roofline.traffic`, keyed by section label.
 
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB per dispatch -> bytes): FETCH_SIZE under-reports wide coalesced
-reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section; the calibration copy in the same file confirms it per run),
-WRITE_SIZE is taken as is.  Each entry carries the digest of the library it was measured on ({generated}/{name}.digest):
-bench.py prints a traffic figure only for the library with that digest."""
+reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section; the 1 GiB calibration copy of the same pass is recorded next to
+every entry), WRITE_SIZE is taken as is.  Each entry carries the digest of the library it was measured on
+({generated}/{name}.digest): bench.py prints a traffic figure only for the library with that digest."""
 import json
 import os
-import re
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main(txt, tag):
-  rows = {}
-  model = None
-  with open(txt, encoding="utf-8") as f:
-    for line in f:
-      m = re.search(r"rocprofv3 --pmc (\w+) .*bench\.py(?: --model (\w+))?", line)
-      if m:
-        model = m.group(2) or "kinematic6"
-        continue
-      m = re.match(r"(k_step_\S+)\(.*?\s+(FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+([\d.]+)", line)
-      if m and model:
-        rows.setdefault((model, m.group(1)), {})[m.group(2)] = (int(m.group(3)), float(m.group(4)))
+def main(fetch_json, write_json, tag):
+  with open(fetch_json, encoding="utf-8") as f:
+    fe = json.load(f)
+  with open(write_json, encoding="utf-8") as f:
+    wr = json.load(f)
+  gen = os.environ.get("RN_GEN_DIR") or os.path.join(REPO, "generated")
   calib = {}
-  with open(txt, encoding="utf-8") as f:
-    for line in f:
-      m = re.match(r"__amd_rocclr_copyBuffer\s+(FETCH_SIZE|WRITE_SIZE)\s+\d+\s+([\d.]+)", line)
-      if m:
-        calib[m.group(1)] = float(m.group(2)) / (2**30 / 1024)
+  for name, rec in (("FETCH_SIZE", fe), ("WRITE_SIZE", wr)):
+    c = rec.get("calibration") or {}
+    if c.get("counters", {}).get(name):
+      calib[name] = c["counters"][name] * 1024.0 / c["bytes_read"]        # counter bytes / true bytes (expected 0.5 and 1.0)
+  wsec = {s["label"]: s for s in wr["sections"]}
   out = {}
-  for model, n in (("kinematic6", 65536), ("live", 16384)):
-    ks = {k: v for (mdl, k), v in rows.items() if mdl == model and "FETCH_SIZE" in v and "WRITE_SIZE" in v and "<true>" in k}
-    if not ks:
+  for s in fe["sections"]:
+    w = wsec.get(s["label"])
+    if w is None or "FETCH_SIZE" not in s["counters"] or "WRITE_SIZE" not in w["counters"]:
       continue
-    calls = sum(v["FETCH_SIZE"][0] for v in ks.values())
-    fetch = sum(v["FETCH_SIZE"][0] * v["FETCH_SIZE"][1] for v in ks.values()) / calls
-    write = sum(v["WRITE_SIZE"][0] * v["WRITE_SIZE"][1] for v in ks.values()) / sum(v["WRITE_SIZE"][0] for v in ks.values())
-    dg = os.path.join(REPO, "generated", f"{model}.digest")
+    fetch, write = s["counters"]["FETCH_SIZE"], w["counters"]["WRITE_SIZE"]
+    dg = os.path.join(gen, f"{s['lib']}.digest")
     digest = open(dg, encoding="utf-8").read().strip() if os.path.exists(dg) else None
-    out[f"{model}_b{n}"] = {"hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0, "fetch_size_kib_raw": fetch, "fetch_correction": 2.0,
-                           "write_size_kib_raw": write, "write_correction": 1.0, "kernels": sorted(ks), "calibration_copy_ratio": calib,
-                           "source": f"profiles/{tag}_pmc_hbm_traffic.txt", "lib_digest": digest}
+    hbm = (2.0 * fetch + write) * 1024.0
+    out[s["label"]] = {"hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": s["algorithmic_bytes_per_dispatch"],
+                       "traffic_ratio": hbm / s["algorithmic_bytes_per_dispatch"], "fetch_size_kib_raw": fetch, "fetch_correction": 2.0,
+                       "write_size_kib_raw": write, "write_correction": 1.0, "kernels": sorted(s["kernels"]), "dispatches": s["dispatches"],
+                       "calibration_copy_ratio": calib, "source": f"profiles/{tag}_pmc_FETCH_SIZE.txt, profiles/{tag}_pmc_WRITE_SIZE.txt",
+                       "lib": s["lib"], "lib_digest": digest}
   print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
-  main(sys.argv[1], sys.argv[2])
+  main(*sys.argv[1:4])

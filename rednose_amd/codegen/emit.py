@@ -22,14 +22,21 @@ SMALL_MAX_E = 7    # lane-per-filter register budget: x, P and the update's temp
                    # wrong for single filters on some runs (tools/stress_run_trace.py); 8 goes to the lane-group kernels
 
 
-RTS_ONE_WAVE = set() # model names whose smoother spilled under the two-wavefronts-per-SIMD register budget: regenerated with the full file
-FORCE_WIDE = set()   # model names whose lane-per-filter build spilled registers: gen_code regenerates them in the lane-group family
+# Fallback structures gen_code may ask for when the first build of a model does not fit the register file (they are arguments
+# of ONE emit() call, not process state: nothing about a model survives its gen_code call):
+#   force_wide         the lane-per-filter build spilled registers -> lane-group family
+#   no_model_defaults  the per-model tuning defaults (two wavefronts per SIMD) spilled -> general structure
+#   rts_one_wave       the smoother spilled under the two-wavefronts-per-SIMD budget -> full register file
+#   no_rts             the smoother still touches scratch -> library without batch_rts (forward filter unaffected)
+FALLBACKS = ("force_wide", "no_model_defaults", "rts_one_wave", "no_rts")
+_active = frozenset()      # fallbacks of the emit() call in progress
 
 
-def family(spec):
+def family(spec, fallbacks=None):
   """Lane-per-filter kernels up to SMALL_MAX_E error states; lane-group kernels above, and for every MSCKF model
   (the null-space projection of feature-track kinds is emitted for the lane-group family only)."""
-  if any(k.He_sym is not None for k in spec.kinds) or spec.name in FORCE_WIDE:
+  fb = _active if fallbacks is None else fallbacks
+  if any(k.He_sym is not None for k in spec.kinds) or "force_wide" in fb:
     return "wide"
   from rednose_amd.codegen import tuning
   return "small" if spec.dim_err <= min(SMALL_MAX_E, tuning.current().small_max_e) else "wide"
@@ -49,11 +56,17 @@ def ea_req(k):
   return " && ea" if ea_len(k) else ""
 
 
-def emit(spec):
-  """-> (header_text, hip_text)."""
+def emit(spec, fallbacks=()):
+  """-> (header_text, hip_text).  `fallbacks`: see FALLBACKS."""
+  global _active      # pylint: disable=global-statement
   from rednose_amd.codegen import tuning
-  with tuning.using_model(spec):
-    return _emit(spec)
+  assert set(fallbacks) <= set(FALLBACKS), fallbacks
+  _active = frozenset(fallbacks)
+  try:
+    with tuning.using_model(spec, enabled="no_model_defaults" not in _active):
+      return _emit(spec)
+  finally:
+    _active = frozenset()
 
 
 def plugin_text(spec):
@@ -105,10 +118,6 @@ def _emit(spec):
         kernels=lambda sp_: emit_wide2.kernels(sp_) + "\n" + emit_wide3.kernels(sp_) + "\n" + emit_wide2.maha_kernels(sp_),
         launch_predict=emit_wide2.launch_predict, launch_step=emit_wide2.launch_step, launch_run=emit_wide3.launch_run,
         launch_maha=emit_wide2.launch_maha)
-      if tuning.current().wide_step3:     # experiment: step-granular kernels in the fused run's layout
-        fam_mod.kernels = lambda sp_: (emit_wide2.kernels(sp_) + "\n" + emit_wide3.kernels(sp_) + "\n" + emit_wide3.step_kernels(sp_) +
-                                       "\n" + emit_wide2.maha_kernels(sp_))
-        fam_mod.launch_step = emit_wide3.launch_step3
   else:
     fam_mod = types.SimpleNamespace(
       kernels=lambda sp_: emit_small.kernels(sp_) + "\n" + emit_small.maha_kernels(sp_),
@@ -163,7 +172,7 @@ def _emit(spec):
   # smoother.  Lane-per-filter models: rn::k_rts (state and covariance of a filter in one lane's registers).  Lane-group
   # models, MSCKF ones included (their main block is smoothed, ekf_sym.py:675-686): rn::k_rts_group.
   group_rts = fam == "wide"
-  has_rts = group_rts or (fam == "small" and spec.dim_main == spec.dim_x and spec.dim_main_err == spec.dim_err)
+  has_rts = (group_rts or (fam == "small" and spec.dim_main == spec.dim_x and spec.dim_main_err == spec.dim_err)) and "no_rts" not in _active
   if has_rts:
     quat = "".join(f" rn::normalize_quat<{D}>(x, {q});" for q in spec.quaternion_idxs)
     grp = f"""
@@ -174,7 +183,7 @@ def _emit(spec):
   static constexpr int OFF_X = SLOT_OFF_X;
   static constexpr int OFF_DT = SLOT_OFF_DT;
   static __device__ __forceinline__ void scal(const double* xin, double dt, double* sl, int norm) {{ scal_predict(xin, dt, sl, norm); }}
-  static constexpr int WAVES = {2 if (M <= 22 and spec.name not in RTS_ONE_WAVE) else 1};       // wavefronts per SIMD the register budget is set for (see k_rts_group)
+  static constexpr int WAVES = {2 if (M <= 22 and "rts_one_wave" not in _active) else 1};       // wavefronts per SIMD the register budget is set for (see k_rts_group)
   static __device__ __forceinline__ void mat_predict(const double (&row)[{M}], double* sB, const double* gQc, const double* sl, int cc, bool act,
                                                      double (&y)[{M}]) {{ mat_predict_rts(row, sB, gQc, sl, cc, act, y); }}""" if group_rts else ""
     src.append(f"""

@@ -181,7 +181,6 @@ def _lean_update(k, Hs, lay, E, rows_in_regs=False):
   Zf = k.zdim
   feat = k.He_sym is not None
   Z = Zf - EADIM if feat else Zf
-  U = tuning.current().wide_unroll
   used = sorted({kk for zi in range(Zf) for kk, _ in Hs.row_nz(zi)})
   b = [f"double R[{Z * Z}];", f"double* pr = sP + cc * {E};"]
   if rows_in_regs:
@@ -237,7 +236,7 @@ def _lean_update(k, Hs, lay, E, rows_in_regs=False):
   b.append("if (act) { " + " ".join(f"sK[{zi} * {E} + cc] = kk[{zi}];" for zi in range(Z)) + f" sw[{lay.OFF_DX} + cc] = dxc; if (cc == 0) sw[{lay.OFF_FL}] = {fl}; }}")
   b.append("rn::wave_lds_sync();")
   src = "row[j]" if rows_in_regs else "pr[j]"
-  b += ["if (act) {", "#pragma unroll" if rows_in_regs else f"#pragma unroll {U}", f"  for (int j = 0; j < {E}; j++) {{",
+  b += ["if (act) {", "#pragma unroll" if rows_in_regs else "#pragma unroll 2", f"  for (int j = 0; j < {E}; j++) {{",
         f"    const double bj = {src} - (" + " + ".join(f"kk[{zi}]*sG[{zi * E} + j]" for zi in range(Z)) + ");",
         "    pr[j] = bj + (" + " + ".join(f"Dm_{zi}*sK[{zi * E} + j]" for zi in range(Z)) + ");", "  }", "}", "rn::wave_lds_sync();"]
   return b
@@ -401,7 +400,7 @@ def device_functions(spec, lay_cls=None, sfx=""):
     Z = k.zdim
     if lean == 1:
       b = _lean_update(k, Hs, lay, E)
-    elif lean == 2 or k.He_sym is not None:
+    elif k.He_sym is not None:
       b = _lean_update(k, Hs, lay, E, rows_in_regs=True)
     else:
       b = [f"double row[{E}], R[{Z * Z}];", "#pragma unroll", f"for (int j = 0; j < {E}; j++) row[j] = sP[cc * {E} + j];"]

@@ -25,8 +25,8 @@ twice: columns of A = P F^T are rows of F P (predict_fn), and column j of G = He
 Results agree with the step-granular path to rounding (different association of the same sums); tests/test_gpu_run.py,
 test_gpu_random.py, test_gpu_msckf.py, test_gpu_fullsize.py bound it.  Measurements and what hipcc needed: DESIGN.md section 3.
 
-`step_kernels` (tuning knob wide_step3, off): the same layout for the step-granular entry points -- measured slower than the
-three-phase kernels of emit_wide2 (one wavefront per SIMD cannot overlap its own HBM round trip), kept as an experiment.
+(The same layout for the step-granular entry points was built in round 2 and measured slower than the three-phase kernels of
+emit_wide2 -- one wavefront per SIMD cannot overlap its own HBM round trip; numbers in profiles/tuning_notes.md.)
 """
 import sympy as sp
 
@@ -181,7 +181,7 @@ def predict_fn(spec):
   return "\n".join([head] + _ind(b) + ["}"])
 
 
-def update_fn(spec, k, prefetch=False):
+def update_fn(spec, k):
   """Matrix part of the update of kind k on register rows.  y, the non-trivial entries of He = H H_mod and, for feature-track
   kinds, the Householder reflectors and the projected noise are read from the filter's slot (phase 1 put them there); dx and
   the gate / rank flags go back to it."""
@@ -230,11 +230,6 @@ def update_fn(spec, k, prefetch=False):
           "#pragma unroll", f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}",
           f"    rn::spd_factor<{Z}>(S, L, iL);", "  }", "}"]
   b += _tl(11)
-  if prefetch:
-    # every ordinary global load of this step (Q, R, extra arguments, z) has been consumed: an asynchronous HBM -> LDS copy
-    # issued here is not drained early by a later s_waitcnt vmcnt (the counter retires in order); the image of P is idle from
-    # predict's transposition to the end of the step
-    b += [f"if (pf_nd > 0) rn::async_copy_g2l<FPWR * {E * E}>(pf_src, pf_nd, pf_dst, (int)threadIdx.x);"]
   for s in range(R):
     b.append(f"rn::spd_solve<{Z}>(L, iL, kk{s});                       // K[row][:]")
     if feat:     # the reference's numpy path ignores a measurement whose null-space projection failed (ekf_sym.py:589-591)
@@ -265,9 +260,8 @@ def update_fn(spec, k, prefetch=False):
   b.append("rn::wave_lds_sync();      // the broadcast buffer is free again")
   rows = ", ".join(f"double (&row{s})[{E}]" for s in range(R))
   idx = ", ".join(f"const int rr{s}, const int rc{s}, const bool ok{s}" for s in range(R))
-  pf = ", const double* __restrict__ pf_src, const int pf_nd, double* pf_dst" if prefetch else ""
-  head = (f"__device__ __forceinline__ void update_{k.kind}_rows{'_pf' if prefetch else ''}({rows}, const double* __restrict__ gR, double* sP, "
-          f"double* sG, const double* sl, double* sw, {idx}{pf}{_tl_arg()}) {{")
+  head = (f"__device__ __forceinline__ void update_{k.kind}_rows({rows}, const double* __restrict__ gR, double* sP, "
+          f"double* sG, const double* sl, double* sw, {idx}{_tl_arg()}) {{")
   return "\n".join([head] + _ind(b) + ["}"])
 
 
@@ -292,7 +286,29 @@ def run_kernel(spec):
   GL, R, FPW = layout(spec)
   lay, _, _ = _tables(spec)
   zmax = max(k.zdim for k in spec.kinds)
-  assert FPW * zmax <= 64, "the observation prefetch of the fused run takes one value per lane"
+  # observation entries a lane carries between HBM and the slots: FPW * zmax values per tile and step, one per lane and pass
+  # (a single pass up to 8-dimensional observations at 8 filters per wavefront; the reference puts no limit on ZDIM, ekf_c.c:37)
+  NZ = -(-(FPW * zmax) // 64)
+  if NZ == 1:
+    z_decl = f"const int zf = lane / {zmax}, zc = lane % {zmax};                // observation entry this lane carries between HBM and the slots"
+    z_tile_a = "    const bool zlive = zf < cnt;\n"
+    z_tile_b = f"    double* slz = s_sl + (zlive ? zf : 0) * SLOT_R + {lay.OFF_Y} + zc;\n"
+    z_first = f"    if (zlive) *slz = gz[base * {zmax} + lane];"
+    z_next = ("      double zn = 0.0;                                 // next step's observation, in flight during this step\n"
+              f"      if (t + 1 < T && zlive) zn = gz[((t + 1) * n + base) * {zmax} + lane];")
+    z_out = f"      if (zlive) gz[(t * n + base) * {zmax} + lane] = *slz;          // y (the observation itself after an unknown kind)"
+    z_commit = "      if (zlive) *slz = zn;"
+  else:
+    q_ = range(NZ)
+    z_decl = " ".join(f"const int zf{q} = (lane + {64 * q}) / {zmax}, zc{q} = (lane + {64 * q}) % {zmax};" for q in q_) + \
+             f"      // {NZ} observation entries per lane ({FPW} filters x {zmax})"
+    z_tile_a = "".join(f"    const bool zlive{q} = zf{q} < cnt;\n" for q in q_)
+    z_tile_b = "".join(f"    double* slz{q} = s_sl + (zlive{q} ? zf{q} : 0) * SLOT_R + {lay.OFF_Y} + zc{q};\n" for q in q_)
+    z_first = "\n".join(f"    if (zlive{q}) *slz{q} = gz[base * {zmax} + lane + {64 * q}];" for q in q_)
+    z_next = "\n".join([f"      double zn[{NZ}] = {{{', '.join('0.0' for _ in q_)}}};                 // next step's observations, in flight during this step"] +
+                        [f"      if (t + 1 < T && zlive{q}) zn[{q}] = gz[((t + 1) * n + base) * {zmax} + lane + {64 * q}];" for q in q_])
+    z_out = "\n".join(f"      if (zlive{q}) gz[(t * n + base) * {zmax} + lane + {64 * q}] = *slz{q};" for q in q_)
+    z_commit = "\n".join(f"      if (zlive{q}) *slz{q} = zn[{q}];" for q in q_)
   EAM = ea_max(spec)
   rows = ", ".join(f"row{s}" for s in range(R))
   idx = ", ".join(f"rr{s}, rc{s}, ok{s}" for s in range(R))
@@ -371,29 +387,26 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
   const int lane = threadIdx.x;
   const int g = lane / GLR;
   const int c = lane % GLR;
-  const int zf = lane / {zmax}, zc = lane % {zmax};                // observation entry this lane carries between HBM and the slots
+  {z_decl}
   const int64_t tiles = (n + FPWR - 1) / FPWR;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
     const int64_t base = tile * FPWR;
     const int cnt = (n - base) < FPWR ? (int)(n - base) : FPWR;
     const int gg = g < cnt ? g : 0;
     const bool live = g < cnt;
-    const bool zlive = zf < cnt;
-    double* sP = s_P + gg * {EE};
+{z_tile_a}    double* sP = s_P + gg * {EE};
     double* sl = s_sl + gg * SLOT_R;
-    double* slz = s_sl + (zlive ? zf : 0) * SLOT_R + {lay.OFF_Y} + zc;
-{decl_idx}
+{z_tile_b}{decl_idx}
     int lb = lane;
     asm volatile("" : "+v"(lb));         // opaque copy of the lane index: the copies' index arithmetic stays inside the tile
     rn::copy_g2l<FPWR * {EE}>(gP + base * {EE}, cnt * {EE}, s_P, lb);
     for (int i = lane; i < cnt * {D}; i += 64) s_sl[(i / {D}) * SLOT_R + {lay.OFF_X} + i % {D}] = gx[base * {D} + i];
-    if (zlive) *slz = gz[base * {zmax} + lane];
+{z_first}
     rn::wave_lds_sync();
 {decl_rows}
 {load_rows}
     for (int64_t t = 0; t < T; t++) {{
-      double zn = 0.0;                                 // next step's observation, in flight during this step
-      if (t + 1 < T && zlive) zn = gz[((t + 1) * n + base) * {zmax} + lane];
+{z_next}
       const int kind = kinds[t];
       const double dt = dts[t];
       const bool do_pred = {id0_guard};
@@ -437,7 +450,7 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       }}
       rn::wave_lds_sync();
       {TL(5)}
-      if (zlive) gz[(t * n + base) * {zmax} + lane] = *slz;          // y (the observation itself after an unknown kind)
+{z_out}
       int lz = lane;
       asm volatile("" : "+v"(lz));       // the copies' per-iteration indices are not worth registers across the step loop
       if (tx != nullptr) {{
@@ -450,7 +463,7 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       }}
       rn::wave_lds_sync();
       {TL(6)}
-      if (zlive) *slz = zn;
+{z_commit}
       rn::wave_lds_sync();
       {TL(7)}{aug}
     }}
@@ -464,132 +477,6 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
   }}
 }}
 """
-
-
-def step_kernels(spec):
-  """EXPERIMENT (tuning knob wide_step3, off by default): the step-granular kernels k_step_{kind}<DO_PREDICT> in the fused
-  run's layout.  A wavefront takes tiles of FPWR filters in turn; P goes HBM -> LDS image -> register rows, the step runs as
-  in k_run, the rows are stored straight from registers (16-byte stores at a row stride: the image is busy), and the NEXT
-  tile's P is copied HBM -> LDS asynchronously from the middle of the update on, so that from the second tile on the load
-  latency is off the critical path.  Same arguments as emit_wide2's kernels (per-filter dt, per-filter R, extra arguments)."""
-  D, E = spec.dim_x, spec.dim_err
-  EE = E * E
-  GL, R, FPW = layout(spec)
-  lay, _, _ = _tables(spec)
-  rows = ", ".join(f"row{s}" for s in range(R))
-  idx = ", ".join(f"rr{s}, rc{s}, ok{s}" for s in range(R))
-  decl_rows = "\n".join(f"    double row{s}[{E}];" for s in range(R))
-  decl_idx = "\n".join(f"    const int rr{s} = c + {GL * s}; const bool ok{s} = live && rr{s} < {E}; const int rc{s} = rr{s} < {E} ? rr{s} : 0;" for s in range(R))
-  load_rows = "\n".join(f"#pragma unroll\n    for (int j = 0; j < {E}; j++) row{s}[j] = sP[rc{s} * {E} + j];" for s in range(R))
-  if E % 2 == 0:      # rows start 16-byte aligned (P is, the API checks it): 16-byte stores
-    store_rows = "\n".join(f"    if (ok{s}) {{\n      double2* pr_ = reinterpret_cast<double2*>(gP + (base + g) * {EE} + rr{s} * {E});\n#pragma unroll\n"
-                           f"      for (int j = 0; j < {E // 2}; j++) pr_[j] = make_double2(row{s}[2 * j], row{s}[2 * j + 1]);\n    }}" for s in range(R))
-  else:
-    store_rows = "\n".join(f"    if (ok{s}) {{\n#pragma unroll\n      for (int j = 0; j < {E}; j++) gP[(base + g) * {EE} + rr{s} * {E} + j] = row{s}[j];\n    }}"
-                           for s in range(R))
-  if spec.identity_at_dt0():
-    do_pred = "DO_PREDICT && !(gdt == nullptr && dt_scalar == 0.0)"
-  else:
-    do_pred = "DO_PREDICT"
-  out = []
-  for k in spec.kinds:
-    Z = k.zdim
-    assert FPW * Z <= 64
-    EA = ea_dim(k)
-    feat = k.He_sym is not None
-    out.append(update_fn(spec, k, prefetch=True))
-    sargs = f"sl, sl + {lay.OFF_Y}"
-    if EA:
-      sargs += f", gea + (base + g) * {EA}"
-    if feat:
-      sargs += f", r_per_filter ? gR + (base + g) * {Z * Z} : gR"
-    out.append(f"""
-template <bool DO_PREDICT>
-__global__ __launch_bounds__(64) void k_step3_{k.kind}(double* __restrict__ gx, double* __restrict__ gP,
-    double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const double* __restrict__ gea,
-    const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
-    const int norm_quats, uint8_t* __restrict__ flags) {{
-  (void)gea;
-  __shared__ __attribute__((aligned(16))) double s_P[FPWR * {EE} + 2];
-  __shared__ __attribute__((aligned(16))) double s_G[FPWR * {Z * E}];
-  __shared__ __attribute__((aligned(16))) double s_sl[FPWR * SLOT_R];
-  const int lane = threadIdx.x;
-  const int g = lane / GLR;
-  const int c = lane % GLR;
-  const int zf = lane / {Z}, zc = lane % {Z};
-  const bool do_pred = {do_pred};
-  const int64_t tiles = (n + FPWR - 1) / FPWR;
-  int64_t tile = blockIdx.x;
-  if (tile < tiles) {{
-    const int64_t base0 = tile * FPWR;
-    const int cnt0 = (n - base0) < FPWR ? (int)(n - base0) : FPWR;
-    rn::async_copy_g2l<FPWR * {EE}>(gP + base0 * {EE}, cnt0 * {EE}, s_P, lane);
-  }}
-  for (; tile < tiles; tile += gridDim.x) {{
-    const int64_t base = tile * FPWR;
-    const int cnt = (n - base) < FPWR ? (int)(n - base) : FPWR;
-    const int gg = g < cnt ? g : 0;
-    const bool live = g < cnt;
-    const bool zlive = zf < cnt;
-    double* sP = s_P + gg * {EE};
-    double* sl = s_sl + gg * SLOT_R;
-    double* slz = s_sl + (zlive ? zf : 0) * SLOT_R + {lay.OFF_Y} + zc;
-{decl_idx}
-    for (int i = lane; i < cnt * {D}; i += 64) s_sl[(i / {D}) * SLOT_R + {lay.OFF_X} + i % {D}] = gx[base * {D} + i];
-    if (zlive) *slz = gz[base * {Z} + lane];
-    rn::async_wait();                   // this tile's P (requested before the loop or during the previous tile's update)
-    rn::wave_lds_sync();
-{decl_rows}
-{load_rows}
-    // ---- phase 1a / 2a: predict ----
-    if (c == 0 && live) {{
-      if (do_pred) scal_predict_r(sl + {lay.OFF_X}, gdt != nullptr ? gdt[base + g] : dt_scalar, sl, norm_quats);
-      else scal_keep_r(sl + {lay.OFF_X}, sl, DO_PREDICT ? norm_quats : 0);      // predict(dt = 0) still renormalises
-    }}
-    rn::wave_lds_sync();
-    if (do_pred) predict_rows({rows}, sP, gQ, sl, {idx});
-    // ---- phase 1b / 2b: update; the next tile's P starts to land in the image from the middle of it ----
-    if (c == 0 && live) scal_obs_{k.kind}_r{'<true>' if feat else ''}({sargs});
-    rn::wave_lds_sync();
-    const int64_t nbase = (tile + gridDim.x) * FPWR;
-    const int ncnt = (tile + gridDim.x) < tiles ? ((n - nbase) < FPWR ? (int)(n - nbase) : FPWR) : 0;
-    update_{k.kind}_rows_pf({rows}, r_per_filter ? gR + (base + gg) * {Z * Z} : gR, sP, s_G + gg * {Z * E}, sl, sl, {idx},
-        gP + nbase * {EE}, ncnt * {EE}, s_P);
-    // ---- phase 3: injection; everything leaves from registers / the slots ----
-    if (c == 0 && live) {{
-      const int fl = scal_inject_r(sl, sl + {lay.OFF_X}, norm_quats) | (int)sl[{lay.OFF_FL}];
-      if (flags != nullptr) flags[base + g] = (uint8_t)fl;
-    }}
-    rn::wave_lds_sync();
-    if (zlive) gz[base * {Z} + lane] = *slz;
-    for (int i = lane; i < cnt * {D}; i += 64) gx[base * {D} + i] = s_sl[(i / {D}) * SLOT_R + {lay.OFF_X} + i % {D}];
-{store_rows}
-    rn::wave_lds_sync();
-  }}
-}}
-""")
-  return "\n".join(out)
-
-
-def launch_step3(kind, do_predict):
-  from rednose_amd.codegen import tuning
-  per_cu = 4 * max(1, tuning.current().wide_step3)      # knob value 2: twice as many workgroups as resident slots (one tile each at 16 384 live filters)
-  tf = "true" if do_predict else "false"
-  if do_predict:
-    args = "x, P, z, R, r_per_filter, ea, Q, dt_vec, dt, n, norm_quats, flags"
-  else:
-    args = "x, P, z, R, r_per_filter, ea, nullptr, nullptr, 0.0, n, norm_quats, flags"
-  return f"""  const int64_t tiles = (n + FPWR - 1) / FPWR;
-  // one wavefront per SIMD is resident (4 per CU): more workgroups than that queue behind them, fewer tiles per wavefront
-  // than two leave nothing to prefetch
-  static const int64_t slots = [] {{
-    int dev_ = 0, cus_ = 256;
-    (void)hipGetDevice(&dev_);
-    (void)hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, dev_);
-    return (int64_t){per_cu} * cus_;
-  }}();
-  hipLaunchKernelGGL(k_step3_{kind}<{tf}>, dim3((unsigned)(tiles < slots ? tiles : slots)), dim3(64), 0, (hipStream_t)stream,
-                     {args});"""
 
 
 def launch_run():

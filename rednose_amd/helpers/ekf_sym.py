@@ -43,56 +43,50 @@ def gen_code(folder, name, f_sym, dt_sym, x_sym, obs_eqs, dim_x, dim_err, eskf_p
   with open(os.path.join(folder, f"{name}.hip"), "w", encoding="utf-8") as f:
     f.write(source)
   if compile and not fresh:
-    rn_build.compile_filter(folder, name, verbose=verbose)
     # Register spills are not tolerated where they were seen to matter: a lane-per-filter build that spilled (8 error states
     # in round 1) also produced a wrong fused-run trace on some runs, and whether hipcc spills depends on the user's f / h
-    # expressions, not only on the state count.  Such a model is regenerated in the lane-group family; a smoother kernel that
-    # spills is an error (RN_ALLOW_SPILLS=1 overrides, for experiments).
+    # expressions, not only on the state count.  The model is then re-emitted in a fallback structure (emit.FALLBACKS) and
+    # rebuilt; the stamp keeps the digest of the FIRST emission, so a later gen_code call of this model emits the default text
+    # again, finds it stamped and reuses the library.  RN_ALLOW_SPILLS=1 keeps the first build (experiments).
     from rednose_amd.codegen import emit as rn_emit
-    bad = rn_build.spilled_kernels(rn_build.compile_filter.last_usage)
-    if bad and rn_emit.family(spec) == "small" and not os.environ.get("RN_ALLOW_SPILLS"):
-      if verbose:
-        print(f"{name}: lane-per-filter kernels {bad} spill registers -> regenerating in the lane-group family")
-      rn_emit.FORCE_WIDE.add(name)
-      header, source = emit(spec)         # the stamp keeps the digest of the FIRST emission: a later gen_code call of this
-      #                                     model emits the lane-per-filter text again, finds it stamped and reuses the library
-      with open(os.path.join(folder, f"{name}.h"), "w", encoding="utf-8") as f:
-        f.write(header)
-      with open(os.path.join(folder, f"{name}.hip"), "w", encoding="utf-8") as f:
-        f.write(source)
-      rn_build.compile_filter(folder, name, verbose=verbose)
-      bad = rn_build.spilled_kernels(rn_build.compile_filter.last_usage)
     from rednose_amd.codegen import tuning as rn_tuning
-    heavy = [k for k in bad if rn_build.compile_filter.last_usage[k]["vgpr_spill"] > 8]
-    if heavy and rn_tuning.model_defaults(spec) and not os.environ.get("RN_ALLOW_SPILLS"):
-      # the two-wavefronts-per-SIMD structure chosen for this model size does not fit 256 registers with this model's
-      # expressions: build the general structure instead
-      if verbose:
-        print(f"{name}: {heavy} spill under the per-model tuning defaults -> regenerating with the general structure")
-      rn_tuning.NO_MODEL_DEFAULTS.add(name)
-      header, source = emit(spec)
-      with open(os.path.join(folder, f"{name}.h"), "w", encoding="utf-8") as f:
-        f.write(header)
-      with open(os.path.join(folder, f"{name}.hip"), "w", encoding="utf-8") as f:
-        f.write(source)
+    fallbacks = []
+
+    def build():
+      if fallbacks:
+        hdr_, src_ = emit(spec, fallbacks=tuple(fallbacks))
+        with open(os.path.join(folder, f"{name}.h"), "w", encoding="utf-8") as f_:
+          f_.write(hdr_)
+        with open(os.path.join(folder, f"{name}.hip"), "w", encoding="utf-8") as f_:
+          f_.write(src_)
       rn_build.compile_filter(folder, name, verbose=verbose)
-      bad = rn_build.spilled_kernels(rn_build.compile_filter.last_usage)
-    bad_rts = [k for k in bad if k.startswith("k_rts") and rn_build.compile_filter.last_usage[k]["scratch"] > 0]
-    if bad_rts and name not in rn_emit.RTS_ONE_WAVE and not os.environ.get("RN_ALLOW_SPILLS"):
-      if verbose:
-        print(f"{name}: the smoother spills under the two-wavefronts-per-SIMD register budget -> one wavefront per SIMD")
-      rn_emit.RTS_ONE_WAVE.add(name)
-      header, source = emit(spec)
-      with open(os.path.join(folder, f"{name}.h"), "w", encoding="utf-8") as f:
-        f.write(header)
-      with open(os.path.join(folder, f"{name}.hip"), "w", encoding="utf-8") as f:
-        f.write(source)
-      rn_build.compile_filter(folder, name, verbose=verbose)
-      bad = rn_build.spilled_kernels(rn_build.compile_filter.last_usage)
-      bad_rts = [k for k in bad if k.startswith("k_rts") and rn_build.compile_filter.last_usage[k]["scratch"] > 0]
-    if bad_rts and not os.environ.get("RN_ALLOW_SPILLS"):
-      raise RuntimeError(f"{name}: smoother kernel {bad_rts} spills registers (see {folder}/{name}.kernels.txt); "
-                         "set RN_ALLOW_SPILLS=1 to build it anyway")
+      usage = rn_build.compile_filter.last_usage
+      return usage, rn_build.spilled_kernels(usage)
+
+    def fall_back(which, why):
+      msg = f"{name}: {why} -> {which}"
+      (print if verbose else logging.getLogger(__name__).info)(msg)
+      fallbacks.append(which)
+      return build()
+
+    usage, bad = build()
+    if not os.environ.get("RN_ALLOW_SPILLS"):
+      if bad and rn_emit.family(spec, ()) == "small":
+        usage, bad = fall_back("force_wide", f"lane-per-filter kernels {bad} spill registers: regenerating in the lane-group family")
+      heavy = [k for k in bad if usage[k]["vgpr_spill"] > 8]
+      if heavy and rn_tuning.model_defaults(spec):
+        # the two-wavefronts-per-SIMD structure chosen for this model size does not fit 256 registers with this model's expressions
+        usage, bad = fall_back("no_model_defaults", f"{heavy} spill under the per-model tuning defaults: regenerating with the general structure")
+      rts_scratch = lambda: [k for k in bad if k.startswith("k_rts") and usage[k]["scratch"] > 0]      # noqa: E731
+      if rts_scratch():
+        usage, bad = fall_back("rts_one_wave", "the smoother spills under the two-wavefronts-per-SIMD register budget: one wavefront per SIMD")
+      if rts_scratch():
+        # the forward filter is intact: ship it without the smoother rather than no library at all (batch_rts is then absent and
+        # BatchedEKF.rts_smooth raises KalmanError, as for any model without one)
+        import warnings
+        warnings.warn(f"{name}: smoother kernel {rts_scratch()} does not fit the register file (see {folder}/{name}.kernels.txt); "
+                      f"lib{name}.so is built WITHOUT batch_rts", RuntimeWarning)
+        usage, bad = fall_back("no_rts", "the smoother still touches scratch memory: library without batch_rts")
     with open(stamp_fn, "w", encoding="utf-8") as f:
       f.write(digest)
   return spec
@@ -779,7 +773,12 @@ class BatchedEKF:
     fl = torch.zeros((T, nb), dtype=torch.uint8, device=self.device) if flags else None
     if nb == 0:
       return zs, tx, tP, fl
-    xv, Pv = self.x[lo:hi], self.P[lo:hi]          # contiguous views: record lo starts 16-byte aligned whenever record 0 does
+    # contiguous views of the filters' records; the C ABI moves them with 16-byte transfers, so record `lo` has to start on an
+    # even double: always true for even record sizes, for odd ones (live: 23 states) only at even `lo`
+    if (lo * self.dim_x) % 2 or (lo * self.dim_err * self.dim_err) % 2:
+      raise KalmanError(f"run(filters=({lo}, {hi})): with {self.dim_x} states / {self.dim_err} error states per filter a sub-batch must "
+                        "start at an even filter index (16-byte alignment of its first record)")
+    xv, Pv = self.x[lo:hi], self.P[lo:hi]
     ead = max(list(self.eadims.values()) + [0])
     ea = None if extra_args is None else self._dev(extra_args, (T, nb, ead))
     ag = None
@@ -788,23 +787,27 @@ class BatchedEKF:
       ag = torch.as_tensor(np.asarray(augment, dtype=np.int32).reshape(T), device=self.device)
     self._call("batch_run", self._p(xv), self._p(Pv), self._p(self.Q), self._p(kd), self._p(dd), T, self._p(zs),
                self._p(Rd), nb, self.norm_quats, self._p(fl), self._p(tx), self._p(tP), self._p(ea), self._p(ag), self._stream())
-    if ag is not None and self.msckf:
-      for t_, a_ in zip(ts, np.asarray(augment).reshape(T)):
-        if a_:
-          self.augment_times = self.augment_times[1:] + [float(t_)]
-    self.filter_time = float(ts[-1])
+    if nb == self.batch:          # a strict subset leaves the orchestrator's clock alone: the other filters have not moved
+      if ag is not None and self.msckf:
+        for t_, a_ in zip(ts, np.asarray(augment).reshape(T)):
+          if a_:
+            self.augment_times = self.augment_times[1:] + [float(t_)]
+      self.filter_time = float(ts[-1])
     self._keepalive = (kd, dd, Rd, ea, ag)      # the launch is asynchronous: keep its inputs alive
     return zs, tx, tP, fl
 
   # -- offline smoothing ----------------------------------------------------------------------------
-  def smooth(self, ts, kinds, zs, Rs, passes=1, chunk=None, norm_quats=None, on_chunk=None, flags=False):
+  def smooth(self, ts, kinds, zs, Rs, passes=1, chunk=None, norm_quats=None, on_chunk=None, flags=False, extra_args=None, augment=None):
     """Offline estimation over a whole observation stream: forward filter keeping the filtered trace, then the RTS
     backward pass -- `passes` times, each pass restarting the filter from the oldest smoothed estimate of the previous
     one ("multiple forward and backwards passes of the data", /root/reference/README.md:41-45, built on rts_smooth,
     ekf_sym.py:651-690).
 
-    ts, kinds, zs, Rs: as for run() (zs (T, N, zmax) is NOT consumed here).  The filter starts every pass at the filter
-    time it had when smooth() was called (None: the first step has dt = 0) and, for pass 1, from its current (x, P).
+    ts, kinds, zs, Rs, extra_args, augment: as for run() (zs (T, N, zmax) is NOT consumed here).  Pass 1 starts from the
+    filter's current (x, P) at the filter time it had when smooth() was called (None: the first step has dt = 0); every later
+    pass starts from the oldest smoothed estimate, which is an estimate AT ts[0], so its first step has dt = 0 (the
+    reference's loop does init_state(x_s[0], P_s[0], None) between passes).  A chunk must start at an even filter index when
+    the record sizes are odd (see run()).
     chunk: filters per forward/backward sweep.  The filtered trace of T steps costs T * (D + E*E) * 8 bytes per filter
     (live: 17 MB per filter at 2 100 steps, 279 GB for 16 384 filters with the predicted pairs the reference keeps,
     140 GB here); filters are independent, so the batch is swept in chunks whose trace fits -- the result is identical
@@ -829,10 +832,11 @@ class BatchedEKF:
       hi = min(self.batch, lo + step)
       m = hi - lo
       bx, bP = (tx, tP) if m == step else (tx[:, :m].contiguous(), tP[:, :m].contiguous())
+      ea = None if extra_args is None else self._dev(extra_args)[:, lo:hi].contiguous()
       for p in range(passes):
-        self.filter_time = t_init
+        self.filter_time = t_init if p == 0 else float(ts[0])
         zc = zs[:, lo:hi].clone()               # run() consumes its observations (overwrites them with the residuals)
-        ys, _, _, fl = self.run(ts, kinds, zc, Rs, flags=flags, out=(bx, bP), filters=(lo, hi))
+        ys, _, _, fl = self.run(ts, kinds, zc, Rs, flags=flags, out=(bx, bP), filters=(lo, hi), extra_args=ea, augment=augment)
         # the smoother works on the trace of this chunk only: a view of the orchestrator restricted to its filters
         xs, Ps = self._rts_on(bx, bP, ts, m, norm_quats)
         if p + 1 < passes:
@@ -841,6 +845,10 @@ class BatchedEKF:
       if on_chunk is not None:
         on_chunk(lo, hi, xs, Ps, ys, fl)
     self.filter_time = float(ts[-1])
+    if augment is not None and self.msckf:
+      for t_, a_ in zip(ts, np.asarray(augment).reshape(T)):
+        if a_:
+          self.augment_times = self.augment_times[1:] + [float(t_)]
     if on_chunk is None:
       return xs, Ps
     return None
@@ -867,8 +875,11 @@ class BatchedEKF:
     predicted pairs are recomputed on the GPU from the filtered ones (templates/ekf_hip_rts.h).  MSCKF models: only
     the main block of the covariance and the main states are smoothed, the rest passes through (:675-686).
     last_predicted = (x (N, D), P (N, E, E)): the predicted pair of the last step (xk_km1, Pk_km1 of its estimate), which
-    the reference returns verbatim as the newest smoothed estimate; default: recomputed from the filtered pair of step
-    T - 2 (exact unless an MSCKF window shift happened between the last two steps).
+    the reference returns verbatim as the newest smoothed estimate.  Default: its MAIN block is recomputed from the filtered
+    pair of step T - 2 -- exact for models without an MSCKF window; for MSCKF models the window states and the window /
+    cross-covariance blocks of that ONE estimate (index T - 1) are then the filtered ones of the trace, not the predicted
+    ones (F_main P[main, window] is not formed), so pass last_predicted when the newest estimate's window blocks matter.
+    Every older estimate is unaffected: the reference smooths the main block only (:675-686).
     Returns (states (T, N, D), covs (T, N, E, E)) device tensors, oldest first.
     """
     torch = self._torch

@@ -276,8 +276,10 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
 // the main states [:DM] are smoothed; everything else of (xk_k, Pk_k) passes through.  The main block of the predicted pair is
 // recomputed from the filtered main block (F_main Pk_k[:EM, :EM] F_main^T + dt Q[:EM, :EM], ekf_c.c:24,28), which assumes what
 // an MSCKF means: main dynamics that do not read the window clones.  The predicted pair of the LAST step, which the reference
-// returns verbatim as the newest smoothed estimate, can be passed in (xl, Pl); otherwise it is recomputed as well (exact for
-// models without a window; for MSCKF models the window part of that one estimate is then the filtered one).
+// returns verbatim as the newest smoothed estimate, can be passed in (xl, Pl); otherwise its main block is recomputed as well:
+// exact for models without a window; for MSCKF models the window states and the window / cross-covariance blocks of that one
+// estimate (index T - 1) are then the FILTERED ones of the trace (F_main P[main, window] is not formed here) -- a predicted
+// main block next to filtered cross blocks, so callers that need the newest estimate exactly pass (xl, Pl).
 //
 // Model: constants D, E, DM, EM, SLOT, OFF_X, OFF_DT and the functions
 //   scal(xin, dt, sl, norm)                      one filter's f / F non-zeros -> slot (x' = f(x) [normalised] at sl[OFF_X..])

@@ -279,3 +279,98 @@ def test_config4_full_size_gate_and_smoother():
   _report("config4", filters=N, steps=T_FULL, gate_flips_vs_oracle=flips, gate_flips_oracle_vs_perturbed_oracle=flips_self,
           gated_fraction_of_gnss=float(flr[gnss].mean()), filters_compared=int(same.sum()),
           smoother_err_states_covs_cond={str(k): v for k, v in worst.items()})
+
+
+def test_config3_resynchronised_strict_checks_at_full_size():
+  """The free-running comparisons above are bounded by the chaos of the worst filters (cond(P0) = 1e12).  Here chaos drops
+  out: at every 100-step boundary of the 16 384 x 2 100 fused run the GPU's OWN (x, P) of ALL filters -- states the
+  trajectories actually visit -- are handed bit for bit to the oracle, and ONE step of each kind of the stream is run on
+  both from that state: gyro (dt = 0.01: the covariance predict runs), accelerometer and GNSS (dt = 0), through the
+  step-granular kernels, plus the three in sequence through the fused run.  Single-call tolerance: 1e-10 of the row maximum
+  (tests/test_gpu_live.py::test_single_calls_vs_oracle_strict uses it at n <= 33 on random states)."""
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  torch, L, f, o, rng, x0, hacc = _setup("live", N, 2025)
+  kinds, ts = _schedule(T_FULL)
+  Rs = {int(k): L.obs_noise[int(k)] for k in (4, 10, 12)}
+  P0 = np.diag(L.initial_P_diag)
+  f.init_state(x0, P0, None)
+  s = BatchedEKF(f.folder, "live", L.Q, L.initial_x, P0, 23, 22, batch=N, quaternion_idxs=[3])
+  worst = {"x": 0.0, "P": 0.0, "y": 0.0, "run_x": 0.0, "run_P": 0.0}
+  hist = []
+  for lo in range(0, T_FULL, 100):
+    hi = lo + 100
+    f.run(ts[lo:hi], kinds[lo:hi], _observations(L, rng, hacc, kinds[lo:hi], N), Rs)
+    Xh, Ph = f.state(), f.covs()                  # the oracle's inputs: the GPU's bits
+    assert np.isfinite(Xh).all() and np.isfinite(Ph).all()
+    z3 = _observations(L, rng, hacc, np.array([4, 10, 12]), N)
+    bx = bP = 0.0
+    for i, (k, dt) in enumerate(((4, 0.01), (10, 0.0), (12, 0.0))):
+      s.x.copy_(f.x); s.P.copy_(f.P); s.filter_time = 0.0
+      y = s.predict_and_update_batch(dt, k, z3[i].copy(), Rs[k])
+      xr, Pr, zr = Xh.copy(), Ph.copy(), z3[i].copy()
+      o.batch_step(k, xr, Pr, zr, Rs[k], L.Q, dt, quat_idx=3)
+      what = f"after step {hi}, kind {k}"
+      assert_close(s.state(), xr, rtol=1e-10, floor=1e-10, what=what + " x")
+      assert_close(s.covs().reshape(N, -1), Pr.reshape(N, -1), rtol=1e-10, floor=1e-10, what=what + " P")
+      assert_close(y.cpu().numpy(), zr, rtol=1e-9, atol=1e-9, what=what + " y")
+      bx = max(bx, float(_rel(s.state(), xr).max())); bP = max(bP, float(_rel(s.covs(), Pr).max()))
+      worst["y"] = max(worst["y"], float(np.abs(y.cpu().numpy() - zr).max()))
+    # the same three observations in sequence through the fused run (state resident in registers): three chained steps
+    s.x.copy_(f.x); s.P.copy_(f.P); s.filter_time = 0.0
+    s.run(np.array([0.01, 0.01, 0.01]), np.array([4, 10, 12], dtype=np.int32), z3.copy(), Rs)
+    xr, Pr = Xh.copy(), Ph.copy()
+    o.batch_run(np.array([4, 10, 12], dtype=np.int32), np.array([0.01, 0.0, 0.0]), xr, Pr, z3.copy(), _Rtable(L, [4, 10, 12]), L.Q, quat_idx=3)
+    assert_close(s.state(), xr, rtol=1e-9, floor=1e-9, what=f"after step {hi}, fused run of 3 x")
+    assert_close(s.covs().reshape(N, -1), Pr.reshape(N, -1), rtol=1e-9, floor=1e-9, what=f"after step {hi}, fused run of 3 P")
+    worst["run_x"] = max(worst["run_x"], float(_rel(s.state(), xr).max())); worst["run_P"] = max(worst["run_P"], float(_rel(s.covs(), Pr).max()))
+    worst["x"] = max(worst["x"], bx); worst["P"] = max(worst["P"], bP)
+    hist.append((hi, bx, bP))
+  _report("config3_resynchronised", filters=N, boundaries=len(hist), single_call_x_err_max=worst["x"], single_call_P_err_max=worst["P"],
+          single_call_y_abs_err_max=worst["y"], fused_run3_x_err_max=worst["run_x"], fused_run3_P_err_max=worst["run_P"],
+          history_step_xErr_PErr=hist)
+
+
+def test_config4_resynchronised_backward_steps():
+  """One backward RTS step at a time on trajectory states: 256 filters of the config-4 stream free-run 2 000 steps, the last
+  100 steps keep the filtered trace, the GPU smooths it; then every backward step k is recomputed on the host from the GPU's
+  OWN smoothed estimate of step k + 1 and the filtered pair of step k (numpy restatement of ekf_sym.py:651-690 over the
+  oracle's f / F / err / inv_err), so no error is carried from step to step.  What is left is the conditioning of the one
+  solve per step: the bound is 1e-10 of the row maximum or 20 cond(Pk1_k) eps, whichever is larger."""
+  torch, L, f, o, rng, x0, hacc = _setup("live_maha", 256, 77)
+  n, Tw = 256, 100
+  kinds, ts = _schedule(T_FULL)
+  Rs = {int(k): L.obs_noise[int(k)] for k in (4, 10, 12)}
+  f.init_state(x0, np.diag(L.initial_P_diag), None)
+  zs = _observations(L, rng, hacc, kinds, n, outlier_frac=0.02)
+  f.run(ts[:T_FULL - Tw], kinds[:T_FULL - Tw], zs[:T_FULL - Tw].copy(), Rs)
+  _, tx, tP, _ = f.run(ts[T_FULL - Tw:], kinds[T_FULL - Tw:], zs[T_FULL - Tw:].copy(), Rs, trace=True)
+  tw = ts[T_FULL - Tw:]
+  xs, Ps = f.rts_smooth(tx, tP, tw)
+  torch.cuda.synchronize()
+  X, P, Xs, Pss = tx.cpu().numpy(), tP.cpu().numpy(), xs.cpu().numpy(), Ps.cpu().numpy()
+  assert np.isfinite(Xs).all() and np.isfinite(Pss).all()
+  worst_x = worst_P = worst_ratio = 0.0
+  for j in range(n):
+    for k in range(Tw - 2, -1, -1):
+      dt = float(tw[k + 1] - tw[k])
+      x1k = np.zeros(23); Fk = np.zeros(22 * 22)
+      o.call("f_fun", X[k, j].copy(), dt, x1k); o.call("F_fun", X[k, j].copy(), dt, Fk)
+      x1k[3:7] /= np.linalg.norm(x1k[3:7])                  # the forward pass renormalised the predicted state
+      Fk = Fk.reshape(22, 22)
+      P1k = Fk @ P[k, j] @ Fk.T + dt * L.Q
+      if k == Tw - 2:      # recursion start: the newest smoothed estimate is the predicted pair (normalised in place, :665-667)
+        assert_close(Xs[Tw - 1, j], x1k, rtol=1e-12, floor=1e-13, what="newest smoothed state")
+        assert_close(Pss[Tw - 1, j], P1k, rtol=1e-10, floor=1e-12, what="newest smoothed covariance")
+      x1n, P1n = Xs[k + 1, j], Pss[k + 1, j]                 # the GPU's own values: every step is checked on its own
+      Ck = np.linalg.solve(P1k, Fk @ P[k, j].T).T
+      delta = np.zeros(22); xkn = np.zeros(23)
+      o.call("inv_err_fun", x1k.copy(), x1n.copy(), delta)
+      o.call("err_fun", X[k, j].copy(), Ck @ delta, xkn)
+      if k > 0:
+        xkn[3:7] /= np.linalg.norm(xkn[3:7])                 # returned states other than the oldest are normalised
+      Pkn = P[k, j] + Ck @ (P1n - P1k) @ Ck.T
+      ex = float(_rel(Xs[k, j][None], xkn[None])[0]); eP = float(_rel(Pss[k, j][None], Pkn[None])[0])
+      bound = max(1e-10, 20 * np.linalg.cond(P1k) * 2.2e-16)
+      worst_x, worst_P, worst_ratio = max(worst_x, ex), max(worst_P, eP), max(worst_ratio, max(ex, eP) / bound)
+      assert ex <= bound and eP <= bound, f"filter {j} backward step {k}: x {ex:.2e} P {eP:.2e} bound {bound:.2e}"
+  _report("config4_resynchronised_backward", filters=n, steps=Tw - 1, x_err_max=worst_x, P_err_max=worst_P, worst_error_over_bound=worst_ratio)

@@ -125,3 +125,46 @@ x.hip:3:1: remark:     VGPRs Spill: 129 [-Rpass-analysis=kernel-resource-usage]
   assert list(u) == ["k_fn_err_fun", "k_step_1<true>", "k_rts_wide"]
   assert u["k_step_1<true>"] == dict(vgprs=242, agprs=0, scratch=0, lds=28960, vgpr_spill=0, occupancy=2)
   assert u["k_rts_wide"]["scratch"] == 464 and u["k_rts_wide"]["vgpr_spill"] == 129
+
+
+def test_gen_code_falls_back_instead_of_failing(tmp_path, monkeypatch):
+  """gen_code must not leave a model unbuildable because an OPTIONAL kernel does not fit the register file: a smoother that
+  still touches scratch after the one-wavefront fallback is dropped (library without batch_rts, RuntimeWarning), the
+  forward filter ships.  No process-global state survives the call (round 2 kept model names in module-level sets).
+  hipcc is replaced by a stub that reports scratch for k_rts_group on every build."""
+  import warnings
+  import examples.random_kf as R
+  from rednose_amd import build as rb
+  from rednose_amd.codegen import emit as rn_emit
+  seen = []
+
+  def fake_compile(folder, name, **kw):
+    src = open(f"{folder}/{name}.hip", encoding="utf-8").read()
+    has_rts = "_batch_rts(" in src
+    seen.append(has_rts)
+    usage = {"k_step_1<true>": dict(vgprs=200, agprs=0, scratch=0, lds=0, vgpr_spill=0, occupancy=2)}
+    if has_rts:
+      usage["k_rts_group"] = dict(vgprs=256, agprs=256, scratch=64, lds=0, vgpr_spill=8, occupancy=1)
+    fake_compile.last_usage = usage
+    rb.compile_filter.last_usage = usage
+    return f"{folder}/lib{name}.so"
+  monkeypatch.setattr(rb, "compile_filter", fake_compile)
+  M = R.Random11Kalman
+  with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    M.generate_code(str(tmp_path))
+  assert seen == [True, True, False], seen            # default, one wavefront per SIMD, without the smoother
+  assert any("WITHOUT batch_rts" in str(x.message) for x in w)
+  assert "_batch_rts(" not in open(tmp_path / f"{M.name}.h", encoding="utf-8").read()
+  assert (tmp_path / f"{M.name}.digest").exists()
+  assert rn_emit._active == frozenset() and not hasattr(rn_emit, "FORCE_WIDE")      # pylint: disable=protected-access
+
+
+def test_fused_run_generates_for_wide_observations():
+  """8 filters x 9 observation entries > 64 lanes: the fused run carries two entries per lane instead of asserting."""
+  import examples.random_kf as R
+  from rednose_amd.codegen.spec import build_spec
+  from rednose_amd.codegen.emit import emit
+  mdl = R.RandomWideObs10Kalman.model()
+  hdr, src = emit(build_spec(**mdl))
+  assert "randz10_batch_run(" in hdr and "zn[2]" in src and "ERR_UNSUPPORTED" not in src.split("randz10_batch_run(")[1].split("}")[0]

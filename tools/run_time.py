@@ -1,5 +1,5 @@
 """Timing of the live fused multi-step run alone (8 192 filters x 252 steps of the IMU / GNSS pattern, no trace unless `trace`
-is given); RN_GEN_DIR selects an A/B build.  Used under rocprofv3 --pmc by profiles/collect_run_counters.sh."""
+is given); RN_GEN_DIR selects an A/B build.  (Counters: the live_run_notrace section of profiles/pmc_workload.py.)"""
 import os
 import sys
 
