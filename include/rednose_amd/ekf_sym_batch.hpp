@@ -12,6 +12,10 @@
 //     replayed (:111-116); older than max_rewind_age or than the ring -> false (:87-94).  Quaternion renormalisation
 //     after predict and update when quaternion_idxs were given to gen_code (:207,213 -- done inside the kernels);
 //     set_global (:79-81) and get_extra_routine (:221-223);
+//   * per-filter timelines (predict_and_update_batch_per_filter): N independent instances of that orchestrator in one batch --
+//     every filter keeps its own filter time and its own ring of checkpoints in HBM; a call advances the filters named by a mask
+//     to their own times through the library's `_masked` entry points, a late observation rewinds, applies and fast-forwards only
+//     the filters it is late for, one that is too old is ignored for that filter alone;
 //   * no Eigen: state lives in HBM as x (N, D), P (N, E, E) row-major fp64; z is a DEVICE pointer (N, Z) that the
 //     kernel overwrites with the residual y; R is a host Z x Z matrix shared by the batch.
 // Errors throw std::runtime_error carrying {name}_last_error_string(); nothing aborts.
@@ -63,10 +67,11 @@ class EKFSymBatch {
   ~EKFSymBatch() {
     for (auto& c : ring_) release(c);
     for (auto& c : spare_) release(c);
-    (void)hipFree(x_);
-    (void)hipFree(P_);
-    (void)hipFree(Q_);
-    (void)hipFree(R_);
+    for (double* p : {x_, P_, Q_, R_, pf_.ring_x, pf_.ring_P, pf_.ring_z, pf_.ring_ea, pf_.dt, pf_.stage_z[0], pf_.stage_z[1], pf_.stage_ea[0],
+                      pf_.stage_ea[1], pf_.Rn, pf_.zpack})
+      (void)hipFree(p);
+    (void)hipFree(pf_.act);
+    (void)hipFree(pf_.slot);
     if (handle_) dlclose(handle_);
   }
   EKFSymBatch(const EKFSymBatch&) = delete;
@@ -156,6 +161,91 @@ class EKFSymBatch {
     return true;
   }
 
+  // ---- per-filter timelines --------------------------------------------------------------------------------------------
+  // One observation kind, every filter on its own clock: t_host (N) observation times, active_host (N bytes; nullptr = every
+  // filter has an observation).  z_dev (N, Z) in: z, out: y for the active filters, untouched for the others; flags_dev (N
+  // bytes or nullptr): kernel flags, 16 for filters that were not active.  A filter whose observation is older than its own
+  // filter time is rewound to its last checkpoint at or before it, gets the observation, and replays what it had overtaken
+  // (needs rewind_to_keep > 0: otherwise std::runtime_error, like dt < 0 in the reference); an observation older than the
+  // filter's ring or than max_rewind_age is ignored for that filter alone (ekf_sym.cc:87-94).  Returns the number of ignored
+  // observations; ignored() tells which.  Do not mix with the shared-timeline calls on one object.
+  int64_t predict_and_update_batch_per_filter(const double* t_host, const uint8_t* active_host, int kind, double* z_dev,
+                                              const double* R_host, uint8_t* flags_dev = nullptr, const double* ea_dev = nullptr) {
+    const int Z = zdim_.at(kind);
+    pf_init();
+    PerFilter& s = pf_;
+    const int K = rewind_to_keep_;
+    std::vector<uint8_t> act(n_, 1), restore(n_, 0);
+    if (active_host) act.assign(active_host, active_host + n_);
+    std::fill(s.ignored.begin(), s.ignored.end(), 0);
+    std::vector<int32_t> slot(n_, 0);
+    std::vector<std::vector<Pending>> rep;           // rep[q]: overtaken observation number q of every rewound filter
+    int64_t n_ignored = 0;
+    // ---- late observations: EKFSym::rewind (ekf_sym.cc:119-140) on every late filter's own ring ----
+    for (int64_t i = 0; i < n_; i++) {
+      if (!act[i] || std::isnan(s.ft[i]) || !(t_host[i] < s.ft[i])) continue;
+      if (K <= 0) throw std::runtime_error("rednose_amd: dt < 0 for a filter and no rewind ring (rewind_to_keep = 0)");
+      const int32_t L = s.len[i], H = s.head[i];
+      auto at = [&](int32_t j) { return (size_t)((H + j) % K) * n_ + i; };
+      if (L == 0 || t_host[i] < s.rt[at(0)] || t_host[i] < s.rt[at(L - 1)] - max_rewind_age_) {
+        s.ignored[i] = 1; act[i] = 0; n_ignored++;
+        continue;
+      }
+      int32_t ix = 0;
+      while (ix < L && s.rt[at(ix)] <= t_host[i]) ix++;                // bisect_right
+      slot[i] = (H + ix - 1) % K;
+      restore[i] = 1;
+      s.ft[i] = s.rt[at(ix - 1)];
+      for (int32_t j = ix; j < L; j++) {
+        if (rep.size() < (size_t)(j - ix + 1)) rep.emplace_back();
+        rep[j - ix].push_back(Pending{i, s.rt[at(j)], s.rkind[at(j)], s.rridx[at(j)], (int32_t)((H + j) % K)});
+      }
+      s.len[i] = ix;
+    }
+    if (!rep.empty() || std::count(restore.begin(), restore.end(), 1) > 0) {
+      upload(s.slot, slot.data(), sizeof(int32_t) * n_);
+      upload(s.act, restore.data(), n_);
+      ring_copy(s.ring_x, D_, x_, D_, D_, false);
+      ring_copy(s.ring_P, (int64_t)E_ * E_, P_, (int64_t)E_ * E_, (int64_t)E_ * E_, false);
+    }
+    // every checkpoint written below lands on the ring slot of the NEXT overtaken observation: that one is staged out first
+    int cur = 0;
+    if (!rep.empty()) stage(rep[0], cur);
+    std::vector<double> tt(t_host, t_host + n_);
+    std::vector<int> ridx(n_, rtable_index(R_host, Z));
+    hip(hipMemcpyAsync(R_, R_host, sizeof(double) * Z * Z, hipMemcpyHostToDevice, stream_), "copy R");
+    masked_step(tt, act, kind, Z, z_dev, R_, 0, flags_dev, ea_dev, ridx);
+    // ---- fast-forward (ekf_sym.cc:111-116): position q of every rewound filter, one launch per kind present there ----
+    for (size_t q = 0; q < rep.size(); q++) {
+      if (q + 1 < rep.size()) stage(rep[q + 1], cur ^ 1);
+      std::map<int, std::vector<const Pending*>> by_kind;
+      for (const Pending& p : rep[q]) by_kind[p.kind].push_back(&p);
+      for (auto& kv : by_kind) {
+        const int k = kv.first, Zk = zdim_.at(k);
+        std::vector<uint8_t> ra(n_, 0);
+        std::vector<double> tq(s.ft), Rn((size_t)n_ * Zk * Zk, 0.0);
+        std::vector<int> rq(n_, 0);
+        for (const Pending* p : kv.second) {
+          ra[p->f] = 1;
+          tq[p->f] = p->t;
+          rq[p->f] = p->ridx;
+          std::copy(s.rtable[p->ridx].begin(), s.rtable[p->ridx].end(), Rn.begin() + (size_t)p->f * Zk * Zk);
+        }
+        // staged observations are (N, zmax) rows, the entry point takes (N, Zk) contiguous
+        hip(hipMemcpy2DAsync(s.zpack, sizeof(double) * Zk, s.stage_z[cur], sizeof(double) * s.zmax, sizeof(double) * Zk, n_,
+                             hipMemcpyDeviceToDevice, stream_), "pack z");
+        upload(s.Rn, Rn.data(), sizeof(double) * Rn.size());
+        const int ek = sym<int (*)(int)>("kind_eadim")(k);
+        if (ek != 0 && ek != s.ead) throw std::runtime_error("rednose_amd: kinds with different extra-argument counts are not supported by the per-filter ring");
+        masked_step(tq, ra, k, Zk, s.zpack, s.Rn, 1, nullptr, ek ? s.stage_ea[cur] : nullptr, rq);
+      }
+      cur ^= 1;
+    }
+    return n_ignored;
+  }
+  const std::vector<double>& filter_times() const { return pf_.ft; }          // NaN: the filter has not stepped yet
+  const std::vector<uint8_t>& ignored() const { return pf_.ignored; }         // 1: the last per-filter call ignored this filter's observation
+
   // MSCKF window shift on every filter (libraries generated with msckf_params only)
   void augment() {
     check(sym<int (*)(double*, double*, int64_t, void*)>("batch_augment")(x_, P_, n_, stream_), "batch_augment");
@@ -239,6 +329,122 @@ class EKFSymBatch {
     return replay;
   }
 
+  // ---- per-filter timelines ---------------------------------------------------------------------------------------------
+  struct Pending { int64_t f; double t; int kind; int ridx; int32_t slot; };   // an overtaken observation still in filter f's ring
+  struct PerFilter {
+    bool ready = false;
+    int zmax = 0, ead = 0;
+    std::vector<double> ft;                  // filter time per filter (NaN: not started)
+    std::vector<uint8_t> ignored;
+    std::vector<int32_t> head, len;          // circular ring position per filter
+    std::vector<double> rt;                  // (K, N) checkpoint times
+    std::vector<int32_t> rkind, rridx;       // (K, N) observation kind / index into rtable
+    std::vector<std::vector<double>> rtable; // distinct noise matrices seen so far (row-major Z x Z)
+    double *ring_x = nullptr, *ring_P = nullptr, *ring_z = nullptr, *ring_ea = nullptr;      // (K, N, rec) device
+    double *dt = nullptr, *Rn = nullptr, *zpack = nullptr;
+    double* stage_z[2] = {nullptr, nullptr};
+    double* stage_ea[2] = {nullptr, nullptr};
+    uint8_t* act = nullptr;
+    int32_t* slot = nullptr;
+  };
+  using masked_fn = int (*)(double*, double*, const double*, const double*, double, double*, const double*, int, const double*,
+                            int64_t, int, uint8_t*, const uint8_t*, void*);
+  using ring_fn = int (*)(double*, int64_t, double*, int64_t, int64_t, const int32_t*, const uint8_t*, int64_t, int, void*);
+
+  void pf_init() {
+    PerFilter& s = pf_;
+    if (s.ready) return;
+    for (auto& kv : zdim_) {
+      s.zmax = std::max(s.zmax, kv.second);
+      s.ead = std::max(s.ead, sym<int (*)(int)>("kind_eadim")(kv.first));
+    }
+    s.ft.assign(n_, filter_time_);
+    s.ignored.assign(n_, 0);
+    s.head.assign(n_, 0);
+    s.len.assign(n_, 0);
+    const size_t K = (size_t)std::max(rewind_to_keep_, 0);
+    s.rt.assign(K * n_, NAN);
+    s.rkind.assign(K * n_, 0);
+    s.rridx.assign(K * n_, 0);
+    auto dmal = [&](double** p, size_t doubles) { hip(hipMalloc((void**)p, sizeof(double) * std::max<size_t>(doubles, 2)), "hipMalloc per-filter buffer"); };
+    const size_t ea1 = (size_t)std::max(s.ead, 1);
+    if (K > 0) {
+      dmal(&s.ring_x, K * n_ * D_);
+      dmal(&s.ring_P, K * n_ * E_ * E_);
+      dmal(&s.ring_z, K * n_ * s.zmax);
+      dmal(&s.ring_ea, K * n_ * ea1);
+    }
+    dmal(&s.dt, n_);
+    dmal(&s.zpack, (size_t)n_ * s.zmax);
+    dmal(&s.Rn, (size_t)n_ * s.zmax * s.zmax);
+    for (int b = 0; b < 2; b++) { dmal(&s.stage_z[b], (size_t)n_ * s.zmax); dmal(&s.stage_ea[b], (size_t)n_ * ea1); }
+    hip(hipMalloc((void**)&s.act, n_ + 16), "hipMalloc mask");
+    hip(hipMalloc((void**)&s.slot, sizeof(int32_t) * n_ + 16), "hipMalloc slots");
+    ring_copy_ = sym<ring_fn>("batch_ring_copy");
+    s.ready = true;
+  }
+  void upload(void* dst, const void* src, size_t bytes) {
+    // pageable host memory: synchronise, so that the caller may reuse `src` right away
+    hip(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream_), "upload");
+    hip(hipStreamSynchronize(stream_), "upload sync");
+  }
+  // one array of a checkpoint, every filter at its own ring position (slot vector and mask already on the device)
+  void ring_copy(double* ring, int64_t ring_stride, double* flat, int64_t flat_stride, int64_t rec, bool to_ring) {
+    check(ring_copy_(ring, ring_stride, flat, flat_stride, rec, pf_.slot, pf_.act, n_, to_ring ? 1 : 0, stream_), "batch_ring_copy");
+  }
+  int rtable_index(const double* R, int Z) {
+    for (size_t i = 0; i < pf_.rtable.size(); i++)
+      if ((int)pf_.rtable[i].size() == Z * Z && std::equal(R, R + Z * Z, pf_.rtable[i].begin())) return (int)i;
+    pf_.rtable.emplace_back(R, R + Z * Z);
+    return (int)pf_.rtable.size() - 1;
+  }
+  // observations of one replay position -> flat staging buffers `b` (their ring slots are about to be overwritten)
+  void stage(const std::vector<Pending>& list, int b) {
+    PerFilter& s = pf_;
+    std::vector<uint8_t> m(n_, 0);
+    std::vector<int32_t> sl(n_, 0);
+    for (const Pending& p : list) { m[p.f] = 1; sl[p.f] = p.slot; }
+    upload(s.slot, sl.data(), sizeof(int32_t) * n_);
+    upload(s.act, m.data(), n_);
+    ring_copy(s.ring_z, s.zmax, s.stage_z[b], s.zmax, s.zmax, false);
+    if (s.ead > 0) ring_copy(s.ring_ea, s.ead, s.stage_ea[b], s.ead, s.ead, false);
+  }
+  // masked predict + update of the filters in `act`, each to its own time, + their checkpoints (EKFSym::predict_and_update_batch's
+  // inner part, ekf_sym.cc:158-194, per filter)
+  void masked_step(const std::vector<double>& t, const std::vector<uint8_t>& act, int kind, int Z, double* z_dev, const double* R_dev,
+                   int r_per_filter, uint8_t* flags_dev, const double* ea_dev, const std::vector<int>& ridx) {
+    PerFilter& s = pf_;
+    const int K = rewind_to_keep_;
+    std::vector<double> dt(n_, 0.0);
+    std::vector<int32_t> slot(n_, 0);
+    for (int64_t i = 0; i < n_; i++) {
+      if (!act[i]) continue;
+      dt[i] = std::isnan(s.ft[i]) ? 0.0 : t[i] - s.ft[i];             // first call of a filter adopts t (ekf_sym.cc:198-200)
+      if (dt[i] < 0.0) throw std::runtime_error("rednose_amd: dt < 0 in a per-filter step");
+      s.ft[i] = t[i];
+      if (K > 0) {
+        if (s.len[i] == K) s.head[i] = (s.head[i] + 1) % K; else s.len[i]++;
+        slot[i] = (s.head[i] + s.len[i] - 1) % K;
+        const size_t at = (size_t)slot[i] * n_ + i;
+        s.rt[at] = t[i]; s.rkind[at] = kind; s.rridx[at] = ridx[i];
+      }
+    }
+    upload(s.dt, dt.data(), sizeof(double) * n_);
+    upload(s.act, act.data(), n_);
+    const int ek = sym<int (*)(int)>("kind_eadim")(kind);
+    if (K > 0) {
+      upload(s.slot, slot.data(), sizeof(int32_t) * n_);
+      ring_copy(s.ring_z, s.zmax, z_dev, Z, Z, true);                  // the observation, before the kernel turns it into the residual
+      if (ek > 0 && ea_dev) ring_copy(s.ring_ea, s.ead, const_cast<double*>(ea_dev), ek, ek, true);
+    }
+    auto fn = sym<masked_fn>("batch_predict_update_" + std::to_string(kind) + "_masked");
+    check(fn(x_, P_, Q_, s.dt, 0.0, z_dev, R_dev, r_per_filter, ea_dev, n_, norm_quats_, flags_dev, s.act, stream_), "batch_predict_update_masked");
+    if (K > 0) {
+      ring_copy(s.ring_x, D_, x_, D_, D_, true);
+      ring_copy(s.ring_P, (int64_t)E_ * E_, P_, (int64_t)E_ * E_, (int64_t)E_ * E_, true);
+    }
+  }
+
   using predict_fn = int (*)(double*, double*, const double*, const double*, double, int64_t, int, void*);
   using step_fn = int (*)(double*, double*, const double*, const double*, double, double*, const double*, int, const double*,
                           int64_t, int, uint8_t*, void*);
@@ -280,6 +486,8 @@ class EKFSymBatch {
   double max_rewind_age_ = 1.0;
   std::deque<Checkpoint> ring_;
   std::vector<Checkpoint> spare_;
+  PerFilter pf_;
+  ring_fn ring_copy_ = nullptr;
 };
 
 }  // namespace rednose_amd

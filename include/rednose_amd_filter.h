@@ -75,7 +75,10 @@ extern "C" {
    * norm_quats != 0 renormalises the quaternion slices given to gen_code (EKFSym::normalize_quaternions,      \
    * ekf_sym.cc:69-77,207) */                                                                                  \
   int RN_FN(name, batch_predict)(double *x, double *P, const double *Q, const double *dt_vec, double dt,         \
-                                 int64_t n, int norm_quats, void *stream);
+                                 int64_t n, int norm_quats, void *stream);                                       \
+  /* the same for the filters with active[i] != 0 only (see RN_DECLARE_BATCH_KIND_MASKED) */                     \
+  int RN_FN(name, batch_predict_masked)(double *x, double *P, const double *Q, const double *dt_vec, double dt,  \
+                                        int64_t n, int norm_quats, const uint8_t *active, void *stream);
 
 /* fused multi-step run and offline smoothing (SURVEY.md 8b "proposed new batched exports") */
 #define RN_DECLARE_BATCH_RUN(name)                                                                               \
@@ -127,6 +130,32 @@ extern "C" {
                                             double dt, double *z, const double *R, int r_per_filter,             \
                                             const double *ea, int64_t n, int norm_quats, uint8_t *flags,         \
                                             void *stream);
+
+/* Per-filter timelines.  Every filter of the reference is its own instance with its own filter_time and its own rewind ring
+ * (EKFSym::predict_and_update_batch / rewind, /root/reference/rednose/helpers/ekf_sym.cc:83-156); a batch fed from n INDEPENDENT
+ * logs therefore needs calls that advance only SOME filters, each by its own dt.  The `_masked` twins of the step-granular entry
+ * points take `active` (n bytes, DEVICE): filters with active[i] == 0 pass through untouched -- x, P and z[i] leave exactly as
+ * they came -- and get flags[i] = 16 (bit 4); the others see the plain entry point's arithmetic with dt_vec[i].  active == NULL is
+ * the plain entry point.  (Bit 5 of the orchestrators' flags, "observation too old for this filter's ring, ignored"
+ * -- ekf_sym.cc:87-94 -- is set on the host side: BatchedEKF / EKFSymBatch.) */
+/* Checkpoint rings of per-filter timelines: `rec` doubles of record i of a flat DEVICE array (row stride flat_stride) <-> entry
+ * slot[i] of filter i in a ring laid out (K, n, ring_stride), for the filters with active[i] != 0 (NULL: all); to_ring != 0
+ * stores, 0 loads.  One launch moves one array of a checkpoint (x: D, P: E * E, z: Z of the kind into a ring of stride zmax) for
+ * the whole batch, every filter at its own ring position -- the batched form of EKFSym::checkpoint / ::rewind's state copy
+ * (ekf_sym.cc:119-156), whose lists are per filter instance. */
+#define RN_DECLARE_BATCH_RING(name)                                                                              \
+  int RN_FN(name, batch_ring_copy)(double *ring, int64_t ring_stride, double *flat, int64_t flat_stride,          \
+                                   int64_t rec, const int32_t *slot, const uint8_t *active, int64_t n,            \
+                                   int to_ring, void *stream);
+
+#define RN_DECLARE_BATCH_KIND_MASKED(name, k)                                                                    \
+  int RN_FN(name, batch_update_##k##_masked)(double *x, double *P, double *z, const double *R, int r_per_filter,  \
+                                             const double *ea, int64_t n, int norm_quats, uint8_t *flags,         \
+                                             const uint8_t *active, void *stream);                                \
+  int RN_FN(name, batch_predict_update_##k##_masked)(double *x, double *P, const double *Q, const double *dt_vec, \
+                                                     double dt, double *z, const double *R, int r_per_filter,     \
+                                                     const double *ea, int64_t n, int norm_quats, uint8_t *flags, \
+                                                     const uint8_t *active, void *stream);
 
 #ifdef __cplusplus
 }

@@ -403,8 +403,89 @@ def maha_goldens():
   print("maha accepted", ok.sum(), "of", n)
 
 
+def perfilter_timelines():
+  """N independent instances of the reference's orchestrator, each fed its OWN out-of-order log (SURVEY.md 8f row 1;
+  /root/reference/rednose/helpers/ekf_sym.py:418-482 = ekf_sym.cc:83-156): what a batched orchestrator with per-filter
+  timelines must reproduce filter by filter.
+  Part A, `compare` (2 states, one kind): the stream of /root/reference/examples/test_compare.py:88-120 extended to 700
+  observations (the ring of 512 checkpoints wraps), every filter with a DIFFERENT pair of samples swapped (filter 0: none;
+  some with two swaps; swaps beyond sample 512), one filter with an observation more than max_rewind_age old (ignored: None).
+  Part B, `kinematic9` (9 states, three kinds of 3 / 1 / 3 dimensions): every filter has its own times, its own order of
+  kinds, ticks without an observation, and one late observation at a place of its own."""
+  Q = np.diag([0.1**2, 2.0**2]); x0 = np.array([0.5, 0.0]); P0 = np.diag([1.0, 1.0]); R = np.array([[[0.1**2]]])
+  dt, T, NA = 0.01, 700, 12
+  rng = np.random.default_rng(41)
+  ts0 = np.arange(T) * dt
+  truth = np.concatenate([[0.0], np.cumsum(np.sin(ts0 * 5) * dt)[:-1]])
+  swaps = [[], [(20, 40)], [(21, 22)], [(100, 180)], [(5, 6), (300, 350)], [(250, 251), (400, 460)], [(511, 530)], [(600, 640)],
+           [(650, 699)], [(10, 90), (520, 560)], [(333, 334)], [(40, 60)]]
+  tA = np.tile(ts0, (NA, 1)); zA = np.empty((NA, T)); noneA = np.zeros((NA, T), dtype=bool)
+  xA = np.empty((NA, T, 2)); PA = np.empty((NA, T, 2, 2)); ftA = np.empty((NA, T))
+  for i in range(NA):
+    order = np.arange(T)
+    for a, b in swaps[i]:
+      order[a], order[b] = order[b], order[a]
+    tA[i] = ts0[order]
+    if i == NA - 1:
+      tA[i, 300] = ts0[300] - 2.5           # 2.5 s behind the filter: older than max_rewind_age = 1 s -> ignored
+    zA[i] = truth[order] + rng.normal(size=T) * 0.1
+    f = ref_filter("compare", Q, x0, P0, 2, 2)
+    for j in range(T):
+      ret = f.predict_and_update_batch(float(tA[i, j]), 1, np.array([[zA[i, j]]]), R)
+      noneA[i, j] = ret is None
+      xA[i, j], PA[i, j], ftA[i, j] = f.state(), f.covs(), f.get_filter_time()
+  assert noneA.sum() == 1 and noneA[NA - 1, 300]
+  # ---- part B
+  import importlib.util
+  spec = importlib.util.spec_from_file_location("rn_amd_kinematic9_kf_b", os.path.join(REPO, "examples", "kinematic9_kf.py"))
+  mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+  K9, ANCHOR = mod.Kinematic9Kalman, mod.ANCHOR
+  NB, TB = 10, 48
+  tB = np.full((NB, TB), np.nan); kB = np.zeros((NB, TB), dtype=np.int32); zB = np.zeros((NB, TB, 3))
+  xB = np.empty((NB, TB, 9)); PB = np.empty((NB, TB, 9, 9)); yB = np.zeros((NB, TB, 3))
+  for i in range(NB):
+    f = ref_filter("kinematic9", K9.Q, K9.initial_x, np.diag(K9.initial_P_diag), 9, 9)
+    tr = np.array([0.5, 0.5, 0.5, 1.0, -0.5, 0.2, 0.3, 0.1, -0.2]) + rng.normal(size=9) * 0.05
+    times = np.cumsum(rng.uniform(0.01, 0.05, size=TB)) + rng.uniform(0, 0.3)
+    late_at = int(rng.integers(5, TB - 2))
+    back = int(rng.integers(2, 5))
+    times[late_at] = 0.5 * (times[late_at - back] + times[late_at - back + 1])      # arrives `back` observations late
+    skip = rng.random(TB) < 0.2                                                     # ticks without an observation for this filter
+    skip[late_at] = False
+    t_prev = 0.0
+    for j in range(TB):
+      if skip[j]:
+        xB[i, j], PB[i, j] = f.state(), f.covs()
+        continue
+      t = float(times[j])
+      k = int(rng.integers(1, 4))
+      # truth propagated to t from scratch (constant acceleration): observations need only be plausible
+      p = tr[0:3] + t * tr[3:6] + 0.5 * t * t * tr[6:9]; v = tr[3:6] + t * tr[6:9]
+      if k == 1:
+        z = p + rng.normal(size=3) * 0.1
+      elif k == 2:
+        z = np.array([np.linalg.norm(p - np.array(ANCHOR))]) + rng.normal(size=1) * 0.2
+      else:
+        z = v + rng.normal(size=3) * 0.3
+      ret = f.predict_and_update_batch(t, k, np.array([z]), np.array([K9.obs_noise[k]]))
+      assert ret is not None
+      tB[i, j], kB[i, j] = t, k
+      zB[i, j, :len(z)] = z
+      yB[i, j, :len(z)] = np.ravel(ret[6][0])
+      xB[i, j], PB[i, j] = f.state(), f.covs()
+      t_prev = t
+  np.savez_compressed(os.path.join(GOLD, "perfilter_timelines.npz"), A_t=tA, A_z=zA, A_none=noneA, A_x=xA[:, ::25], A_P=PA[:, ::25],
+                      A_keep=np.arange(T)[::25], A_x_final=xA[:, -1], A_P_final=PA[:, -1], A_ft=ftA,
+                      B_t=tB, B_kind=kB, B_z=zB, B_x=xB, B_P=PB, B_y=yB)
+  print("per-filter timelines: part A", NA, "x", T, "ignored", int(noneA.sum()), "; part B", NB, "x", TB, "observations", int((kB > 0).sum()))
+
+
 if __name__ == "__main__":
   os.makedirs(GOLD, exist_ok=True)
+  if len(sys.argv) > 1:          # python oracle/make_golden.py <function> ...: regenerate only those fixtures
+    for fn_name in sys.argv[1:]:
+      globals()[fn_name]()
+    sys.exit(0)
   kinematic_stream()
   compare_rewind()
   live_single_steps()
@@ -416,5 +497,6 @@ if __name__ == "__main__":
   attitude_goldens()
   feature_goldens()
   feature_goldens(T=15, cls_name="WideFeatureKalman", out_name="feature36_stream.npz", n_upd=6)
+  perfilter_timelines()
   for fn in sorted(os.listdir(GOLD)):
     print(fn, os.path.getsize(os.path.join(GOLD, fn)))

@@ -28,7 +28,8 @@ SMALL_MAX_E = 7    # lane-per-filter register budget: x, P and the update's temp
 #   no_model_defaults  the per-model tuning defaults (two wavefronts per SIMD) spilled -> general structure
 #   rts_one_wave       the smoother spilled under the two-wavefronts-per-SIMD budget -> full register file
 #   no_rts             the smoother still touches scratch -> library without batch_rts (forward filter unaffected)
-FALLBACKS = ("force_wide", "no_model_defaults", "rts_one_wave", "no_rts")
+#   no_rts3            the smoother in the fused run's layout (emit_rts3) spilled -> rn::k_rts_group
+FALLBACKS = ("force_wide", "no_model_defaults", "no_rts3", "rts_one_wave", "no_rts")
 _active = frozenset()      # fallbacks of the emit() call in progress
 
 
@@ -172,6 +173,10 @@ def _emit(spec):
   # smoother.  Lane-per-filter models: rn::k_rts (state and covariance of a filter in one lane's registers).  Lane-group
   # models, MSCKF ones included (their main block is smoothed, ekf_sym.py:675-686): rn::k_rts_group.
   group_rts = fam == "wide"
+  from rednose_amd.codegen import emit_rts3
+  use_rts3 = (group_rts and has_run and emit_rts3.applicable(spec) and tuning.current().rts3 and "no_rts3" not in _active and "no_rts" not in _active)
+  if use_rts3:
+    src.append(emit_rts3.kernel(spec))
   has_rts = (group_rts or (fam == "small" and spec.dim_main == spec.dim_x and spec.dim_main_err == spec.dim_err)) and "no_rts" not in _active
   if has_rts:
     quat = "".join(f" rn::normalize_quat<{D}>(x, {q});" for q in spec.quaternion_idxs)
@@ -280,34 +285,48 @@ int {name}_debug_blocks(unsigned long long *out) {{
     hdr.append(f"int {name}_debug_rts_timeline(unsigned long long *out);")
     hdr.append(f"int {name}_debug_blocks(unsigned long long *out);")
   # batched, device pointers
-  abi.append(f"""int {name}_batch_predict(double *x, double *P, const double *Q, const double *dt_vec, double dt, int64_t n, int norm_quats, void *stream) {{
+  # Every step-granular entry point exists twice: plain, and `_masked` with a per-filter `active` byte (0 = this filter has no
+  # observation in this call: its x, P and z pass through untouched and flag bit 4 is set) -- what a batch of filters on
+  # INDEPENDENT timelines needs (each filter of the reference is its own instance with its own filter_time, ekf_sym.cc:83-117);
+  # together with the per-filter dt vector a call then advances exactly the filters that have something to do.
+  for sfx, act_param, act_decl in (("", "", "  const uint8_t *active = nullptr;\n"), ("_masked", "const uint8_t *active, ", "")):
+    abi.append(f"""int {name}_batch_predict{sfx}(double *x, double *P, const double *Q, const double *dt_vec, double dt, int64_t n, int norm_quats, {act_param}void *stream) {{
   RN_REQUIRE(n >= 0 && x && P && Q, rn::ERR_ARG);
   if (n == 0) return rn::OK;
   RN_REQUIRE(rn::aligned16(x) && rn::aligned16(P), rn::ERR_ALIGN);
-{fam_mod.launch_predict()}
+{act_decl}{fam_mod.launch_predict()}
   RN_HIP(hipGetLastError());
   return rn::OK;
 }}""")
-  hdr.append(f"int {name}_batch_predict(double *x, double *P, const double *Q, const double *dt_vec, double dt, int64_t n, int norm_quats, void *stream);")
-  for k in spec.kinds:
-    abi.append(f"""int {name}_batch_update_{k.kind}(double *x, double *P, double *z, const double *R, int r_per_filter, const double *ea, int64_t n, int norm_quats, uint8_t *flags, void *stream) {{
+    hdr.append(f"int {name}_batch_predict{sfx}(double *x, double *P, const double *Q, const double *dt_vec, double dt, int64_t n, int norm_quats, {act_param}void *stream);")
+    for k in spec.kinds:
+      abi.append(f"""int {name}_batch_update_{k.kind}{sfx}(double *x, double *P, double *z, const double *R, int r_per_filter, const double *ea, int64_t n, int norm_quats, uint8_t *flags, {act_param}void *stream) {{
   RN_REQUIRE(n >= 0 && x && P && z && R{ea_req(k)}, rn::ERR_ARG);
   if (n == 0) return rn::OK;
   RN_REQUIRE(rn::aligned16(x) && rn::aligned16(P) && rn::aligned16(z) && (!r_per_filter || rn::aligned16(R)), rn::ERR_ALIGN);
-{fam_mod.launch_step(k.kind, False)}
+{act_decl}{fam_mod.launch_step(k.kind, False)}
   RN_HIP(hipGetLastError());
   return rn::OK;
 }}
-int {name}_batch_predict_update_{k.kind}(double *x, double *P, const double *Q, const double *dt_vec, double dt, double *z, const double *R, int r_per_filter, const double *ea, int64_t n, int norm_quats, uint8_t *flags, void *stream) {{
+int {name}_batch_predict_update_{k.kind}{sfx}(double *x, double *P, const double *Q, const double *dt_vec, double dt, double *z, const double *R, int r_per_filter, const double *ea, int64_t n, int norm_quats, uint8_t *flags, {act_param}void *stream) {{
   RN_REQUIRE(n >= 0 && x && P && Q && z && R{ea_req(k)}, rn::ERR_ARG);
   if (n == 0) return rn::OK;
   RN_REQUIRE(rn::aligned16(x) && rn::aligned16(P) && rn::aligned16(z) && (!r_per_filter || rn::aligned16(R)), rn::ERR_ALIGN);
-{fam_mod.launch_step(k.kind, True)}
+{act_decl}{fam_mod.launch_step(k.kind, True)}
   RN_HIP(hipGetLastError());
   return rn::OK;
 }}""")
-    hdr.append(f"int {name}_batch_update_{k.kind}(double *x, double *P, double *z, const double *R, int r_per_filter, const double *ea, int64_t n, int norm_quats, uint8_t *flags, void *stream);")
-    hdr.append(f"int {name}_batch_predict_update_{k.kind}(double *x, double *P, const double *Q, const double *dt_vec, double dt, double *z, const double *R, int r_per_filter, const double *ea, int64_t n, int norm_quats, uint8_t *flags, void *stream);")
+      hdr.append(f"int {name}_batch_update_{k.kind}{sfx}(double *x, double *P, double *z, const double *R, int r_per_filter, const double *ea, int64_t n, int norm_quats, uint8_t *flags, {act_param}void *stream);")
+      hdr.append(f"int {name}_batch_predict_update_{k.kind}{sfx}(double *x, double *P, const double *Q, const double *dt_vec, double dt, double *z, const double *R, int r_per_filter, const double *ea, int64_t n, int norm_quats, uint8_t *flags, {act_param}void *stream);")
+
+  abi.append(f"""int {name}_batch_ring_copy(double *ring, int64_t ring_stride, double *flat, int64_t flat_stride, int64_t rec, const int32_t *slot, const uint8_t *active, int64_t n, int to_ring, void *stream) {{
+  RN_REQUIRE(n >= 0 && rec >= 0 && rec <= ring_stride && rec <= flat_stride && ring && flat && slot, rn::ERR_ARG);
+  if (n == 0 || rec == 0) return rn::OK;
+  hipLaunchKernelGGL(rn::k_ring_copy, dim3((unsigned)(n < 65536 ? n : 65536)), dim3(64), 0, (hipStream_t)stream, ring, ring_stride, flat, flat_stride, rec, slot, active, n, to_ring);
+  RN_HIP(hipGetLastError());
+  return rn::OK;
+}}""")
+  hdr.append(f"int {name}_batch_ring_copy(double *ring, int64_t ring_stride, double *flat, int64_t flat_stride, int64_t rec, const int32_t *slot, const uint8_t *active, int64_t n, int to_ring, void *stream);")
 
   if hasattr(fam_mod, "launch_maha"):
     for k in spec.kinds:
@@ -348,7 +367,9 @@ int {name}_batch_predict_update_{k.kind}(double *x, double *P, const double *Q, 
   hdr.append(f"int {name}_batch_run(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts, int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, double *trace_x, double *trace_P, const double *ea, const int32_t *augment, void *stream);")
 
   if has_rts:
-    if group_rts:
+    if use_rts3:
+      launch = emit_rts3.launch()
+    elif group_rts:
       GLr = 16 if M <= 16 else (32 if M <= 32 else 64)
       launch = f"""  const int64_t tiles = (n + {64 // GLr - 1}) / {64 // GLr};
   hipLaunchKernelGGL(rn::k_rts_group<RtsModel>, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,

@@ -1,0 +1,420 @@
+"""Kernel family W, smoother `k_rts3`: the RTS backward pass in the fused run's layout -- SEVERAL ROWS PER LANE, 8 FILTERS PER WAVEFRONT.
+
+Reference: the Python-only `EKF_sym.rts_smooth` (/root/reference/rednose/helpers/ekf_sym.py:651-690); per backward step k
+    Fk = F(xk_k, t[k+1] - t[k]);  Ck = solve(Pk1_k, Fk Pk_k^T)^T;  xk_n = err(xk_k, Ck inv_err(xk1_k, xk1_n));
+    Pk_n = Pk_k + Ck (Pk1_n - Pk1_k) Ck^T
+with the predicted pair (xk1_k, Pk1_k) recomputed from the filtered one (templates/ekf_hip_rts.h explains the memory plan and
+the recursion's quirks, which are kept: start from the PREDICTED pair of the last step, in-place renormalisation of xk1_n).
+
+Why a third smoother.  `rn::k_rts_group` (round 2) gives a filter a 32-lane group -- 2 filters per wavefront for live's 22 error
+states -- and one row of every matrix per lane.  Its backward step is a chain of dependent LDS round trips and fp64
+instructions (a 22-column factorisation, 44 substitution pivots) that TWO filters share: 25 us per wavefront-step, 31 % of the
+wave cycles issuing (profiles/r2_sq_counters_smoother.txt), 160 M steps/s = 16 % of the HBM roofline; the two E^3 products ran on
+v_mfma_f64_16x16x4 tiles that are 57 % padding for E = 22.  Here the layout is the fused run's (emit_wide3): a filter gets
+GL = 8 lanes (16 above 22 error states), lane c owns rows c, c + GL, c + 2 GL ... of every matrix (R = ceil(E / GL) row slots),
+so EIGHT filters share each dependent chain, every broadcast operand read from LDS feeds R FMAs, 22 of 24 row slots are busy,
+and all arithmetic is vector fp64 (the products need 2 R E^2 FMAs per lane and product -- cheaper than the padded MFMA tiles).
+The price is the fused run's: one wavefront per SIMD and ONE matrix image of LDS per filter (8 images + vectors = 41 KB per
+wavefront, 3-4 per CU), and general fp64 arithmetic only sees the 256 architectural registers (the other half of the file is
+parking space): so only TWO row sets live in registers (a, y: 4 R E registers), every matrix that has to be broadcast takes its
+turn in the image -- which holds either one full E x E matrix or the packed lower triangles of TWO symmetric ones -- and the
+smoothed covariance is not carried from step to step in registers but read back from where the previous step stored it:
+
+  step k (image I; row sets a, y):
+    Pk_k HBM -> I (one coalesced asynchronous burst), xk_k -> LDS; lead lanes evaluate f / F non-zeros (scal_predict)
+    a <- rows of Pk_k;  y <- rows of A = Pk_k Fk^T (= columns of M = Fk Pk_k^T: the right-hand sides, row-local)
+    I <- A;  a <- rows of Pk1_k = (columns of A) Fk^T + dt Q   (P = P^T as in the fused run's predict: one transposition)
+    rows of Pk1_n <- Ps[k + 1] (L2; the previous step's output);  I <- tril(Pk1_k) | tril(D = Pk1_n - Pk1_k)
+    Cholesky of Pk1_k, left-looking: pivot row broadcast from I, every lane forms its R entries and the pivot redundantly
+    y <- Pk1_k^-1 y: forward substitution in dot form, backward in axpy form -- both read ROWS of the packed factor
+    state: delta = Ck inv_err(xk1_k, xk1_n), xk_n = err(xk_k, delta)  (lead lanes + one R x E dot per lane)
+    a <- T = Ck D, dot form against the rows of the symmetric D (packed triangle read both ways)
+    I <- Ck;  y <- U = T Ck^T, dot form against the rows of Ck
+    I <- U;  Ps[k] <- Pf[k] + U: one coalesced read-add-write
+
+Generated for ordinary (non-MSCKF) lane-group models up to 32 error states; MSCKF models and larger ones keep rn::k_rts_group.
+"""
+from rednose_amd.codegen.emit_common import term, sum_terms
+
+
+def _ind(lines, n=2):
+  pad = " " * n
+  return [pad + s for s in lines]
+
+
+def applicable(spec):
+  msckf = any(k.He_sym is not None for k in spec.kinds) or spec.N > 0
+  return (not msckf) and spec.dim_main_err == spec.dim_err and spec.dim_err <= 32
+
+
+class RtsLayout:
+  """Scalar slot of the smoother (doubles per filter): x' = f(x) [normalised], the non-trivial entries of F, dt."""
+
+  def __init__(self, spec, f_vars, he_vars_by_kind):        # same constructor as emit_wide2.Layout / emit_wide3.RunLayout
+    D = spec.dim_x
+    self.zmax = max(k.zdim for k in spec.kinds)
+    self.nf = len(f_vars)
+    self.nh = 0
+    self.OFF_X = 0
+    self.OFF_F = D
+    self.OFF_DT = D + self.nf
+    n = self.OFF_DT + 1
+    # fields the shared scalar functions of emit_wide2.device_functions address but the smoother never calls
+    self.OFF_HE = self.OFF_DX = self.OFF_Y = self.OFF_FL = self.OFF_RF = self.OFF_RP = n
+    self.zf = 0
+    self.SLOT = n + 1 - (n & 1)
+
+
+def _tables(spec):
+  from rednose_amd.codegen import emit_wide2 as w2
+  _, _, F, f_vars = w2._lowered_predict(spec)                  # pylint: disable=protected-access
+  lay = RtsLayout(spec, f_vars, {})
+  return lay, w2._slotted(F, f_vars, lay.OFF_F)                # pylint: disable=protected-access
+
+
+def _scal_text(spec):
+  """scal_predict against RtsLayout under the suffix _s (only that function of emit_wide2.device_functions is used)."""
+  from rednose_amd.codegen import emit_wide2 as w2
+  text, lay = w2.device_functions(spec, lay_cls=RtsLayout, sfx="_s")
+  # keep scal_predict_s only: the observation / injection functions address slot fields the smoother does not have
+  keep = []
+  for fn in text.split("\n\n"):
+    if "void scal_predict_s(" in fn:
+      keep.append(fn)
+  assert len(keep) == 1
+  return keep[0], lay
+
+
+def _region(b, head, body, pins):
+  """One scheduling region: operand loads of the NEXT piece of work first (`head`), then this piece's arithmetic, then a
+  compiler fence with the freshly written values pinned in front of it (see emit_wide3._rank_pass for why hipcc needs both)."""
+  b.extend(head)
+  b.extend(body)
+  if pins:
+    b.append("      " + " ".join(f"rn::pin({v});" for v in pins))
+  b.append("      rn::wave_lds_sync();")
+
+
+def tri(i, j):
+  """Index of entry (i, j), j <= i, in row-major packed lower-triangular storage."""
+  assert j <= i
+  return i * (i + 1) // 2 + j
+
+
+def sym(i, j):
+  return tri(i, j) if j <= i else tri(j, i)
+
+
+def kernel(spec):
+  from rednose_amd.codegen import emit_wide3 as w3
+  D, E = spec.dim_x, spec.dim_err
+  EE = E * E
+  TRI = E * (E + 1) // 2
+  IMG = max(EE, 2 * TRI)
+  IMG += IMG & 1
+  GL, R, FPW = w3.layout(spec)
+  scal, lay = _scal_text(spec)
+  _, Fs = _tables(spec)
+  quat = "".join(f" rn::normalize_quat<{D}>(xv, {q});" for q in spec.quaternion_idxs)
+  S = range(R)
+  aligned = EE % 2 == 0          # every tile's records start 16-byte aligned: direct HBM -> LDS copies
+  b = []
+  A = b.append
+
+  def rows_decl(name):
+    return " ".join(f"double {name}{s}[{E}];" for s in S)
+
+  def rows_to_image(name, ind="      "):
+    for s in S:
+      A(f"{ind}if (ok{s}) {{")
+      A("#pragma unroll")
+      A(f"{ind}  for (int j = 0; j < {E}; j++) sI[rr{s} * {E} + j] = {name}{s}[j];")
+      A(f"{ind}}}")
+
+  A(f"// ---- smoother in the fused run's layout: {GL} lanes x {R} rows per filter, {FPW} filters per wavefront (emit_rts3.py) ----")
+  A(f"constexpr int RTS3_SLOT = {lay.SLOT};")
+  A(f"constexpr int RTS3_IMG = {IMG};      // doubles of LDS image per filter: a full E x E matrix, or two packed triangles")
+  A(scal)
+  A(f"""
+__global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, const double* __restrict__ Pf, const double* __restrict__ ts,
+    const int64_t T, const double* __restrict__ gQ, const int64_t n, const int norm_quats, double* __restrict__ xs,
+    double* __restrict__ Ps, const double* __restrict__ xl, const double* __restrict__ Pl) {{
+  __shared__ __attribute__((aligned(16))) double s_I[{FPW} * RTS3_IMG + 2];      // the one matrix image per filter (see emit_rts3.py)
+  __shared__ __attribute__((aligned(16))) double s_sl[{FPW} * RTS3_SLOT];        // x' = f(xk_k), F non-zeros, dt
+  __shared__ __attribute__((aligned(16))) double s_xk[{FPW} * {D} + 2];          // xk_k
+  __shared__ __attribute__((aligned(16))) double s_xn[{FPW} * {D} + 2];          // xk1_n, then xk_n
+  __shared__ __attribute__((aligned(16))) double s_dv[{FPW} * {E} + 2];          // inv_err(xk1_k, xk1_n), then Ck delta
+  const int lane = threadIdx.x;
+  const int g = lane / {GL};
+  const int c = lane % {GL};
+  const int64_t tiles = (n + {FPW} - 1) / {FPW};
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
+    const int64_t base = tile * {FPW};
+    const int cnt = (n - base) < {FPW} ? (int)(n - base) : {FPW};
+    const bool live = g < cnt;
+    const int gg = live ? g : 0;
+    const bool lead = live && c == 0;
+    double* sI = s_I + gg * RTS3_IMG;       // full-matrix view: sI[r * {E} + j]
+    double* sL = sI;                        // packed lower triangle of Pk1_k / its factor: sL[r (r + 1) / 2 + j], j <= r
+    double* sD = sI + {TRI};                // packed lower triangle of D = Pk1_n - Pk1_k (symmetric up to rounding)
+    double* sl = s_sl + gg * RTS3_SLOT;
+    double* sxk = s_xk + gg * {D};
+    double* sxn = s_xn + gg * {D};
+    double* sdv = s_dv + gg * {E};""")
+  for s in S:
+    A(f"    const int rr{s} = c + {GL * s}; const bool ok{s} = live && rr{s} < {E}; const int rc{s} = rr{s} < {E} ? rr{s} : 0;"
+      f" const int tb{s} = rc{s} * (rc{s} + 1) / 2;")
+  A("    if (T == 1) {      // nothing to smooth, the single estimate's predicted pair is not available: the filtered pair passes through")
+  A(f"      if (Ps != Pf) {{ for (int i = lane; i < cnt * {EE}; i += 64) Ps[base * {EE} + i] = Pf[base * {EE} + i]; }}")
+  A(f"      if (xs != xf) {{ for (int i = lane; i < cnt * {D}; i += 64) xs[base * {D} + i] = xf[base * {D} + i]; }}")
+  A("      continue;")
+  A("    }")
+  A("    for (int64_t k = T - 2; k >= 0; k--) {")
+  A("      const bool first = (k == T - 2);")
+  A("      int lb = lane;")
+  A('      asm volatile("" : "+v"(lb));         // opaque copy of the lane index: the copies\' index arithmetic stays inside the step')
+  A("      // ---- A. filtered pair of step k: Pk_k -> image in one coalesced burst, xk_k -> LDS ----")
+  if aligned and IMG == EE:
+    A(f"      rn::async_copy_g2l<{FPW} * {EE}>(Pf + (k * n + base) * {EE}, cnt * {EE}, s_I, lb);      // no register staging: lands under the scalar phase")
+    pre_wait = "      rn::async_wait();"
+  elif aligned:
+    A("      // (a filter's image is larger than its record: one asynchronous copy per filter)")
+    A(f"      for (int f_ = 0; f_ < cnt; f_++) rn::async_copy_g2l<{EE}>(Pf + (k * n + base + f_) * {EE}, {EE}, s_I + f_ * RTS3_IMG, lb);")
+    pre_wait = "      rn::async_wait();"
+  else:
+    A(f"      for (int i = lb; i < cnt * {EE}; i += 64) s_I[(i / {EE}) * RTS3_IMG + i % {EE}] = Pf[(k * n + base) * {EE} + i];      // (odd record size)")
+    pre_wait = None
+  A(f"      for (int i = lb; i < cnt * {D}; i += 64) s_xk[i] = xf[(k * n + base) * {D} + i];")
+  A("      const double dt = ts[k + 1] - ts[k];")
+  A("      rn::wave_lds_sync();")
+  A("      // ---- B. f(xk_k) [renormalised like the forward pass], non-zeros of Fk: once per filter -> slot ----")
+  A("      if (lead) scal_predict_s(sxk, dt, sl, norm_quats & 1);")
+  if pre_wait:
+    A(pre_wait)
+  A("      rn::wave_lds_sync();")
+  A(f"      {rows_decl('a')}      // rows of Pk_k, then Pk1_k / its factor, then T")
+  A(f"      {rows_decl('y')}      // right-hand sides (rows of A = Pk_k Fk^T), then rows of Ck")
+  for s in S:
+    A("#pragma unroll")
+    A(f"      for (int j = 0; j < {E}; j++) a{s}[j] = sI[rc{s} * {E} + j];")
+  A("      rn::wave_lds_sync();      // every lane has its rows: the image takes A")
+  A("      // ---- C. rows of A = Pk_k Fk^T (row-local, F's structural zeros cost nothing): the right-hand sides, and through the")
+  A("      // image the columns of A = rows of Fk Pk_k (P = P^T up to rounding, as in the fused run's predict) ----")
+  for s in S:
+    for i in range(E):
+      A(f"      y{s}[{i}] = {sum_terms(term(cf, f'a{s}[{kk}]') for kk, cf in Fs.row_nz(i))};")
+  rows_to_image("y")
+  A("      rn::wave_lds_sync();")
+  A("      {")
+  A("        int qz = 0;")
+  A('        asm volatile("" : "+v"(qz));       // Q behind an opaque zero: its addresses are not worth registers across the step loop')
+  A("        const double* __restrict__ gq = gQ + qz;")
+  for s in S:
+    A("        {")
+    A(f"          double col[{E}], q[{E}];")
+    A("#pragma unroll")
+    A(f"          for (int m = 0; m < {E}; m++) col[m] = sI[m * {E} + rc{s}];      // column of A = row of Fk Pk_k")
+    A("#pragma unroll")
+    A(f"          for (int j = 0; j < {E}; j++) q[j] = gq[rc{s} * {E} + j];")
+    for j in range(E):
+      A(f"          a{s}[{j}] = {sum_terms(term(cf, f'col[{m}]') for m, cf in Fs.row_nz(j))} + dt*q[{j}];")
+    A("        }")
+  A("      }")
+  A("      rn::wave_lds_sync();      // the image is free: rows of Pk1_k are in a*")
+  A("      // ---- D. recursion start / difference matrix.  The smoothed covariance of step k + 1 is NOT carried in registers: the")
+  A("      // previous step left it in Ps[k + 1] (through the L2), its rows are read back here, the lower triangle of")
+  A("      // D = Pk1_n - Pk1_k goes straight to LDS and the lower triangle of Pk1_k beside it. ----")
+  A("      if (first) {")
+  A("        // newest estimate := the predicted pair of the last step (passed in, or recomputed just now): ekf_sym.py:658-659")
+  A("        if (live) {       // (two loops, not one select between a global and an LDS source: hipcc 7.2 trips over the generic pointer)")
+  A(f"          if (xl != nullptr) {{ for (int i = c; i < {D}; i += {GL}) sxn[i] = xl[(base + gg) * {D} + i]; }}")
+  A(f"          else {{ for (int i = c; i < {D}; i += {GL}) sxn[i] = sl[{lay.OFF_X} + i]; }}")
+  A("        }")
+  A("        if (Pl != nullptr) {")
+  A(f"          for (int i = lane; i < cnt * {EE}; i += 64) Ps[((k + 1) * n + base) * {EE} + i] = Pl[base * {EE} + i];")
+  A("        } else {")
+  rows_to_image("a", ind="          ")
+  A("          rn::wave_lds_sync();")
+  A(f"          for (int i = lane; i < cnt * {EE}; i += 64) Ps[((k + 1) * n + base) * {EE} + i] = s_I[(i / {EE}) * RTS3_IMG + i % {EE}];")
+  A("          rn::wave_lds_sync();")
+  A("        }")
+  A('        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
+  A("        rn::wave_lds_sync();")
+  A("      }")
+  A("      if (lead && (norm_quats & 2)) {")
+  A(f"        double xv[{D}];")
+  A("#pragma unroll")
+  A(f"        for (int i = 0; i < {D}; i++) xv[i] = sxn[i];")
+  A(f"       {quat}")
+  A("#pragma unroll")
+  A(f"        for (int i = 0; i < {D}; i++) sxn[i] = xv[i];")
+  A("      }")
+  A("      rn::wave_lds_sync();")
+  A("      {")
+  A("        int lo = lane;")
+  A('        asm volatile("" : "+v"(lo));')
+  A(f"        for (int i = lo; i < cnt * {D}; i += 64) xs[((k + 1) * n + base) * {D} + i] = s_xn[i];      // smoothed state of step k + 1 (after its renormalisation)")
+  A("      }")
+  for s in S:
+    A("      {")
+    A(f"        const double* pn_ = Ps + (((k + 1) * n + base + gg) * {EE} + rc{s} * {E});")
+    A(f"        double pn[{E}];")
+    A("#pragma unroll")
+    A(f"        for (int j = 0; j < {E}; j++) pn[j] = __hip_atomic_load(pn_ + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // served by the L2 (another lane of this wavefront stored it)")
+    A("#pragma unroll")
+    A(f"        for (int j = 0; j < {E}; j++) {{")
+    A(f"          if (ok{s} && j <= rr{s}) {{ sD[tb{s} + j] = pn[j] - a{s}[j]; sL[tb{s} + j] = a{s}[j]; }}")
+    A("        }")
+    A("      }")
+  A("      rn::wave_lds_sync();")
+  A("      // ---- E. Cholesky of Pk1_k, left-looking.  Rows in a*, finished rows of the factor in LDS (packed): the pivot row is")
+  A("      // broadcast and every lane forms its entries AND the pivot redundantly (no publish / wait per column).  Column j + 1's")
+  A("      // sums over the columns before j depend on nothing column j produces: they are emitted inside column j's region, so they")
+  A("      // issue while column j's reciprocal square root (a chain of dependent fp64 operations) is in flight.  The diagonal of")
+  A("      // the packed factor ends up holding the RECIPROCAL pivots (the only thing the substitutions need of it). ----")
+  A(f"      double pv_0 = sL[{tri(0, 0)}], pw_0 = 0.0;")
+  for s in S:
+    A(f"      double t{s}_0 = a{s}[0], u{s}_0 = 0.0;")
+  for j in range(E):
+    body = []
+    if j >= 1:        # the last term: entry j - 1 of the pivot row exists since the previous region's store
+      m = j - 1
+      tg = "w" if m & 1 else "v"
+      body.append(f"      {{ const double ql = sL[{tri(j, m)}]; p{tg}_{j} = fma(-ql, ql, p{tg}_{j});" +
+                  "".join(f" {'u' if m & 1 else 't'}{s}_{j} = fma(-a{s}[{m}], ql, {'u' if m & 1 else 't'}{s}_{j});" for s in S) + " }")
+    body.append(f"      const double il_{j} = rn::fast_rsqrt(pv_{j} + pw_{j});")
+    if j + 1 < E:     # early part of column j + 1: entries 0 .. j - 1 of its pivot row are final
+      jn = j + 1
+      body.append(f"      double pv_{jn} = sL[{tri(jn, jn)}], pw_{jn} = 0.0;")
+      for s in S:
+        body.append(f"      double t{s}_{jn} = a{s}[{jn}], u{s}_{jn} = 0.0;")
+      if j >= 1:
+        body.append(f"      {{ double q[{j}];")
+        body.append("#pragma unroll")
+        body.append(f"        for (int m = 0; m < {j}; m++) q[m] = sL[{tri(jn, 0)} + m];")
+        for m in range(j):
+          tg = "w" if m & 1 else "v"
+          body.append(f"        p{tg}_{jn} = fma(-q[{m}], q[{m}], p{tg}_{jn});" +
+                      "".join(f" {'u' if m & 1 else 't'}{s}_{jn} = fma(-a{s}[{m}], q[{m}], {'u' if m & 1 else 't'}{s}_{jn});" for s in S))
+        body.append("      }")
+    for s in S:
+      body.append(f"      a{s}[{j}] = (rr{s} == {j}) ? il_{j} : (t{s}_{j} + u{s}_{j}) * il_{j};")
+      body.append(f"      if (ok{s} && rr{s} >= {j}) sL[tb{s} + {j}] = a{s}[{j}];")
+    pins = [f"a{s}[{j}]" for s in S]
+    if j + 1 < E:
+      pins += [f"t{s}_{j + 1}" for s in S] + [f"u{s}_{j + 1}" for s in S] + [f"pv_{j + 1}", f"pw_{j + 1}"]
+    _region(b, [], body, pins)
+  A("      // ---- F. Ck^T = Pk1_k^-1 M, i.e. every row slot solves with its own right-hand side (row of A).  Forward substitution in")
+  A("      // dot form (row i of the factor against the solved part), backward in axpy form (row m of the factor scaled into the")
+  A("      // unsolved part): both read ROWS of the packed factor, and in both the next row is requested before the current one is")
+  A("      // used. ----")
+
+  def lrow(i, name):          # entries 0 .. i - 1 of row i of the factor and its reciprocal pivot
+    out = []
+    if i:
+      out += [f"      double {name}[{i}];", "#pragma unroll", f"      for (int m = 0; m < {i}; m++) {name}[m] = sL[{tri(i, 0)} + m];"]
+    out.append(f"      const double {name}_il = sL[{tri(i, i)}];")
+    return out
+  b.extend(lrow(0, "f0"))
+  for i in range(E):
+    head = lrow(i + 1, f"f{i + 1}") if i + 1 < E else []
+    body = []
+    for s in S:
+      body.append(f"      double ft{s}_{i} = y{s}[{i}], fu{s}_{i} = 0.0;")
+    for m in range(i):
+      body.append("      " + " ".join(f"f{'u' if m & 1 else 't'}{s}_{i} = fma(-y{s}[{m}], f{i}[{m}], f{'u' if m & 1 else 't'}{s}_{i});" for s in S))
+    body.append("      " + " ".join(f"y{s}[{i}] = (ft{s}_{i} + fu{s}_{i}) * f{i}_il;" for s in S))
+    _region(b, head, body, [f"y{s}[{i}]" for s in S])
+  b.extend(lrow(E - 1, f"g{E - 1}"))
+  for m in range(E - 1, -1, -1):
+    head = lrow(m - 1, f"g{m - 1}") if m >= 1 else []
+    body = ["      " + " ".join(f"y{s}[{m}] *= g{m}_il;" for s in S)]
+    for i in range(m - 1, -1, -1):        # the entry the next pivot needs first
+      body.append("      " + " ".join(f"y{s}[{i}] = fma(-g{m}[{i}], y{s}[{m}], y{s}[{i}]);" for s in S))
+    _region(b, head, body, [f"y{s}[{i}]" for s in S for i in range(m + 1)])
+  A("      // y* = rows of Ck")
+  A("      // ---- G. state: delta = Ck inv_err(xk1_k, xk1_n); xk_n = err(xk_k, delta) ----")
+  A("      if (lead) {")
+  A(f"        double xb[{D}], xn1[{D}], delta[{E}];")
+  A("#pragma unroll")
+  A(f"        for (int i = 0; i < {D}; i++) {{ xb[i] = sl[{lay.OFF_X} + i]; xn1[i] = sxn[i]; }}")
+  A("        inv_err_fun(xb, xn1, delta);")
+  A("#pragma unroll")
+  A(f"        for (int i = 0; i < {E}; i++) sdv[i] = delta[i];")
+  A("      }")
+  A("      rn::wave_lds_sync();")
+  A("      {")
+  A(f"        double de[{E}];")
+  A("#pragma unroll")
+  A(f"        for (int j = 0; j < {E}; j++) de[j] = sdv[j];")
+  for s in S:
+    A(f"        const double dx{s} = (" + " + ".join(f"y{s}[{j}]*de[{j}]" for j in range(0, E, 2)) + ") + (" +
+      (" + ".join(f"y{s}[{j}]*de[{j}]" for j in range(1, E, 2)) or "0.0") + ");")
+  A("        rn::wave_lds_sync();      // every lane has delta: the buffer takes Ck delta")
+  for s in S:
+    A(f"        if (ok{s}) sdv[rr{s}] = dx{s};")
+  A("      }")
+  A("      rn::wave_lds_sync();")
+  A("      if (lead) {")
+  A(f"        double xa[{D}], xnew[{D}], delta[{E}];")
+  A("#pragma unroll")
+  A(f"        for (int i = 0; i < {D}; i++) xa[i] = sxk[i];")
+  A("#pragma unroll")
+  A(f"        for (int i = 0; i < {E}; i++) delta[i] = sdv[i];")
+  A("        err_fun(xa, delta, xnew);")
+  A("#pragma unroll")
+  A(f"        for (int i = 0; i < {D}; i++) sxn[i] = xnew[i];       // xk_n: becomes xk1_n of the next (older) step")
+  A("      }")
+  A("      // ---- H. T = Ck D in dot form: entry j of a row of T is that row of Ck against row j of the symmetric D (its packed")
+  A("      // triangle is read both ways); each finished column of T is final, only Ck's rows stay live as coefficients ----")
+
+  def drow(j):
+    return [f"      double d{j}[{E}];"] + [f"      d{j}[{kk}] = sD[{sym(j, kk)}];" for kk in range(E)]
+  b.extend(drow(0))
+  for j in range(E):
+    head = drow(j + 1) if j + 1 < E else []
+    body = ["      " + " ".join(f"double h{s}_{j} = 0.0;" for s in S)]
+    for kk in range(E):
+      body.append("      " + " ".join((f"a{s}[{j}] = {'y%d[%d]*d%d[%d]' % (s, kk, j, kk) if kk == 0 else 'fma(y%d[%d], d%d[%d], a%d[%d])' % (s, kk, j, kk, s, j)};" if kk % 2 == 0 else
+                                       f"h{s}_{j} = fma(y{s}[{kk}], d{j}[{kk}], h{s}_{j});") for s in S))
+    body.append("      " + " ".join(f"a{s}[{j}] += h{s}_{j};" for s in S))
+    _region(b, head, body, [f"a{s}[{j}]" for s in S])
+  A("      // ---- I. U = T Ck^T: rows of Ck are broadcast from the image (full layout again: factor and D are dead), dot form ----")
+  rows_to_image("y")
+  A("      rn::wave_lds_sync();")
+
+  def c_loads(j):
+    return [f"      double c{j}[{E}];", "#pragma unroll", f"      for (int kk = 0; kk < {E}; kk++) c{j}[kk] = sI[{j * E} + kk];"]
+  b.extend(c_loads(0))
+  for j in range(E):
+    head = c_loads(j + 1) if j + 1 < E else []
+    body = ["      " + " ".join(f"double e{s}_{j} = 0.0;" for s in S)]
+    for kk in range(E):
+      body.append("      " + " ".join((f"y{s}[{j}] = {'a%d[%d]*c%d[%d]' % (s, kk, j, kk) if kk == 0 else 'fma(a%d[%d], c%d[%d], y%d[%d])' % (s, kk, j, kk, s, j)};" if kk % 2 == 0 else
+                                       f"e{s}_{j} = fma(a{s}[{kk}], c{j}[{kk}], e{s}_{j});") for s in S))
+    body.append("      " + " ".join(f"y{s}[{j}] += e{s}_{j};" for s in S))
+    _region(b, head, body, [f"y{s}[{j}]" for s in S])
+  A("      // ---- J. Pk_n = Pk_k + U leaves: U's rows through the image, then one coalesced read-add-write over the tile's records ----")
+  rows_to_image("y")
+  A("      rn::wave_lds_sync();")
+  A("      {")
+  A("        int le = lane;")
+  A('        asm volatile("" : "+v"(le));')
+  A(f"        for (int i = le; i < cnt * {EE}; i += 64) Ps[(k * n + base) * {EE} + i] = Pf[(k * n + base) * {EE} + i] + s_I[(i / {EE}) * RTS3_IMG + i % {EE}];")
+  A("      }")
+  A('      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next (older) step reads these rows back through the L2')
+  A("      rn::wave_lds_sync();")
+  A("    }")
+  A("    // ---- the oldest smoothed state goes out un-normalised (ekf_sym.py:665-667 never reaches it); its covariance left above ----")
+  A(f"    for (int i = lane; i < cnt * {D}; i += 64) xs[base * {D} + i] = s_xn[i];")
+  A("    rn::wave_lds_sync();")
+  A("  }")
+  A("}")
+  return "\n".join(b)
+
+
+def launch():
+  from rednose_amd.codegen import emit_wide3 as w3  # noqa: F401  (FPWR of the fused run is this kernel's filters per wavefront)
+  return """  const int64_t tiles = (n + FPWR - 1) / FPWR;
+  hipLaunchKernelGGL(k_rts3, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     xf, Pf, ts, T, Q, n, norm_quats, xs, Ps, x_last, P_last);"""

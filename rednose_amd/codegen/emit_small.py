@@ -273,7 +273,7 @@ def kernels(spec):
 // ---- predict only: one launch propagates n filters by dt -------------------------------------------
 __global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double* __restrict__ gP,
     const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
-    const int norm_quats) {{
+    const int norm_quats, const uint8_t* __restrict__ active) {{
   __shared__ __attribute__((aligned(16))) double s_x[64 * {D | 1}];
   __shared__ __attribute__((aligned(16))) double s_P[64 * {EE | 1}];
   __shared__ __attribute__((aligned(16))) double s_Q[{EE}];
@@ -294,8 +294,12 @@ __global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double*
     predict_regs(x, P, s_Q, dt);
     {norm}
     rn::wave_lds_sync();
-    rn::regs_to_lds<{D}>(s_x, lane, x);
-    rn::regs_to_lds<{EE}>(s_P, lane, P);
+    // a masked-out filter (active[i] == 0: no observation for it in this call) keeps the record it came with: its lane
+    // does not overwrite the LDS image, so the coalesced write-back returns the loaded bytes
+    if (active == nullptr || (lane < cnt && active[base + lane] != 0)) {{
+      rn::regs_to_lds<{D}>(s_x, lane, x);
+      rn::regs_to_lds<{EE}>(s_P, lane, P);
+    }}
     rn::wave_lds_sync();
     rn::tile_l2g<{D}>(gx + base * {D}, cnt, s_x, lane);
     rn::tile_l2g<{EE}>(gP + base * {EE}, cnt, s_P, lane);
@@ -314,7 +318,7 @@ template <bool DO_PREDICT>
 __global__ __launch_bounds__(64){kattr} void k_step_{k.kind}(double* __restrict__ gx, double* __restrict__ gP,
     double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const double* __restrict__ gea,
     const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
-    const int norm_quats, uint8_t* __restrict__ flags) {{
+    const int norm_quats, uint8_t* __restrict__ flags, const uint8_t* __restrict__ active) {{
   __shared__ __attribute__((aligned(16))) double s_x[64 * {D | 1}];
   __shared__ __attribute__((aligned(16))) double s_P[64 * {EE | 1}];
   __shared__ __attribute__((aligned(16))) double s_z[64 * {Z | 1}];
@@ -353,9 +357,13 @@ __global__ __launch_bounds__(64){kattr} void k_step_{k.kind}(double* __restrict_
     int fl = update_{k.kind}_regs(x, P, z, R{ea});
     {norm}
     rn::wave_lds_sync();
-    rn::regs_to_lds<{D}>(s_x, lane, x);
-    rn::regs_to_lds<{EE}>(s_P, lane, P);
-    rn::regs_to_lds<{Z}>(s_z, lane, z);
+    // masked-out filters (active[i] == 0) pass through untouched: x, P and z leave as they came, flag bit 4 is set
+    const bool on = active == nullptr || (lane < cnt && active[base + lane] != 0);
+    if (on) {{
+      rn::regs_to_lds<{D}>(s_x, lane, x);
+      rn::regs_to_lds<{EE}>(s_P, lane, P);
+      rn::regs_to_lds<{Z}>(s_z, lane, z);
+    }}
     rn::wave_lds_sync();
     rn::tile_l2g<{D}>(gx + base * {D}, cnt, s_x, lane);
     rn::tile_l2g<{EE}>(gP + base * {EE}, cnt, s_P, lane);
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(64){kattr} void k_step_{k.kind}(double* __restrict_
 #pragma unroll
       for (int i = 0; i < {D}; i++) acc += x[i];
       if (!(acc - acc == 0.0)) fl |= 2;          // non-finite state
-      flags[base + lane] = (uint8_t)fl;
+      flags[base + lane] = (uint8_t)(on ? fl : 16);
     }}
     rn::wave_lds_sync();
   }}
@@ -474,15 +482,15 @@ def launch_run():
 def launch_predict():
   return """  const int64_t tiles = (n + 63) >> 6;
   hipLaunchKernelGGL(k_predict, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
-                     x, P, Q, dt_vec, dt, n, norm_quats);"""
+                     x, P, Q, dt_vec, dt, n, norm_quats, active);"""
 
 
 def launch_step(kind, do_predict):
   tf = "true" if do_predict else "false"
   if do_predict:
-    args = "x, P, z, R, r_per_filter, ea, Q, dt_vec, dt, n, norm_quats, flags"
+    args = "x, P, z, R, r_per_filter, ea, Q, dt_vec, dt, n, norm_quats, flags, active"
   else:
-    args = "x, P, z, R, r_per_filter, ea, nullptr, nullptr, 0.0, n, norm_quats, flags"
+    args = "x, P, z, R, r_per_filter, ea, nullptr, nullptr, 0.0, n, norm_quats, flags, active"
   return f"""  const int64_t tiles = (n + 63) >> 6;
   hipLaunchKernelGGL(k_step_{kind}<{tf}>, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
                      {args});"""

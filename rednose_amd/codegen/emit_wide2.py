@@ -466,7 +466,7 @@ def kernels(spec):
     dop = "DO_PREDICT" if upd else "true"
     sig_obs = ("double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const double* __restrict__ gea,\n    "
                if upd else "")
-    flags_arg = ", uint8_t* __restrict__ flags" if upd else ""
+    flags_arg = (", uint8_t* __restrict__ flags" if upd else "") + ", const uint8_t* __restrict__ active"
     L = []
     A = L.append
     TLK = tune.wide_timeline
@@ -570,7 +570,9 @@ def kernels(spec):
     TL("4 + 4 * p")
     A("      double* sPc = sPb + sh;")
     A("      const int gg = g < pcnt ? g : 0;")
-    A("      const bool on = act && g < pcnt;")
+    A("      // a masked-out filter (active[i] == 0) is not `on`: every LDS store of the matrix phase is predicated, so its image")
+    A("      // of P goes back to HBM as it came")
+    A(f"      const bool on = act && g < pcnt && (active == nullptr || active[base + {FPW} * p + gg] != 0);")
     A(f"      double* sl = s_sl + ({FPW} * p + gg) * SLOT;")
     A(f"      if (do_pred) mat_predict(sPc + gg * {EE}, qcol, sl, cc, on);")
     TL("5 + 4 * p")
@@ -583,7 +585,7 @@ def kernels(spec):
     A("    }")
     TL(3)
     A("    // ---------------- phase 3: lane l = filter l, inject the error state, write x / y / flags ---------")
-    A("    if (lane < cnt) {")
+    A("    if (lane < cnt && (active == nullptr || active[base + lane] != 0)) {")
     A("      const double* sl = s_sl + lane * SLOT;")
     if upd:
       A(f"      int fl = scal_inject(sl, s_x + lane * {D}, norm_quats);")
@@ -593,6 +595,9 @@ def kernels(spec):
     else:
       A("#pragma unroll")
       A(f"      for (int i = 0; i < {D}; i++) s_x[lane * {D} + i] = sl[{lay.OFF_X} + i];")
+    if upd:
+      A("    } else if (lane < cnt && flags != nullptr) {")
+      A("      flags[base + lane] = 16;       // masked out: x, P and z pass through untouched")
     A("    }")
     A("    rn::wave_lds_sync();")
     A(f"    rn::copy_l2g<FT2 * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);")
@@ -702,15 +707,15 @@ def launch_maha(kind):
 def launch_predict():
   return """  const int64_t tiles = (n + FT2 - 1) / FT2;
   hipLaunchKernelGGL(k_predict, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
-                     x, P, Q, dt_vec, dt, n, norm_quats);"""
+                     x, P, Q, dt_vec, dt, n, norm_quats, active);"""
 
 
 def launch_step(kind, do_predict):
   tf = "true" if do_predict else "false"
   if do_predict:
-    args = "x, P, z, R, r_per_filter, ea, Q, dt_vec, dt, n, norm_quats, flags"
+    args = "x, P, z, R, r_per_filter, ea, Q, dt_vec, dt, n, norm_quats, flags, active"
   else:
-    args = "x, P, z, R, r_per_filter, ea, nullptr, nullptr, 0.0, n, norm_quats, flags"
+    args = "x, P, z, R, r_per_filter, ea, nullptr, nullptr, 0.0, n, norm_quats, flags, active"
   return f"""  const int64_t tiles = (n + FT2 - 1) / FT2;
   hipLaunchKernelGGL(k_step_{kind}<{tf}>, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
                      {args});"""

@@ -73,7 +73,9 @@ def gen_code(folder, name, f_sym, dt_sym, x_sym, obs_eqs, dim_x, dim_err, eskf_p
     if not os.environ.get("RN_ALLOW_SPILLS"):
       if bad and rn_emit.family(spec, ()) == "small":
         usage, bad = fall_back("force_wide", f"lane-per-filter kernels {bad} spill registers: regenerating in the lane-group family")
-      heavy = [k for k in bad if usage[k]["vgpr_spill"] > 8]
+      if "k_rts3" in bad:
+        usage, bad = fall_back("no_rts3", "the smoother in the fused run's layout spills registers: lane-group smoother instead")
+      heavy = [k for k in bad if usage[k]["vgpr_spill"] > 8 and not k.startswith("k_rts")]
       if heavy and rn_tuning.model_defaults(spec):
         # the two-wavefronts-per-SIMD structure chosen for this model size does not fit 256 registers with this model's expressions
         usage, bad = fall_back("no_model_defaults", f"{heavy} spill under the per-model tuning defaults: regenerating with the general structure")
@@ -393,8 +395,14 @@ class BatchedEKF:
   The batch axis does not exist in the reference (its `predict_and_update_batch` applies n observations
   to ONE filter, ekf_sym.py:484-531); this class adds it behind the same vocabulary.  Layout is the
   natural batch of the reference's per-filter buffers: x (N, D), P (N, E, E) row-major fp64, contiguous.
-  All filters share the filter time and the observation kind of a call; z is (N, Z) -- one observation
-  per filter -- and R is one shared (Z, Z) matrix or (N, Z, Z).
+  A call carries ONE observation kind; z is (N, Z) -- one observation per filter -- and R is one shared (Z, Z) matrix or
+  (N, Z, Z).  Two time models:
+    * shared timeline (default): every call advances all filters to one time t;
+    * per-filter timelines (per_filter=True, or the first call that passes a time vector / an `active` mask): every filter
+      keeps its own filter_time, a call advances exactly the filters named by `active` to their own t[i], and -- with
+      rewind_to_keep > 0 -- a late observation rewinds, applies and fast-forwards ONLY the filters it is late for, each
+      through its own ring of checkpoints: N independent instances of the reference's orchestrator
+      (/root/reference/rednose/helpers/ekf_sym.cc:83-156, ekf_sym.py:418-482), fed from N independent logs.
 
   Compute goes through the generated library's `{name}_batch_*` entry points on the current torch HIP
   stream; torch is used only for device memory and streams.  No GPU / no library => KalmanError.
@@ -403,7 +411,7 @@ class BatchedEKF:
 
   def __init__(self, folder, name, Q, x_initial, P_initial, dim_main, dim_main_err,  # pylint: disable=dangerous-default-value
                N=0, dim_augment=0, dim_augment_err=0, maha_test_kinds=[], quaternion_idxs=[], global_vars=None,
-               max_rewind_age=1.0, logger=logging, batch=1, device=None, rewind_to_keep=0):
+               max_rewind_age=1.0, logger=logging, batch=1, device=None, rewind_to_keep=0, per_filter=False):
     import torch  # pylint: disable=import-outside-toplevel
     if not torch.cuda.is_available():
       raise KalmanError("BatchedEKF needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
@@ -421,6 +429,8 @@ class BatchedEKF:
     # (REWIND_TO_KEEP = 512, ekf_sym.h:18) held in HBM.  Off by default -- each checkpoint is a full copy of the
     # batch state (N * (D + E*E) * 8 bytes) -- enable with rewind_to_keep=512 for reference behaviour.
     self.rewind_to_keep = int(rewind_to_keep)
+    self.per_filter = bool(per_filter)
+    self._ring = None                  # per-filter checkpoint rings (allocated by the first per-filter step)
     self.msckf = N > 0
     self.N = N
     self.dim_main, self.dim_augment, self.dim_augment_err = dim_main, dim_augment, dim_augment_err
@@ -493,6 +503,9 @@ class BatchedEKF:
     self.rewind_t = deque(maxlen=keep)
     self.rewind_states = deque(maxlen=keep)
     self.rewind_obscache = deque(maxlen=keep)
+    if getattr(self, "_ring", None) is not None:
+      self._ring["length"].zero_()
+      self._ring["head"].zero_()
 
   def state(self):
     return self.x.cpu().numpy()
@@ -520,7 +533,7 @@ class BatchedEKF:
     if self.filter_time is None:
       self.filter_time = t
     if isinstance(self.filter_time, torch.Tensor):
-      dt = float(t) - self.filter_time
+      dt = torch.nan_to_num(float(t) - self.filter_time, nan=0.0)      # NaN: a filter that has not stepped yet adopts t (dt = 0)
       assert bool((dt >= 0).all()), "observation older than a filter's time"
       return dt
     dt = t - self.filter_time
@@ -534,7 +547,24 @@ class BatchedEKF:
       return self._p(self._keepalive_dt), 0.0
     return None, dt
 
-  def predict(self, t):
+  def predict(self, t, active=None):
+    """Propagate to time t.  Per-filter timelines: t may be (N,) and `active` names the filters to propagate."""
+    if self.per_filter or active is not None or not np.isscalar(t):
+      torch = self._torch
+      N = self.batch
+      self.per_filter = True
+      tt = (torch.full((N,), float(t), dtype=torch.float64, device=self.device) if np.isscalar(t) else self._dev(t, (N,)))
+      act = (torch.ones(N, dtype=torch.bool, device=self.device) if active is None
+             else torch.as_tensor(active, device=self.device).to(torch.bool).expand(N).clone())
+      ft = self.filter_times()
+      dt = torch.where(act, torch.nan_to_num(tt - ft, nan=0.0), torch.zeros_like(tt)).contiguous()
+      assert bool((dt >= 0).all()), "predict: dt < 0 for a filter (ekf_sym.py:459)"
+      au8 = act.to(torch.uint8)
+      self._keepalive_masked = (dt, au8)
+      self._call("batch_predict_masked", self._p(self.x), self._p(self.P), self._p(self.Q), self._p(dt), 0.0, N, self.norm_quats,
+                 self._p(au8), self._stream())
+      self.filter_time = torch.where(act, tt, ft)
+      return
     dt = self._dt(t)
     self.predict_dt(dt)
     self.filter_time = t
@@ -602,13 +632,25 @@ class BatchedEKF:
   def get_augment_times(self):
     return self.augment_times
 
-  def predict_and_update_batch(self, t, kind, z, R, extra_args=None, augment=False, keep_estimate=False):
+  def predict_and_update_batch(self, t, kind, z, R, extra_args=None, augment=False, keep_estimate=False, active=None):
     """One fused predict(t - filter_time) + update(kind) launch over the whole batch.
 
     z: (N, Z) (numpy or device tensor; it is consumed -- the kernel overwrites it with the residual y, as the
     reference's update overwrites in_z, ekf_c.c:120).  keep_estimate=True splits the launch in two and
     returns the reference's 9-tuple (xk_km1, xk_k, Pk_km1, Pk_k, t, kind, y, z, extra_args) of device tensors.
+    t: one time for all filters, or (N,) times; active: (N,) mask of the filters that have an observation in this call
+    (default: all) -- either one switches the orchestrator to per-filter timelines (class docstring): filters that are not
+    active pass through untouched (flag bit 4), late ones are rewound individually (rewind_to_keep > 0) or, when too old
+    for their ring / max_rewind_age, ignored (flag bit 5, the reference's `return None`, ekf_sym.py:464-471).
     """
+    if self.per_filter or active is not None or not np.isscalar(t):
+      if not self.per_filter:
+        if len(self.rewind_t) > 0 and self.rewind_to_keep > 0:
+          raise KalmanError("this orchestrator already holds shared-timeline checkpoints: construct it with per_filter=True "
+                            "(or reset_rewind()) before feeding per-filter times / masks")
+        self.per_filter = True
+      assert not augment, "augment on per-filter timelines is not supported (the reference asserts !augment with its ring, ekf_sym.cc:186)"
+      return self._predict_and_update_per_filter(t, kind, z, R, extra_args, active, keep_estimate)
     if self.rewind_to_keep > 0:
       assert not augment, "augment with the rewind ring is not supported (the reference asserts the same, ekf_sym.cc:186)"
       return self._predict_and_update_with_rewind(t, kind, z, R, extra_args, keep_estimate)
@@ -616,6 +658,176 @@ class BatchedEKF:
     if augment:
       self.augment()
     return ret
+
+  # -- per-filter timelines -------------------------------------------------------------------
+  def filter_times(self):
+    """(N,) device tensor of the filters' times (NaN: not started), whichever time model is in use."""
+    torch = self._torch
+    ft = self.filter_time
+    if isinstance(ft, torch.Tensor):
+      return ft
+    return torch.full((self.batch,), float("nan") if ft is None else float(ft), dtype=torch.float64, device=self.device)
+
+  def _masked_step(self, kind, zin, Rd, per, ea, dt, act_u8, keep_estimate=False):
+    """One launch over the batch that touches only the filters with act_u8 != 0; dt: (N,) device tensor."""
+    dt = dt.contiguous()
+    args_obs = (self._p(zin), self._p(Rd), per, self._p(ea), self.batch, self.norm_quats, self._p(self.flags), self._p(act_u8), self._stream())
+    self._keepalive_masked = (dt, act_u8, zin, Rd, ea)
+    if not keep_estimate:
+      self._call(f"batch_predict_update_{kind}_masked", self._p(self.x), self._p(self.P), self._p(self.Q), self._p(dt), 0.0, *args_obs)
+      return None
+    self._call("batch_predict_masked", self._p(self.x), self._p(self.P), self._p(self.Q), self._p(dt), 0.0, self.batch, self.norm_quats,
+               self._p(act_u8), self._stream())
+    xk_km1, Pk_km1 = self.x.clone(), self.P.clone()
+    self._call(f"batch_update_{kind}_masked", self._p(self.x), self._p(self.P), *args_obs)
+    return xk_km1, Pk_km1
+
+  def _predict_and_update_per_filter(self, t, kind, z, R, extra_args, active, keep_estimate=False):
+    torch = self._torch
+    N = self.batch
+    if kind not in self.zdims:
+      raise KeyError(kind)
+    if not hasattr(self._lib, f"{self.name}_batch_predict_update_{kind}_masked"):
+      raise KalmanError(f"lib{self.name}.so has no masked entry points: regenerate it (gen_code) with this version of rednose_amd")
+    tt = (torch.full((N,), float(t), dtype=torch.float64, device=self.device) if np.isscalar(t) else self._dev(t, (N,)))
+    act = (torch.ones(N, dtype=torch.bool, device=self.device) if active is None
+           else torch.as_tensor(active, device=self.device).to(torch.bool).expand(N).clone())
+    zin, Rd, per = self._obs_args(kind, z, R)
+    if isinstance(z, torch.Tensor) and zin.data_ptr() == z.data_ptr() and keep_estimate:
+      zin = zin.clone()
+    ea = self._ea(kind, extra_args)
+    z_obs = zin.clone() if (self.rewind_to_keep > 0 or keep_estimate) else None       # the kernel overwrites z with the residual
+    ft = self.filter_times()
+    self.filter_time = ft
+    late = act & ~torch.isnan(ft) & (tt < ft)
+    dropped = torch.zeros(N, dtype=torch.bool, device=self.device)
+    replay = None
+    if bool(late.any()):
+      if self.rewind_to_keep <= 0:
+        raise AssertionError("observation older than a filter's time (enable rewind_to_keep to reorder late observations)")
+      dropped, replay = self._ring_rewind(late, tt)
+      if bool(dropped.any()):
+        self.logger.error(f"observation too old for {int(dropped.sum())} filter(s) of the batch, ignoring it for them")
+      act = act & ~dropped
+      ft = self.filter_time
+    dt = torch.where(act, torch.nan_to_num(tt - ft, nan=0.0), torch.zeros_like(tt))
+    est = self._masked_step(kind, zin, Rd, per, ea, dt, act.to(torch.uint8), keep_estimate)
+    self.filter_time = torch.where(act, tt, ft)
+    if self.rewind_to_keep > 0:
+      self._ring_push(act, self.filter_time, kind, z_obs, Rd, per, ea)
+    if replay is not None:
+      self._ring_replay(replay)
+    if bool(dropped.any()):
+      self.flags |= dropped.to(torch.uint8) * 32
+    if keep_estimate:
+      return est[0], self.x.clone(), est[1], self.P.clone(), tt, kind, zin, z_obs, extra_args
+    return zin
+
+  def _ring_alloc(self):
+    torch = self._torch
+    K, N, D, E = self.rewind_to_keep, self.batch, self.dim_x, self.dim_err
+    zmax = max(self.zdims.values())
+    eam = max(list(self.eadims.values()) + [0])
+    f64 = dict(dtype=torch.float64, device=self.device)
+    self._ring = dict(
+      t=torch.full((K, N), float("nan"), **f64), x=torch.empty((K, N, D), **f64), P=torch.empty((K, N, E, E), **f64),
+      kind=torch.zeros((K, N), dtype=torch.int32, device=self.device), z=torch.zeros((K, N, zmax), **f64),
+      R=torch.zeros((K, N, zmax, zmax), **f64), ea=torch.zeros((K, N, max(eam, 1)), **f64),
+      head=torch.zeros(N, dtype=torch.int64, device=self.device), length=torch.zeros(N, dtype=torch.int64, device=self.device))
+
+  def _ring_push(self, mask, times, kind, z_obs, Rd, per, ea):
+    """checkpoint (ekf_sym.py:440-450) of the filters in `mask`: state AFTER the step, its time, and the observation; each filter
+    has its own circular ring of rewind_to_keep entries in HBM."""
+    torch = self._torch
+    if self._ring is None:
+      self._ring_alloc()
+    r, K = self._ring, self.rewind_to_keep
+    idx = torch.nonzero(mask).flatten()
+    if idx.numel() == 0:
+      return
+    full = r["length"][idx] >= K
+    r["head"][idx] = torch.where(full, (r["head"][idx] + 1) % K, r["head"][idx])
+    r["length"][idx] = torch.where(full, r["length"][idx], r["length"][idx] + 1)
+    slot = (r["head"][idx] + r["length"][idx] - 1) % K
+    Z = self.zdims[kind]
+    r["t"][slot, idx] = times[idx]
+    r["x"][slot, idx] = self.x[idx]
+    r["P"][slot, idx] = self.P[idx]
+    r["kind"][slot, idx] = int(kind)
+    r["z"][slot, idx, :Z] = z_obs[idx]
+    r["R"][slot, idx, :Z, :Z] = Rd[idx] if per else Rd
+    if ea is not None:
+      r["ea"][slot, idx, :ea.shape[1]] = ea[idx]
+
+  def _ring_rewind(self, late, tt):
+    """rewind (ekf_sym.py:418-438) of the filters in `late`, each in its own ring: back to its last checkpoint at or before its
+    observation time; -> (mask of filters whose observation is too old and is ignored, what to replay afterwards)."""
+    torch = self._torch
+    if self._ring is None:
+      self._ring_alloc()
+    r, K = self._ring, self.rewind_to_keep
+    idx = torch.nonzero(late).flatten()
+    L, H, ta = r["length"][idx], r["head"][idx], tt[idx]
+    j = torch.arange(K, device=self.device)[:, None]
+    phys = (H[None, :] + j) % K                                  # (K, m): logical position -> slot
+    Tm = r["t"][phys, idx[None, :]]
+    valid = j < L[None, :]
+    newest = Tm.gather(0, (L - 1).clamp(min=0)[None, :])[0]
+    too_old = (L == 0) | (ta < Tm[0]) | (ta < newest - self.max_rewind_age)            # ekf_sym.py:464-471
+    ix = (valid & (Tm <= ta[None, :])).sum(0)                     # bisect_right(times, t)
+    ok = ~too_old
+    dropped = torch.zeros(self.batch, dtype=torch.bool, device=self.device)
+    dropped[idx[too_old]] = True
+    gi, gix, gL, gH = idx[ok], ix[ok], L[ok], H[ok]
+    if gi.numel() == 0:
+      return dropped, None
+    src = (gH + gix - 1) % K
+    self.x[gi] = r["x"][src, gi]
+    self.P[gi] = r["P"][src, gi]
+    ft = self.filter_time.clone()
+    ft[gi] = r["t"][src, gi]
+    self.filter_time = ft
+    nrep = gL - gix
+    maxrep = int(nrep.max())
+    rep = dict(idx=gi, n=nrep, t=[], kind=[], z=[], R=[], ea=[])
+    for q in range(maxrep):                                      # copies: the pushes below reuse these slots
+      p_ = (gH + gix + q) % K
+      for key in ("t", "kind", "z", "R", "ea"):
+        rep[key].append(r[key][p_, gi])
+    r["length"][gi] = gix
+    return dropped, rep
+
+  def _ring_replay(self, rep):
+    """fast-forward (ekf_sym.py:477-479): the overtaken observations of every rewound filter are applied again, oldest first;
+    position q of all rewound filters is one launch per observation kind present at that position."""
+    torch = self._torch
+    N, gi = self.batch, rep["idx"]
+    for q in range(len(rep["t"])):
+      has = rep["n"] > q
+      for kind in torch.unique(rep["kind"][q][has]).tolist():
+        sel = has & (rep["kind"][q] == kind)
+        fi = gi[sel]
+        Z = self.zdims[kind]
+        act = torch.zeros(N, dtype=torch.bool, device=self.device)
+        act[fi] = True
+        tt = self.filter_time.clone()
+        tt[fi] = rep["t"][q][sel]
+        zin = torch.zeros((N, Z), dtype=torch.float64, device=self.device)
+        zin[fi] = rep["z"][q][sel][:, :Z]
+        Rd = torch.zeros((N, Z, Z), dtype=torch.float64, device=self.device)
+        Rd[fi] = rep["R"][q][sel][:, :Z, :Z]
+        EA = self.eadims.get(kind, 0)
+        ea = None
+        if EA:
+          ea = torch.zeros((N, EA), dtype=torch.float64, device=self.device)
+          ea[fi] = rep["ea"][q][sel][:, :EA]
+        z_obs = zin.clone()
+        dt = torch.where(act, tt - self.filter_time, torch.zeros_like(tt))
+        fl = self.flags.clone()
+        self._masked_step(kind, zin, Rd, 1, ea, dt, act.to(torch.uint8))
+        self.flags = torch.where(act, self.flags, fl)              # flags of the filters this replay did not touch stay
+        self.filter_time = torch.where(act, tt, self.filter_time)
+        self._ring_push(act, self.filter_time, kind, z_obs, Rd, 1, ea)
 
   def _predict_and_update_with_rewind(self, t, kind, z, R, extra_args, keep_estimate):
     """Reference semantics of EKFSym::predict_and_update_batch (ekf_sym.cc:83-117) for the whole batch: an

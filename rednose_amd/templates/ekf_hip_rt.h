@@ -511,12 +511,30 @@ __device__ __forceinline__ void normalize_quat(double (&x)[DIM], int idx) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// host side: scratch for the single-filter host-pointer entry points (the reference's scalar ABI)
+// per-filter checkpoint rings (orchestrators with per-filter timelines): `rec` doubles of record i of a flat array (row
+// stride flat_stride) <-> entry slot[i] of filter i in a ring laid out (K, n, ring_stride), for the filters with
+// active[i] != 0 (NULL: all).  One wavefront per filter and grid-stride; a record is contiguous on both sides.  The reference
+// keeps one (x, P, observation) checkpoint list PER FILTER INSTANCE (/root/reference/rednose/helpers/ekf_sym.py:440-450,
+// ekf_sym.cc:142-156); in a batch every filter may be at a different position of its own ring, hence the slot vector.
 // ------------------------------------------------------------------------------------------------
-// The reference's generated functions are re-entrant (stack arrays only, ekf_c.c:11-12,46-50).  Here they stage through ONE
-// device buffer per library, so every host-pointer entry point holds `mu` from the first H2D copy to the last D2H copy:
-// concurrent callers (e.g. two EKF_sym instances of one library on two threads) serialise instead of racing on the
-// buffer contents or on ensure()'s free / realloc.
+__global__ __launch_bounds__(64) void k_ring_copy(double* __restrict__ ring, const int64_t ring_stride, double* __restrict__ flat,
+                                                  const int64_t flat_stride, const int64_t rec, const int32_t* __restrict__ slot,
+                                                  const uint8_t* __restrict__ active, const int64_t n, const int to_ring) {
+  for (int64_t f = blockIdx.x; f < n; f += gridDim.x) {
+    if (active != nullptr && active[f] == 0) continue;
+    double* r = ring + ((int64_t)slot[f] * n + f) * ring_stride;
+    double* a = flat + f * flat_stride;
+    if (to_ring) {
+      for (int64_t i = threadIdx.x; i < rec; i += 64) r[i] = a[i];
+    } else {
+      for (int64_t i = threadIdx.x; i < rec; i += 64) a[i] = r[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side scratch for the single-filter host-pointer entry points
+// ------------------------------------------------------------------------------------------------
 struct Scratch {
   std::mutex mu;
   double* dev = nullptr;

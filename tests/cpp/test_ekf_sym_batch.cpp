@@ -35,6 +35,29 @@ static int run_rewind(const char* dir, const char* stream, int64_t n) {
   return 0;
 }
 
+// Timelines mode: per-filter logs (tests/golden/perfilter_timelines.npz part A: one line per arrival, "t0 z0 t1 z1 ..." for the n
+// filters): every filter on its own clock with its own checkpoint ring.  Prints per arrival and filter: ignored, filter time, x.
+static int run_timelines(const char* dir, const char* stream, int64_t n) {
+  rednose_amd::EKFSymBatch kf(dir, "kinematic", {0.1 * 0.1, 0.0, 0.0, 2.0 * 2.0}, {0.5, 0.0}, {1.0, 0.0, 0.0, 1.0}, n, false, nullptr, 512, 1.0);
+  std::ifstream in(stream);
+  std::vector<double> ts(n), zs(n);
+  double* z_dev = nullptr;
+  if (hipMalloc((void**)&z_dev, sizeof(double) * n) != hipSuccess) return 3;
+  const double R[1] = {0.1 * 0.1};
+  while (true) {
+    for (int64_t i = 0; i < n; i++) in >> ts[i] >> zs[i];
+    if (!in) break;
+    if (hipMemcpy(z_dev, zs.data(), sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) return 3;
+    kf.predict_and_update_batch_per_filter(ts.data(), nullptr, 1, z_dev, R);
+    kf.synchronize();
+    const std::vector<double> x = kf.state();
+    for (int64_t i = 0; i < n; i++)
+      std::printf("%d %.17g %.17g %.17g%s", (int)kf.ignored()[i], kf.filter_times()[i], x[2 * i], x[2 * i + 1], i + 1 < n ? " " : "\n");
+  }
+  (void)hipFree(z_dev);
+  return 0;
+}
+
 // Globals mode: set_global / get_extra_routine on a model generated with global_vars (tests/test_global_vars.py's gv_runtime)
 static int run_globals(const char* dir) {
   rednose_amd::EKFSymBatch kf(dir, "gv_runtime", {0.01, 0.0, 0.0, 4.0}, {0.5, 0.3}, {1.0, 0.0, 0.0, 1.0}, 3);
@@ -59,6 +82,7 @@ int main(int argc, char** argv) {
   try {
     if (argc >= 5 && std::string(argv[4]) == "rewind") return run_rewind(argv[1], argv[2], n);
     if (argc >= 5 && std::string(argv[4]) == "globals") return run_globals(argv[1]);
+    if (argc >= 5 && std::string(argv[4]) == "timelines") return run_timelines(argv[1], argv[2], n);
     rednose_amd::EKFSymBatch kf(argv[1], "kinematic", {0.1 * 0.1, 0.0, 0.0, 2.0 * 2.0}, {0.5, 0.0}, {1.0, 0.0, 0.0, 1.0}, n);
     std::ifstream in(argv[2]);
     std::vector<double> zs(n);

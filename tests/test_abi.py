@@ -54,14 +54,14 @@ def test_generic_header_macros_cover_generated_symbols(gen_dir):
   """Every symbol family documented in rednose_amd_filter.h exists in a generated library, and vice versa."""
   with open(os.path.join(INCLUDE, "rednose_amd_filter.h"), encoding="utf-8") as f:
     text = f.read()
-  documented = set(re.findall(r"RN_FN\(name, (\w+?)(?:##k)?\)", text)) - {"sym", "batch_augment"}   # augment: MSCKF models only
+  documented = {a + b for a, b in re.findall(r"RN_FN\(name, (\w+?)(?:##k(?:##(\w+))?)?\)", text)} - {"sym", "batch_augment"}   # augment: MSCKF models only
   from rednose_amd.helpers import parse_prototypes
   with open(os.path.join(gen_dir, "kinematic6.h"), encoding="utf-8") as f:
     protos = parse_prototypes(f.read())
   generated = set()
   for sym in protos:
     s = sym[len("kinematic6_"):]
-    generated.add(re.sub(r"_\d+$", "_", s) if re.search(r"_\d+$", s) else s)
+    generated.add(re.sub(r"_\d+(_masked)?$", lambda m: "_" + (m.group(1) or ""), s))      # the kind number is part of the symbol
   assert generated == documented, (sorted(generated - documented), sorted(documented - generated))
 
 

@@ -117,3 +117,25 @@ def test_cpp_set_global_and_extra_routine():
   # x0 + dt * gain * x1 with gain = 2.5, dt = 0.1
   assert abs(float(out[1]) - (0.5 + 0.1 * 2.5 * 0.3)) < 1e-14 and abs(float(out[2]) - 0.3) < 1e-15
   assert out[4] == "1" and out[6] == "1"
+
+
+@pytest.mark.gpu
+def test_cpp_orchestrator_per_filter_timelines(tmp_path):
+  """EKFSymBatch::predict_and_update_batch_per_filter: 12 filters, each fed its own out-of-order log of 700 observations (a
+  different swapped pair per filter, the ring of 512 wraps, one observation too old for its filter) -- every filter must follow
+  the reference instance that was fed its log (tests/golden/perfilter_timelines.npz, oracle/make_golden.py)."""
+  from examples import ensure_generated
+  gen = ensure_generated(["kinematic"])
+  g = golden("perfilter_timelines.npz")
+  NA, T = g["A_t"].shape
+  stream = tmp_path / "logs.txt"
+  with open(stream, "w", encoding="utf-8") as f:
+    for j in range(T):
+      f.write(" ".join(f"{float(g['A_t'][i, j])!r} {float(g['A_z'][i, j])!r}" for i in range(NA)) + "\n")
+  out = subprocess.run([_build(), gen, str(stream), str(NA), "timelines"], check=True, capture_output=True, text=True).stdout.strip().split("\n")
+  rows = np.array([[float(v) for v in line.split()] for line in out]).reshape(T, NA, 4)
+  assert np.array_equal(rows[:, :, 0].T != 0, g["A_none"])
+  assert np.abs(rows[:, :, 1].T - g["A_ft"]).max() < 1e-12
+  keep = g["A_keep"]
+  assert np.abs(rows[keep][:, :, 2:4].transpose(1, 0, 2) - g["A_x"]).max() < 1e-9
+  assert np.abs(rows[-1, :, 2:4] - g["A_x_final"]).max() < 1e-9
