@@ -86,9 +86,14 @@ def _scal_text(spec):
 
 
 def _region(b, head, body, pins):
-  """One scheduling region: operand loads of the NEXT piece of work first (`head`), then this piece's arithmetic, then a
-  compiler fence with the freshly written values pinned in front of it (see emit_wide3._rank_pass for why hipcc needs both)."""
+  """One scheduling region: operand loads of the NEXT piece of work first (`head`, held there by a scheduling barrier), then this
+  piece's arithmetic, then a compiler fence with the freshly written values pinned in front of it (see emit_wide3._rank_pass for
+  why hipcc needs both)."""
   b.extend(head)
+  if head:
+    # without this hipcc sinks the requests to the end of the region, right in front of their first use in the next one, and
+    # every region then starts with a full LDS round trip (seen in the ISA of the first build: ds_read x 11, s_waitcnt, FMAs)
+    b.append("      __builtin_amdgcn_sched_barrier(0);")
   b.extend(body)
   if pins:
     b.append("      " + " ".join(f"rn::pin({v});" for v in pins))
@@ -368,32 +373,42 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
   A("      // ---- H. T = Ck D in dot form: entry j of a row of T is that row of Ck against row j of the symmetric D (its packed")
   A("      // triangle is read both ways); each finished column of T is final, only Ck's rows stay live as coefficients ----")
 
-  def drow(j):
-    return [f"      double d{j}[{E}];"] + [f"      d{j}[{kk}] = sD[{sym(j, kk)}];" for kk in range(E)]
-  b.extend(drow(0))
-  for j in range(E):
-    head = drow(j + 1) if j + 1 < E else []
-    body = ["      " + " ".join(f"double h{s}_{j} = 0.0;" for s in S)]
-    for kk in range(E):
-      body.append("      " + " ".join((f"a{s}[{j}] = {'y%d[%d]*d%d[%d]' % (s, kk, j, kk) if kk == 0 else 'fma(y%d[%d], d%d[%d], a%d[%d])' % (s, kk, j, kk, s, j)};" if kk % 2 == 0 else
-                                       f"h{s}_{j} = fma(y{s}[{kk}], d{j}[{kk}], h{s}_{j});") for s in S))
-    body.append("      " + " ".join(f"a{s}[{j}] += h{s}_{j};" for s in S))
-    _region(b, head, body, [f"a{s}[{j}]" for s in S])
+  # Both products in dot form, a region = one output column against HALF a broadcast row: two half rows of operands in flight
+  # (44 registers) next to the coefficient row set (4 R E = 132 for live) fit the 256 architectural registers; with whole rows
+  # hipcc parked the coefficients in AGPRs and read each one back in front of its FMA (two extra instructions per FMA).
+  H2 = (E + 1) // 2
+  halves = [list(range(0, H2)), list(range(H2, E))]
+
+  def product(coef, out, src_index, tmp, opname):
+    pieces = [(j, h) for j in range(E) for h in (0, 1)]
+
+    def loads(pc):
+      j, h = pc
+      return [f"      const double {opname}{j}_{kk} = {src_index(j, kk)};" for kk in halves[h]]
+    b.extend(loads(pieces[0]))
+    for pi, (j, h) in enumerate(pieces):
+      head = loads(pieces[pi + 1]) if pi + 1 < len(pieces) else []
+      body = []
+      if h == 0:
+        body.append("      " + " ".join(f"double {tmp}{s}_{j} = 0.0;" for s in S))
+      for kk in halves[h]:
+        first = (kk == 0)
+        body.append("      " + " ".join(
+          (f"{out}{s}[{j}] = {coef}{s}[{kk}]*{opname}{j}_{kk};" if first else
+           (f"{out}{s}[{j}] = fma({coef}{s}[{kk}], {opname}{j}_{kk}, {out}{s}[{j}]);" if kk % 2 == 0 else
+            f"{tmp}{s}_{j} = fma({coef}{s}[{kk}], {opname}{j}_{kk}, {tmp}{s}_{j});")) for s in S))
+      pins = [f"{out}{s}[{j}]" for s in S]
+      if h == 1:
+        body.append("      " + " ".join(f"{out}{s}[{j}] += {tmp}{s}_{j};" for s in S))
+      else:
+        pins += [f"{tmp}{s}_{j}" for s in S]
+      _region(b, head, body, pins)
+
+  product("y", "a", lambda j, kk: f"sD[{sym(j, kk)}]", "h", "d")
   A("      // ---- I. U = T Ck^T: rows of Ck are broadcast from the image (full layout again: factor and D are dead), dot form ----")
   rows_to_image("y")
   A("      rn::wave_lds_sync();")
-
-  def c_loads(j):
-    return [f"      double c{j}[{E}];", "#pragma unroll", f"      for (int kk = 0; kk < {E}; kk++) c{j}[kk] = sI[{j * E} + kk];"]
-  b.extend(c_loads(0))
-  for j in range(E):
-    head = c_loads(j + 1) if j + 1 < E else []
-    body = ["      " + " ".join(f"double e{s}_{j} = 0.0;" for s in S)]
-    for kk in range(E):
-      body.append("      " + " ".join((f"y{s}[{j}] = {'a%d[%d]*c%d[%d]' % (s, kk, j, kk) if kk == 0 else 'fma(a%d[%d], c%d[%d], y%d[%d])' % (s, kk, j, kk, s, j)};" if kk % 2 == 0 else
-                                       f"e{s}_{j} = fma(a{s}[{kk}], c{j}[{kk}], e{s}_{j});") for s in S))
-    body.append("      " + " ".join(f"y{s}[{j}] += e{s}_{j};" for s in S))
-    _region(b, head, body, [f"y{s}[{j}]" for s in S])
+  product("a", "y", lambda j, kk: f"sI[{'%d' % 0} + {j * E} + {kk}]".replace("0 + ", ""), "e", "c")
   A("      // ---- J. Pk_n = Pk_k + U leaves: U's rows through the image, then one coalesced read-add-write over the tile's records ----")
   rows_to_image("y")
   A("      rn::wave_lds_sync();")

@@ -388,6 +388,7 @@ def run_kernel(spec, norm):
   D, E = spec.dim_x, spec.dim_err
   EE = E * E
   zmax = max(k.zdim for k in spec.kinds)
+  KP = 8 if zmax <= 2 else 4          # observation rows in flight per wavefront (zmax doubles of staging registers per lane each)
   cases = []
   EAM = max([int(sp.Matrix(k.ea_sym).shape[0]) for k in spec.kinds if k.ea_sym is not None] + [0])
   for k in spec.kinds:
@@ -431,14 +432,22 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
     double x[{D}], P[{EE}], z[{zmax}];
     rn::lds_to_regs<{D}>(s_x, lane, x);
     rn::lds_to_regs<{EE}>(s_P, lane, P);
-    for (int64_t t = 0; t < T; t++) {{
+    // Observation prefetch, {KP} steps deep: a step of a small model takes a fraction of a microsecond, less than one HBM round
+    // trip, so with the next step's row alone in flight every step waited for its observation (r3a counters of the 2-state
+    // model: 59 % of the wave cycles in s_waitcnt, 13 % issuing).  ring[j] carries the row of the step t = j (mod {KP}); the
+    // step loop is unrolled {KP} times so that the ring index is a compile-time constant (a runtime index would put the staging
+    // registers into scratch memory).  Loads are issued unconditionally on a clamped row (see TilePrefetch).
+    rn::TilePrefetch<{zmax}> ring[{KP}];
+#pragma unroll
+    for (int u = 1; u < {KP}; u++) ring[u].issue(gz + ((u < T ? u : T - 1) * n + base) * {zmax}, cnt, lane);
+    for (int64_t tb = 0; tb < T; tb += {KP}) {{
+#pragma unroll
+    for (int u = 0; u < {KP}; u++) {{
+      const int64_t t = tb + u;
+      if (t < T) {{
       rn::lds_to_regs<{zmax}>(s_z, lane, z);
       rn::wave_lds_sync();
-      // software prefetch: next step's observations travel while this step computes
-      // (issued unconditionally, the last step re-reads its own row: a predicated issue demotes the staging registers to
-      // scratch memory, 48 bytes per lane that every step then travels through)
-      rn::TilePrefetch<{zmax}> nxt;
-      nxt.issue(gz + ((t + 1 < T ? t + 1 : t) * n + base) * {zmax}, cnt, lane);
+      ring[u].issue(gz + ((t + {KP} < T ? t + {KP} : T - 1) * n + base) * {zmax}, cnt, lane);
       const int kind = kinds[t];
       const double dt = dts[t];
       predict_regs(x, P, s_Q, dt);
@@ -459,8 +468,10 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       if (tP != nullptr) rn::tile_l2g<{EE}>(tP + (t * n + base) * {EE}, cnt, s_P, lane);
       if (flags != nullptr && lane < cnt) flags[t * n + base + lane] = (uint8_t)fl;
       rn::wave_lds_sync();
-      if (t + 1 < T) nxt.commit(s_z, cnt, lane);
+      if (t + 1 < T) ring[(u + 1) % {KP}].commit(s_z, cnt, lane);
       rn::wave_lds_sync();
+      }}
+    }}
     }}
     rn::regs_to_lds<{D}>(s_x, lane, x);
     rn::regs_to_lds<{EE}>(s_P, lane, P);

@@ -137,15 +137,21 @@ def _tables(spec):
   return lay, Fs, Hs
 
 
-def predict_fn(spec):
+def predict_fn(spec, qdiag=False):
   """Matrix part of predict on register rows; F's non-trivial entries are broadcast reads of the filter's slot.
 
   P' = F P F^T + dt Q with ONE transposition through LDS: rows of A = P F^T are row-local; under P = P^T the columns of A are the
   rows of B = F P (B[r][m] = sum_k F[r][k] P[k][m] = sum_k F[r][k] P[m][k] = A[m][r]), and P'[r][:] = B[r][:] F^T + dt Q[r][:] is
   row-local again, so the new rows land in the registers that hold them for the next step.  (P is symmetric up to the rounding
-  of the Joseph form, in the reference as here; the reference multiplies F P F^T out entry by entry, ekf_c.c:8-33.)"""
+  of the Joseph form, in the reference as here; the reference multiplies F P F^T out entry by entry, ekf_c.c:8-33.)
+
+  qdiag=True emits the variant for a DIAGONAL process noise (detected once per launch by k_run): the lane's diagonal entries of Q
+  arrive as register operands and no global memory is read.  That matters beyond the 3 R E loads saved: a load's s_waitcnt
+  vmcnt also waits for every EARLIER store of the wavefront (the counter retires in order), so with the trace enabled the rows
+  of Q fetched here drained the previous step's 32 KB of trace stores on every step -- the only vector load consumed in the
+  middle of a step (profiles/r3a: 11.6 us per step with the trace against 8.7 without)."""
   E = spec.dim_err
-  _, R, _ = layout(spec)
+  GL, R, _ = layout(spec)
   lay, Fs, _ = _tables(spec)
   b = [f"const double dt = sl[{lay.OFF_DT}];"]
   # rows of A, whole rows at a time: 16-byte LDS stores of a lane's contiguous row (entry-wise 8-byte stores at a row stride
@@ -159,25 +165,40 @@ def predict_fn(spec):
     b.append("}")
   b.append("rn::wave_lds_sync();")
   b += _tl(8)
-  # Q is read from HBM / L2 (no LDS left for it): slot s's row of Q is requested one slot ahead of its use
-  b.append(f"double q0[{E}];")
-  b += ["#pragma unroll", f"for (int j = 0; j < {E}; j++) q0[j] = gQ[rc0 * {E} + j];"]
-  for s in range(R):
-    if s + 1 < R:
-      b.append(f"double q{s + 1}[{E}];")
-    b.append("{")
-    b.append(f"  double a[{E}];")
-    b += ["#pragma unroll", f"  for (int m = 0; m < {E}; m++) a[m] = sP[m * {E} + rc{s}];      // column of A = row of B"]
-    if s + 1 < R:
-      b += ["#pragma unroll", f"  for (int j = 0; j < {E}; j++) q{s + 1}[j] = gQ[rc{s + 1} * {E} + j];"]
-    for j in range(E):
-      b.append(f"  row{s}[{j}] = {sum_terms(term(cf, f'a[{m}]') for m, cf in Fs.row_nz(j))} + dt*q{s}[{j}];")
-    b.append("}")
+  if qdiag:
+    for s in range(R):
+      b.append(f"const double dq{s} = dt * qd{s};")
+      b.append("{")
+      b.append(f"  double a[{E}];")
+      b += ["#pragma unroll", f"  for (int m = 0; m < {E}; m++) a[m] = sP[m * {E} + rc{s}];      // column of A = row of B"]
+      for j in range(E):
+        diag = f" + (rc{s} == {j} ? dq{s} : 0.0)" if GL * s <= j < GL * (s + 1) else ""      # the lane's own row index is c + {GL} s
+        b.append(f"  row{s}[{j}] = {sum_terms(term(cf, f'a[{m}]') for m, cf in Fs.row_nz(j))}{diag};")
+      b.append("}")
+  else:
+    # Q is read from HBM / L2 (no LDS left for it): slot s's row of Q is requested one slot ahead of its use
+    b.append(f"double q0[{E}];")
+    b += ["#pragma unroll", f"for (int j = 0; j < {E}; j++) q0[j] = gQ[rc0 * {E} + j];"]
+    for s in range(R):
+      if s + 1 < R:
+        b.append(f"double q{s + 1}[{E}];")
+      b.append("{")
+      b.append(f"  double a[{E}];")
+      b += ["#pragma unroll", f"  for (int m = 0; m < {E}; m++) a[m] = sP[m * {E} + rc{s}];      // column of A = row of B"]
+      if s + 1 < R:
+        b += ["#pragma unroll", f"  for (int j = 0; j < {E}; j++) q{s + 1}[j] = gQ[rc{s + 1} * {E} + j];"]
+      for j in range(E):
+        b.append(f"  row{s}[{j}] = {sum_terms(term(cf, f'a[{m}]') for m, cf in Fs.row_nz(j))} + dt*q{s}[{j}];")
+      b.append("}")
   b.append("rn::wave_lds_sync();      // the image is free again")
   b += _tl(9)
   rows = ", ".join(f"double (&row{s})[{E}]" for s in range(R))
   idx = ", ".join(f"const int rr{s}, const int rc{s}, const bool ok{s}" for s in range(R))
-  head = (f"__device__ __forceinline__ void predict_rows({rows}, double* sP, const double* __restrict__ gQ, const double* sl, {idx}{_tl_arg()}) {{")
+  if qdiag:
+    qarg = ", ".join(f"const double qd{s}" for s in range(R))
+    head = (f"__device__ __forceinline__ void predict_rows_qd({rows}, double* sP, {qarg}, const double* sl, {idx}{_tl_arg()}) {{")
+  else:
+    head = (f"__device__ __forceinline__ void predict_rows({rows}, double* sP, const double* __restrict__ gQ, const double* sl, {idx}{_tl_arg()}) {{")
   return "\n".join([head] + _ind(b) + ["}"])
 
 
@@ -273,7 +294,7 @@ def kernels(spec):
   scal_text, lay = w2.device_functions(spec, lay_cls=RunLayout, sfx="_r")
   out = [f"constexpr int GLR = {GL};    // fused run: lanes per filter", f"constexpr int RPL = {R};    // rows of P per lane",
          f"constexpr int FPWR = {FPW};   // filters per wavefront", f"constexpr int SLOT_R = {lay.SLOT};   // fused run: doubles per scalar slot",
-         "", scal_text, "", predict_fn(spec)]
+         "", scal_text, "", predict_fn(spec), predict_fn(spec, qdiag=True)]
   for k in spec.kinds:
     out.append(update_fn(spec, k))
   out.append(run_kernel(spec))
@@ -359,6 +380,8 @@ def run_kernel(spec):
       }}"""
   # predict(dt = 0) is skipped only for models where it is symbolically the identity (FilterSpec.identity_at_dt0)
   id0_guard = "true" if not spec.identity_at_dt0() else "dt != 0.0"
+  qd_decl = "\n".join(f"  const double qd{s} = gQ[((c + {GL * s}) < {E} ? (c + {GL * s}) : 0) * {E + 1}];" for s in range(R))
+  qd_args = ", ".join(f"qd{s}" for s in range(R))
   decl_rows = "\n".join(f"    double row{s}[{E}];" for s in range(R))
   decl_idx = "\n".join(f"    const int rr{s} = c + {GL * s}; const bool ok{s} = live && rr{s} < {E}; const int rc{s} = rr{s} < {E} ? rr{s} : 0;" for s in range(R))
   load_rows = "\n".join(f"#pragma unroll\n    for (int j = 0; j < {E}; j++) row{s}[j] = sP[rc{s} * {E} + j];" for s in range(R))
@@ -388,6 +411,11 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
   const int g = lane / GLR;
   const int c = lane % GLR;
   {z_decl}
+  // a diagonal process noise (the usual case) lives in registers: see predict_fn(qdiag=True)
+  int qoff = 0;
+  for (int i = lane; i < {EE}; i += 64) qoff |= (i / {E} != i % {E}) && (gQ[i] != 0.0);
+  const bool qdiag = !__any(qoff);
+{qd_decl}
   const int64_t tiles = (n + FPWR - 1) / FPWR;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
     const int64_t base = tile * FPWR;
@@ -419,9 +447,13 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       rn::wave_lds_sync();
       {TL(1)}
       if (do_pred) {{
-        int qz = 0;
-        asm volatile("" : "+v"(qz));                   // Q behind an opaque zero: its addresses are not worth registers across the step loop
-        predict_rows({rows}, sP, gQ + qz, sl, {idx}{_tl_arg(True)});
+        if (qdiag) {{
+          predict_rows_qd({rows}, sP, {qd_args}, sl, {idx}{_tl_arg(True)});
+        }} else {{
+          int qz = 0;
+          asm volatile("" : "+v"(qz));                 // Q behind an opaque zero: its addresses are not worth registers across the step loop
+          predict_rows({rows}, sP, gQ + qz, sl, {idx}{_tl_arg(True)});
+        }}
       }}
       {TL(2)}
       // ---- phase 1b / 2b: update ----

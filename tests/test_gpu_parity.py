@@ -155,7 +155,12 @@ def test_split_predict_then_update_equals_fused(gen_dir, torch_cuda):
   ya = a.predict_and_update_batch(0.01, 1, z.copy(), R)
   est = b.predict_and_update_batch(0.01, 1, z.copy(), R, keep_estimate=True)
   torch.cuda.synchronize()
-  assert torch.equal(a.x, b.x) and torch.equal(a.P, b.P) and torch.equal(ya, est[6])
+  # the fused launch and the predict / update pair run the same generated device functions, but hipcc contracts multiplies and
+  # adds into FMAs per KERNEL (-ffp-contract=fast), so the two may differ in the last bits (they were bit-identical until the
+  # masked entry points changed the step kernel's control flow in round 3)
+  assert_close(a.x.cpu().numpy(), b.x.cpu().numpy(), rtol=1e-13, floor=1e-14, what="fused vs split x")
+  assert_close(a.P.cpu().numpy().reshape(n, -1), b.P.cpu().numpy().reshape(n, -1), rtol=1e-13, floor=1e-14, what="fused vs split P")
+  assert_close(ya.cpu().numpy(), est[6].cpu().numpy(), rtol=1e-13, atol=1e-14, what="fused vs split y")
   assert len(est) == 9 and torch.equal(est[1], b.x) and not torch.equal(est[0], est[1])
 
 
