@@ -29,7 +29,9 @@ SMALL_MAX_E = 7    # lane-per-filter register budget: x, P and the update's temp
 #   rts_one_wave       the smoother spilled under the two-wavefronts-per-SIMD budget -> full register file
 #   no_rts             the smoother still touches scratch -> library without batch_rts (forward filter unaffected)
 #   no_rts3            the smoother in the fused run's layout (emit_rts3) spilled -> rn::k_rts_group
-FALLBACKS = ("force_wide", "no_model_defaults", "no_rts3", "rts_one_wave", "no_rts")
+#   no_run             the fused multi-step run of a model above 32 error states touches scratch -> library without batch_run
+#                      (status ERR_UNSUPPORTED, the step-granular entry points cover such models)
+FALLBACKS = ("force_wide", "no_model_defaults", "no_rts3", "rts_one_wave", "no_rts", "no_run")
 _active = frozenset()      # fallbacks of the emit() call in progress
 
 
@@ -102,7 +104,7 @@ def _emit(spec):
   fam = family(spec)
   if E > 64:
     raise NotImplementedError(f"{E} error states: the lane-group kernels hold one row of P per lane of a wavefront (<= 64)")
-  has_run = E <= 32        # fused multi-step run: rows of P stay in VGPRs (emit_wide3); above 32 error states it spills (feature36: 120 VGPRs)
+  has_run = "no_run" not in _active     # fused multi-step run: rows of P stay in VGPRs (emit_wide3: several rows per lane up to 32 error states, one above)
   import types
   from rednose_amd.codegen import tuning
   if fam == "wide":
@@ -174,7 +176,7 @@ def _emit(spec):
   # models, MSCKF ones included (their main block is smoothed, ekf_sym.py:675-686): rn::k_rts_group.
   group_rts = fam == "wide"
   from rednose_amd.codegen import emit_rts3
-  use_rts3 = (group_rts and has_run and emit_rts3.applicable(spec) and tuning.current().rts3 and "no_rts3" not in _active and "no_rts" not in _active)
+  use_rts3 = (group_rts and E <= 32 and emit_rts3.applicable(spec) and tuning.current().rts3 and "no_rts3" not in _active and "no_rts" not in _active)
   if use_rts3:
     src.append(emit_rts3.kernel(spec))
   has_rts = (group_rts or (fam == "small" and spec.dim_main == spec.dim_x and spec.dim_main_err == spec.dim_err)) and "no_rts" not in _active
@@ -360,7 +362,7 @@ int {name}_batch_predict_update_{k.kind}{sfx}(double *x, double *P, const double
   RN_REQUIRE(n >= 0 && T >= 0 && x && P && Q && kinds && dts && z && R, rn::ERR_ARG);
   if (n == 0 || T == 0) return rn::OK;
   RN_REQUIRE(rn::aligned16(x) && rn::aligned16(P) && rn::aligned16(z) && rn::aligned16(trace_x) && rn::aligned16(trace_P), rn::ERR_ALIGN);
-{fam_mod.launch_run() if has_run else '  (void)norm_quats; (void)flags; (void)stream; (void)ea; (void)augment; return rn::fail(rn::ERR_UNSUPPORTED, 0, "batch_run: not generated above 32 error states", __LINE__);'}
+{fam_mod.launch_run() if has_run else '  (void)norm_quats; (void)flags; (void)stream; (void)ea; (void)augment; return rn::fail(rn::ERR_UNSUPPORTED, 0, "batch_run: not generated for this model (its fused run did not fit the register file)", __LINE__);'}
   {'RN_HIP(hipGetLastError());' if has_run else ''}
   return rn::OK;
 }}""")

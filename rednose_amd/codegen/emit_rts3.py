@@ -178,6 +178,7 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
   A("      const bool first = (k == T - 2);")
   A("      int lb = lane;")
   A('      asm volatile("" : "+v"(lb));         // opaque copy of the lane index: the copies\' index arithmetic stays inside the step')
+  A("      RN_RTS_STAMP(0);")
   A("      // ---- A. filtered pair of step k: Pk_k -> image in one coalesced burst, xk_k -> LDS ----")
   if aligned and IMG == EE:
     A(f"      rn::async_copy_g2l<{FPW} * {EE}>(Pf + (k * n + base) * {EE}, cnt * {EE}, s_I, lb);      // no register staging: lands under the scalar phase")
@@ -189,9 +190,17 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
   else:
     A(f"      for (int i = lb; i < cnt * {EE}; i += 64) s_I[(i / {EE}) * RTS3_IMG + i % {EE}] = Pf[(k * n + base) * {EE} + i];      // (odd record size)")
     pre_wait = None
-  A(f"      for (int i = lb; i < cnt * {D}; i += 64) s_xk[i] = xf[(k * n + base) * {D} + i];")
+  XT = -(-(FPW * D) // 64)
+  A("      {")
+  A(f"        double xv_[{XT}];")
+  A("#pragma unroll")
+  A(f"        for (int it = 0; it < {XT}; it++) {{ const int i = lb + 64 * it; xv_[it] = xf[(k * n + base) * {D} + (i < cnt * {D} ? i : 0)]; }}")
+  A("#pragma unroll")
+  A(f"        for (int it = 0; it < {XT}; it++) {{ const int i = lb + 64 * it; if (i < cnt * {D}) s_xk[i] = xv_[it]; }}")
+  A("      }")
   A("      const double dt = ts[k + 1] - ts[k];")
   A("      rn::wave_lds_sync();")
+  A("      RN_RTS_STAMP(1);")
   A("      // ---- B. f(xk_k) [renormalised like the forward pass], non-zeros of Fk: once per filter -> slot ----")
   A("      if (lead) scal_predict_s(sxk, dt, sl, norm_quats & 1);")
   if pre_wait:
@@ -203,6 +212,7 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
     A("#pragma unroll")
     A(f"      for (int j = 0; j < {E}; j++) a{s}[j] = sI[rc{s} * {E} + j];")
   A("      rn::wave_lds_sync();      // every lane has its rows: the image takes A")
+  A("      RN_RTS_STAMP(2);")
   A("      // ---- C. rows of A = Pk_k Fk^T (row-local, F's structural zeros cost nothing): the right-hand sides, and through the")
   A("      // image the columns of A = rows of Fk Pk_k (P = P^T up to rounding, as in the fused run's predict) ----")
   for s in S:
@@ -226,6 +236,7 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
     A("        }")
   A("      }")
   A("      rn::wave_lds_sync();      // the image is free: rows of Pk1_k are in a*")
+  A("      RN_RTS_STAMP(3);")
   A("      // ---- D. recursion start / difference matrix.  The smoothed covariance of step k + 1 is NOT carried in registers: the")
   A("      // previous step left it in Ps[k + 1] (through the L2), its rows are read back here, the lower triangle of")
   A("      // D = Pk1_n - Pk1_k goes straight to LDS and the lower triangle of Pk1_k beside it. ----")
@@ -260,18 +271,26 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
   A('        asm volatile("" : "+v"(lo));')
   A(f"        for (int i = lo; i < cnt * {D}; i += 64) xs[((k + 1) * n + base) * {D} + i] = s_xn[i];      // smoothed state of step k + 1 (after its renormalisation)")
   A("      }")
+  A('      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the previous step\'s output stores have reached the L2')
   for s in S:
     A("      {")
-    A(f"        const double* pn_ = Ps + (((k + 1) * n + base + gg) * {EE} + rc{s} * {E});")
     A(f"        double pn[{E}];")
-    A("#pragma unroll")
-    A(f"        for (int j = 0; j < {E}; j++) pn[j] = __hip_atomic_load(pn_ + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // served by the L2 (another lane of this wavefront stored it)")
+    if E % 2 == 0:
+      A("        typedef double rts3_v2d __attribute__((ext_vector_type(2)));")
+      A(f"        const rts3_v2d* pn_ = reinterpret_cast<const rts3_v2d*>(Ps + (((k + 1) * n + base + gg) * {EE} + rc{s} * {E}));")
+      A("#pragma unroll")
+      A(f"        for (int j = 0; j < {E // 2}; j++) {{ const rts3_v2d v_ = __builtin_nontemporal_load(pn_ + j); pn[2 * j] = v_.x; pn[2 * j + 1] = v_.y; }}      // L2-served (not this CU's L1: another lane stored these rows)")
+    else:
+      A(f"        const double* pn_ = Ps + (((k + 1) * n + base + gg) * {EE} + rc{s} * {E});")
+      A("#pragma unroll")
+      A(f"        for (int j = 0; j < {E}; j++) pn[j] = __builtin_nontemporal_load(pn_ + j);      // L2-served (not this CU's L1: another lane stored these rows)")
     A("#pragma unroll")
     A(f"        for (int j = 0; j < {E}; j++) {{")
     A(f"          if (ok{s} && j <= rr{s}) {{ sD[tb{s} + j] = pn[j] - a{s}[j]; sL[tb{s} + j] = a{s}[j]; }}")
     A("        }")
     A("      }")
   A("      rn::wave_lds_sync();")
+  A("      RN_RTS_STAMP(4);")
   A("      // ---- E. Cholesky of Pk1_k, left-looking.  Rows in a*, finished rows of the factor in LDS (packed): the pivot row is")
   A("      // broadcast and every lane forms its entries AND the pivot redundantly (no publish / wait per column).  Column j + 1's")
   A("      // sums over the columns before j depend on nothing column j produces: they are emitted inside column j's region, so they")
@@ -309,6 +328,7 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
     if j + 1 < E:
       pins += [f"t{s}_{j + 1}" for s in S] + [f"u{s}_{j + 1}" for s in S] + [f"pv_{j + 1}", f"pw_{j + 1}"]
     _region(b, [], body, pins)
+  A("      RN_RTS_STAMP(5);")
   A("      // ---- F. Ck^T = Pk1_k^-1 M, i.e. every row slot solves with its own right-hand side (row of A).  Forward substitution in")
   A("      // dot form (row i of the factor against the solved part), backward in axpy form (row m of the factor scaled into the")
   A("      // unsolved part): both read ROWS of the packed factor, and in both the next row is requested before the current one is")
@@ -338,6 +358,7 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
       body.append("      " + " ".join(f"y{s}[{i}] = fma(-g{m}[{i}], y{s}[{m}], y{s}[{i}]);" for s in S))
     _region(b, head, body, [f"y{s}[{i}]" for s in S for i in range(m + 1)])
   A("      // y* = rows of Ck")
+  A("      RN_RTS_STAMP(6);")
   A("      // ---- G. state: delta = Ck inv_err(xk1_k, xk1_n); xk_n = err(xk_k, delta) ----")
   A("      if (lead) {")
   A(f"        double xb[{D}], xn1[{D}], delta[{E}];")
@@ -370,6 +391,7 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
   A("#pragma unroll")
   A(f"        for (int i = 0; i < {D}; i++) sxn[i] = xnew[i];       // xk_n: becomes xk1_n of the next (older) step")
   A("      }")
+  A("      RN_RTS_STAMP(7);")
   A("      // ---- H. T = Ck D in dot form: entry j of a row of T is that row of Ck against row j of the symmetric D (its packed")
   A("      // triangle is read both ways); each finished column of T is final, only Ck's rows stay live as coefficients ----")
 
@@ -405,20 +427,54 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
       _region(b, head, body, pins)
 
   product("y", "a", lambda j, kk: f"sD[{sym(j, kk)}]", "h", "d")
+  A("      RN_RTS_STAMP(8);")
   A("      // ---- I. U = T Ck^T: rows of Ck are broadcast from the image (full layout again: factor and D are dead), dot form ----")
   rows_to_image("y")
   A("      rn::wave_lds_sync();")
-  product("a", "y", lambda j, kk: f"sI[{'%d' % 0} + {j * E} + {kk}]".replace("0 + ", ""), "e", "c")
+  product("a", "y", lambda j, kk: f"sI[{j * E + kk}]", "e", "c")
+  A("      RN_RTS_STAMP(9);")
   A("      // ---- J. Pk_n = Pk_k + U leaves: U's rows through the image, then one coalesced read-add-write over the tile's records ----")
   rows_to_image("y")
   A("      rn::wave_lds_sync();")
   A("      {")
   A("        int le = lane;")
   A('        asm volatile("" : "+v"(le));')
-  A(f"        for (int i = le; i < cnt * {EE}; i += 64) Ps[(k * n + base) * {EE} + i] = Pf[(k * n + base) * {EE} + i] + s_I[(i / {EE}) * RTS3_IMG + i % {EE}];")
+  # every load of the tile's records is issued before the first is used (a rolled loop of load -> add -> store pays one
+  # memory round trip per iteration: 61 of them per step in the first build, half of the kernel's time in s_waitcnt)
+  if EE % 2 == 0:
+    IT = -(-(FPW * EE // 2) // 64)
+    A("        typedef double rts3_d2 __attribute__((ext_vector_type(2)));")
+    A(f"        const rts3_d2* __restrict__ in2 = reinterpret_cast<const rts3_d2*>(Pf + (k * n + base) * {EE});")
+    A(f"        rts3_d2* __restrict__ out2 = reinterpret_cast<rts3_d2*>(Ps + (k * n + base) * {EE});")
+    A(f"        const int nv = cnt * {EE // 2};")
+    A(f"        rts3_d2 v[{IT}];")
+    A("#pragma unroll")
+    A(f"        for (int it = 0; it < {IT}; it++) {{ const int idx = le + 64 * it; v[it] = in2[idx < nv ? idx : nv - 1]; }}")
+    A("#pragma unroll")
+    A(f"        for (int it = 0; it < {IT}; it++) {{")
+    A("          const int idx = le + 64 * it;")
+    A("          if (idx < nv) {")
+    A(f"            const int f_ = idx / {EE // 2}, r_ = idx - f_ * {EE // 2};")
+    A("            const rts3_d2 u_ = *reinterpret_cast<const rts3_d2*>(s_I + f_ * RTS3_IMG + 2 * r_);")
+    A("            out2[idx] = v[it] + u_;")
+    A("          }")
+    A("        }")
+  else:
+    IT = -(-(FPW * EE) // 64)
+    A(f"        const double* __restrict__ in1 = Pf + (k * n + base) * {EE};")
+    A(f"        double* __restrict__ out1 = Ps + (k * n + base) * {EE};")
+    A(f"        const int nv = cnt * {EE};")
+    A(f"        double v[{IT}];")
+    A("#pragma unroll")
+    A(f"        for (int it = 0; it < {IT}; it++) {{ const int idx = le + 64 * it; v[it] = in1[idx < nv ? idx : nv - 1]; }}")
+    A("#pragma unroll")
+    A(f"        for (int it = 0; it < {IT}; it++) {{")
+    A("          const int idx = le + 64 * it;")
+    A(f"          if (idx < nv) out1[idx] = v[it] + s_I[(idx / {EE}) * RTS3_IMG + idx % {EE}];")
+    A("        }")
   A("      }")
-  A('      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next (older) step reads these rows back through the L2')
   A("      rn::wave_lds_sync();")
+  A("      RN_RTS_STAMP(10);")
   A("    }")
   A("    // ---- the oldest smoothed state goes out un-normalised (ekf_sym.py:665-667 never reaches it); its covariance left above ----")
   A(f"    for (int i = lane; i < cnt * {D}; i += 64) xs[base * {D} + i] = s_xn[i];")

@@ -50,9 +50,10 @@ def ea_max(spec):
 
 def layout(spec):
   """-> (GL lanes per filter, R rows per lane, FPW filters per wavefront).  8 lanes while 8 covariance images fit the LDS
-  budget of a wavefront (E <= 22), 16 above."""
+  budget of a wavefront (E <= 22), 16 up to 32 error states; above that the row sets of several rows per lane no longer fit the
+  register file (feature36 at 16 lanes x 3 rows: 120 spilled registers) and a filter takes the whole wavefront, a row per lane."""
   E = spec.dim_err
-  GL = 8 if E <= 22 else 16
+  GL = 8 if E <= 22 else (16 if E <= 32 else 64)       # above 32 error states: one filter per wavefront, one row per lane
   return GL, -(-E // GL), 64 // GL
 
 

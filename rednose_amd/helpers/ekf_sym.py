@@ -75,7 +75,9 @@ def gen_code(folder, name, f_sym, dt_sym, x_sym, obs_eqs, dim_x, dim_err, eskf_p
         usage, bad = fall_back("force_wide", f"lane-per-filter kernels {bad} spill registers: regenerating in the lane-group family")
       if "k_rts3" in bad:
         usage, bad = fall_back("no_rts3", "the smoother in the fused run's layout spills registers: lane-group smoother instead")
-      heavy = [k for k in bad if usage[k]["vgpr_spill"] > 8 and not k.startswith("k_rts")]
+      if "k_run" in bad and usage["k_run"]["scratch"] > 0 and spec.dim_err > 32:
+        usage, bad = fall_back("no_run", "the fused run touches scratch memory: library without batch_run (step-granular entry points only)")
+      heavy = [k for k in bad if usage[k]["vgpr_spill"] > 8 and not k.startswith(("k_rts", "k_run"))]
       if heavy and rn_tuning.model_defaults(spec):
         # the two-wavefronts-per-SIMD structure chosen for this model size does not fit 256 registers with this model's expressions
         usage, bad = fall_back("no_model_defaults", f"{heavy} spill under the per-model tuning defaults: regenerating with the general structure")

@@ -450,7 +450,7 @@ __device__ __forceinline__ void rts_products(double* Bf, double* Cf, const doubl
 // 100 MHz wall clock at the phase boundaries of the backward step k == T / 2 of its first tile (tools/timeline.py).
 #ifdef RN_RTS_TL
 __device__ unsigned long long g_rts_tl[256 * 16];
-#define RN_RTS_STAMP(i) do { if (lane == 0 && blockIdx.x < 256 && tile == blockIdx.x && k == T / 2) g_rts_tl[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#define RN_RTS_STAMP(i) do { if (lane == 0 && blockIdx.x < 256 && tile == blockIdx.x && k == T / 2) rn::g_rts_tl[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define RN_RTS_STAMP(i) do { } while (0)
 #endif

@@ -184,7 +184,7 @@ def test_fused_run_with_landmarks_and_window_shifts(env):
   """The whole MSCKF stream of the reference's numpy path -- POSITION fixes followed by a window shift, FEATURE tracks with their
   per-observation landmark -- in ONE {name}_batch_run launch: extra arguments per filter and step, augment flags in the
   schedule.  Filtered trace (the estimate before each shift, like the reference's Estimate), final state after the last shift,
-  projected residual norms.  Above 32 error states the library has no fused run: status 4."""
+  projected residual norms.  Both layouts of the fused run: several rows per lane (15 states), one filter per wavefront (36)."""
   torch, gen, FK = env
   from rednose_amd.helpers import KalmanError
   g = _gold(env)
@@ -195,10 +195,8 @@ def test_fused_run_with_landmarks_and_window_shifts(env):
   zs = np.tile(g["zs"][:, None, :], (1, n, 1))
   eas = np.tile(g["eas"][:, None, :], (1, n, 1))
   Rs = {1: FK.obs_noise[1], 2: FK.obs_noise[2]}
-  if FK.dim_state > 32:
-    with pytest.raises(KalmanError):
-      f.run(ts, kinds, zs.copy(), Rs, extra_args=eas, augment=g["augment"])
-    return
+  # (round 3: above 32 error states the fused run gives a filter the whole wavefront, one row of P per lane -- feature36 runs
+  # through batch_run like the 15-state model)
   ys, tx, tP, fl = f.run(ts, kinds, zs.copy(), Rs, trace=True, flags=True, extra_args=eas, augment=g["augment"])
   torch.cuda.synchronize()
   X, P, Y = tx.cpu().numpy(), tP.cpu().numpy(), ys.cpu().numpy()
@@ -223,8 +221,8 @@ def test_fused_run_with_landmarks_and_window_shifts(env):
 
 
 def test_kalmanfilter_stream_with_landmarks_and_window_shifts(env):
-  """KalmanFilter.predict_and_observe_stream with extra_args / augment: the fused run where the library has one (feature), one
-  call per step where it has not (feature36, status 4 -> fallback); both against the reference's numpy stream."""
+  """KalmanFilter.predict_and_observe_stream with extra_args / augment through the fused run, against the reference's numpy
+  stream (the per-step fallback for libraries without batch_run is covered by tests/test_gpu_random.py: 56 states)."""
   torch, gen, FK = env
   from rednose_amd.helpers.kalmanfilter import KalmanFilter
   g = _gold(env)
@@ -240,8 +238,7 @@ def test_kalmanfilter_stream_with_landmarks_and_window_shifts(env):
   eas = np.tile(g["eas"][:, None, :], (1, n, 1))
   res = kf.predict_and_observe_stream(ts, kinds, zs.copy(), extra_args=eas, augment=g["augment"])
   torch.cuda.synchronize()
-  fused = FK.dim_state <= 32
-  assert isinstance(res, list) != fused
+  assert not isinstance(res, list), "both models have a fused run since round 3"
   for j in (0, n - 1):
     assert_close(kf.x[j], g["x_after"][-1], rtol=1e-8, floor=1e-10, what="stream API, state after the last window shift")
     assert_close(kf.P[j].reshape(1, -1), g["P_after"][-1].reshape(1, -1), rtol=1e-7, floor=1e-9)

@@ -103,7 +103,11 @@ def rts():
   rel = a[:, :10] - a[:, :1]
   names = ["step start", "x landed", "scalars (f, F) done", "predict done (B = Pk1_k)", "difference / output issued", "Cholesky done",
            "solves done", "state update done", "T = Ck Dm done", "Pk_n done (step end)"]
-  print("--- smoother, one backward step (us after the step's start; 2 wavefronts per SIMD)")
+  if "rts3=0" not in os.environ.get("RN_TUNE", ""):      # k_rts3 (emit_rts3.py): eleven stamps
+    rel = a[:, :11] - a[:, :1]
+    names = ["step start", "Pk copy + x issued", "scalars done, Pk landed", "predict done (rows of Pk1_k)", "Pk1_n read back, D / Pk1_k in LDS",
+             "Cholesky done", "solves done", "state update done", "T = Ck D done", "U = T Ck^T done", "Pk_n stored (step end)"]
+  print("--- smoother, one backward step (us after the step's start)")
   prev = 0.0
   for i, nm in enumerate(names):
     m = rel[:, i].mean()
