@@ -86,15 +86,15 @@ def fp64_valu_instructions(lib, kernel="k_run"):
     os.unlink(fb)
   except Exception:      # pylint: disable=broad-except
     return None
-  count, inside = 0, False
+  counts, cur = {}, None
   for line in dis.split("\n"):
     m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
     if m:
-      inside = kernel in m.group(1)
+      cur = m.group(1) if kernel in m.group(1) else None      # (lane-per-filter kernels exist per tile size: k_run<64>, k_run<32>)
       continue
-    if inside and re.search(r"\bv_\w+_f64", line):
-      count += 1
-  return count or None
+    if cur is not None and re.search(r"\bv_\w+_f64", line):
+      counts[cur] = counts.get(cur, 0) + 1
+  return max(counts.values()) if counts else None
 
 
 def cpu_baseline(name, kind, K6, batch, budget_s=5.0, suffix="", cflags=None):

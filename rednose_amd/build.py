@@ -79,7 +79,14 @@ def kernel_resources(remarks):
       if mm:
         ident = mm.group(2)[:int(mm.group(1))]
         rest = mm.group(2)[int(mm.group(1)):]
-        cur = ident + ("<true>" if rest.startswith("ILb1E") else "<false>" if rest.startswith("ILb0E") else "")
+        # template arguments: <bool DO_PREDICT>, <int TF> (filters per tile of the lane-per-filter kernels), or both
+        mt = re.match(r"I(?:Lb([01])E)?(?:Li(\d+)E)?E", rest)
+        targs = []
+        if mt and mt.group(1) is not None:
+          targs.append("true" if mt.group(1) == "1" else "false")
+        if mt and mt.group(2) is not None:
+          targs.append(mt.group(2))
+        cur = ident + (f"<{','.join(targs)}>" if targs else "")
       out[cur] = dict(vgprs=0, agprs=0, scratch=0, lds=0, vgpr_spill=0, occupancy=0)
       continue
     if cur is None:

@@ -174,6 +174,10 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
   A(f"      if (xs != xf) {{ for (int i = lane; i < cnt * {D}; i += 64) xs[base * {D} + i] = xf[base * {D} + i]; }}")
   A("      continue;")
   A("    }")
+  XT = -(-(FPW * D) // 64)
+  A(f"    double xnext[{XT}];      // filtered state of the next step to process, in flight across the loop's back edge")
+  A("#pragma unroll")
+  A(f"    for (int it = 0; it < {XT}; it++) {{ const int i = lane + 64 * it; xnext[it] = xf[((T - 2) * n + base) * {D} + (i < cnt * {D} ? i : 0)]; }}")
   A("    for (int64_t k = T - 2; k >= 0; k--) {")
   A("      const bool first = (k == T - 2);")
   A("      int lb = lane;")
@@ -190,13 +194,9 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
   else:
     A(f"      for (int i = lb; i < cnt * {EE}; i += 64) s_I[(i / {EE}) * RTS3_IMG + i % {EE}] = Pf[(k * n + base) * {EE} + i];      // (odd record size)")
     pre_wait = None
-  XT = -(-(FPW * D) // 64)
-  A("      {")
-  A(f"        double xv_[{XT}];")
+  A("      {      // xk_k was requested at the end of the previous (newer) step (before the loop for the first): its round trip is off the path")
   A("#pragma unroll")
-  A(f"        for (int it = 0; it < {XT}; it++) {{ const int i = lb + 64 * it; xv_[it] = xf[(k * n + base) * {D} + (i < cnt * {D} ? i : 0)]; }}")
-  A("#pragma unroll")
-  A(f"        for (int it = 0; it < {XT}; it++) {{ const int i = lb + 64 * it; if (i < cnt * {D}) s_xk[i] = xv_[it]; }}")
+  A(f"        for (int it = 0; it < {XT}; it++) {{ const int i = lb + 64 * it; if (i < cnt * {D}) s_xk[i] = xnext[it]; }}")
   A("      }")
   A("      const double dt = ts[k + 1] - ts[k];")
   A("      rn::wave_lds_sync();")
@@ -436,6 +436,10 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
   A("      // ---- J. Pk_n = Pk_k + U leaves: U's rows through the image, then one coalesced read-add-write over the tile's records ----")
   rows_to_image("y")
   A("      rn::wave_lds_sync();")
+  A("      if (k > 0) {")
+  A("#pragma unroll")
+  A(f"        for (int it = 0; it < {XT}; it++) {{ const int i = lane + 64 * it; xnext[it] = xf[((k - 1) * n + base) * {D} + (i < cnt * {D} ? i : 0)]; }}")
+  A("      }")
   A("      {")
   A("        int le = lane;")
   A('        asm volatile("" : "+v"(le));')
