@@ -312,6 +312,8 @@ def fused_run_extra(torch, model, n, T, dev):
   moved = 8.0 * (2 * Z) * n * T + 8.0 * 2 * (D + E * E) * n
   rate = n * T / (best * 1e-3)
   insts = fp64_valu_instructions(os.path.join(gen, f"lib{M.name}.so"))
+  if insts:         # the kernel's loop body holds run_unroll steps (its observation prefetch ring is that deep)
+    insts = insts / max(1, getattr(f._lib, f"{M.name}_run_unroll")())      # pylint: disable=protected-access
   roof = {"bound": "fp64-valu", "achieved": None, "peak": FP64_VALU_LANE_OPS / 1e12, "unit": "T fp64 lane-instructions/s", "frac": None,
           "fp64_valu_instructions_per_filter_step": insts, "hbm_GBs": moved / (best * 1e-3) / 1e9, "hbm_frac": moved / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
           "kernel": "k_run", "traffic": measured_traffic(f"{model}_fused_b{n}", M.name, gen)}

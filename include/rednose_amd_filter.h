@@ -83,6 +83,7 @@ extern "C" {
 /* fused multi-step run and offline smoothing (SURVEY.md 8b "proposed new batched exports") */
 #define RN_DECLARE_BATCH_RUN(name)                                                                               \
   int RN_FN(name, zmax)(void);                        /* largest Z over the kinds: row stride of z in batch_run  */  \
+  int RN_FN(name, run_unroll)(void);                  /* steps per iteration of batch_run's loop (instruction accounting) */ \
   /* T predict+update steps in ONE launch, x and P resident on chip between steps.  kinds (T) int32, dts (T),   \
    * R (T, zmax*zmax; the leading Z*Z entries of row t are that step's row-major R) and z (T, n, zmax; in: z,   \
    * out: y) are DEVICE arrays; the schedule is shared by all filters.  flags (T, n), trace_x (T, n, D) and      \

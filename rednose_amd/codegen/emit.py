@@ -358,6 +358,9 @@ int {name}_batch_predict_update_{k.kind}{sfx}(double *x, double *P, const double
   zmax = max(k.zdim for k in spec.kinds)
   abi.append(f"int {name}_zmax(void) {{ return {zmax}; }}")
   hdr.append(f"int {name}_zmax(void);")
+  unroll = emit_small.run_unroll(spec) if fam == "small" else 1
+  abi.append(f"int {name}_run_unroll(void) {{ return {unroll}; }}")
+  hdr.append(f"int {name}_run_unroll(void);")
   abi.append(f"""int {name}_batch_run(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts, int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, double *trace_x, double *trace_P, const double *ea, const int32_t *augment, void *stream) {{
   RN_REQUIRE(n >= 0 && T >= 0 && x && P && Q && kinds && dts && z && R, rn::ERR_ARG);
   if (n == 0 || T == 0) return rn::OK;

@@ -271,40 +271,38 @@ def kernels(spec):
 
   out.append(f"""
 // ---- predict only: one launch propagates n filters by dt -------------------------------------------
-template <int TF>
 __global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double* __restrict__ gP,
     const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
     const int norm_quats, const uint8_t* __restrict__ active) {{
-  __shared__ __attribute__((aligned(16))) double s_x[TF * {D | 1}];
-  __shared__ __attribute__((aligned(16))) double s_P[TF * {EE | 1}];
+  __shared__ __attribute__((aligned(16))) double s_x[64 * {D | 1}];
+  __shared__ __attribute__((aligned(16))) double s_P[64 * {EE | 1}];
   __shared__ __attribute__((aligned(16))) double s_Q[{EE}];
   const int lane = threadIdx.x;
-  const int ll = lane < TF ? lane : TF - 1;      // half tiles (TF = 32): lanes 32 .. 63 shadow the last filter and store nothing
   for (int i = lane; i < {EE}; i += 64) s_Q[i] = gQ[i];       // Q as LDS broadcast operands (36 SGPR pairs spilled otherwise)
-  const int64_t tiles = (n + TF - 1) / TF;
+  const int64_t tiles = (n + 63) >> 6;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
-    const int64_t base = tile * TF;
-    const int cnt = (n - base) < TF ? (int)(n - base) : TF;
-    rn::tile_g2l_async<{D}, TF>(gx + base * {D}, cnt, s_x, lane);
-    rn::tile_g2l_async<{EE}, TF>(gP + base * {EE}, cnt, s_P, lane);
+    const int64_t base = tile << 6;
+    const int cnt = (n - base) < 64 ? (int)(n - base) : 64;
+    rn::tile_g2l_async<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_g2l_async<{EE}>(gP + base * {EE}, cnt, s_P, lane);
     const double dt = (gdt != nullptr && lane < cnt) ? gdt[base + lane] : dt_scalar;
     rn::async_wait();
     rn::wave_lds_sync();
     double x[{D}], P[{EE}];
-    rn::lds_to_regs<{D}>(s_x, ll, x);
-    rn::lds_to_regs<{EE}>(s_P, ll, P);
+    rn::lds_to_regs<{D}>(s_x, lane, x);
+    rn::lds_to_regs<{EE}>(s_P, lane, P);
     predict_regs(x, P, s_Q, dt);
     {norm}
     rn::wave_lds_sync();
     // a masked-out filter (active[i] == 0: no observation for it in this call) keeps the record it came with: its lane
     // does not overwrite the LDS image, so the coalesced write-back returns the loaded bytes
-    if (lane < TF && (active == nullptr || (lane < cnt && active[base + lane] != 0))) {{
+    if (active == nullptr || (lane < cnt && active[base + lane] != 0)) {{
       rn::regs_to_lds<{D}>(s_x, lane, x);
       rn::regs_to_lds<{EE}>(s_P, lane, P);
     }}
     rn::wave_lds_sync();
-    rn::tile_l2g<{D}, TF>(gx + base * {D}, cnt, s_x, lane);
-    rn::tile_l2g<{EE}, TF>(gP + base * {EE}, cnt, s_P, lane);
+    rn::tile_l2g<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_l2g<{EE}>(gP + base * {EE}, cnt, s_P, lane);
     rn::wave_lds_sync();
   }}
 }}
@@ -316,39 +314,38 @@ __global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double*
     ea = f", gea + (base + (lane < cnt ? lane : 0)) * {int(sp.Matrix(k.ea_sym).shape[0])}" if k.ea_sym is not None else ""
     out.append(f"""
 // ---- kind {k.kind}: [predict +] update, state round-trips HBM once per launch --------------------------
-template <bool DO_PREDICT, int TF>
+template <bool DO_PREDICT>
 __global__ __launch_bounds__(64){kattr} void k_step_{k.kind}(double* __restrict__ gx, double* __restrict__ gP,
     double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const double* __restrict__ gea,
     const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
     const int norm_quats, uint8_t* __restrict__ flags, const uint8_t* __restrict__ active) {{
-  __shared__ __attribute__((aligned(16))) double s_x[TF * {D | 1}];
-  __shared__ __attribute__((aligned(16))) double s_P[TF * {EE | 1}];
-  __shared__ __attribute__((aligned(16))) double s_z[TF * {Z | 1}];
-  __shared__ __attribute__((aligned(16))) double s_R[TF * {ZZ | 1}];
+  __shared__ __attribute__((aligned(16))) double s_x[64 * {D | 1}];
+  __shared__ __attribute__((aligned(16))) double s_P[64 * {EE | 1}];
+  __shared__ __attribute__((aligned(16))) double s_z[64 * {Z | 1}];
+  __shared__ __attribute__((aligned(16))) double s_R[64 * {ZZ | 1}];
   __shared__ __attribute__((aligned(16))) double s_Q[{EE}];
   const int lane = threadIdx.x;
-  const int ll = lane < TF ? lane : TF - 1;      // half tiles (TF = 32): lanes 32 .. 63 shadow the last filter and store nothing
   if (DO_PREDICT) {{
     for (int i = lane; i < {EE}; i += 64) s_Q[i] = gQ[i];
   }}
-  const int64_t tiles = (n + TF - 1) / TF;
+  const int64_t tiles = (n + 63) >> 6;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
-    const int64_t base = tile * TF;
-    const int cnt = (n - base) < TF ? (int)(n - base) : TF;
-    rn::tile_g2l_async<{D}, TF>(gx + base * {D}, cnt, s_x, lane);
-    rn::tile_g2l_async<{EE}, TF>(gP + base * {EE}, cnt, s_P, lane);
-    rn::tile_g2l_async<{Z}, TF>(gz + base * {Z}, cnt, s_z, lane);
-    if (r_per_filter) rn::tile_g2l_async<{ZZ}, TF>(gR + base * {ZZ}, cnt, s_R, lane);
+    const int64_t base = tile << 6;
+    const int cnt = (n - base) < 64 ? (int)(n - base) : 64;
+    rn::tile_g2l_async<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_g2l_async<{EE}>(gP + base * {EE}, cnt, s_P, lane);
+    rn::tile_g2l_async<{Z}>(gz + base * {Z}, cnt, s_z, lane);
+    if (r_per_filter) rn::tile_g2l_async<{ZZ}>(gR + base * {ZZ}, cnt, s_R, lane);
     double dt = dt_scalar;
     if (DO_PREDICT && gdt != nullptr && lane < cnt) dt = gdt[base + lane];
     rn::async_wait();
     rn::wave_lds_sync();
     double x[{D}], P[{EE}], z[{Z}], R[{ZZ}];
-    rn::lds_to_regs<{D}>(s_x, ll, x);
-    rn::lds_to_regs<{EE}>(s_P, ll, P);
-    rn::lds_to_regs<{Z}>(s_z, ll, z);
+    rn::lds_to_regs<{D}>(s_x, lane, x);
+    rn::lds_to_regs<{EE}>(s_P, lane, P);
+    rn::lds_to_regs<{Z}>(s_z, lane, z);
     if (r_per_filter) {{
-      rn::lds_to_regs<{ZZ}>(s_R, ll, R);
+      rn::lds_to_regs<{ZZ}>(s_R, lane, R);
     }} else {{
 #pragma unroll
       for (int i = 0; i < {ZZ}; i++) R[i] = gR[i];
@@ -361,16 +358,16 @@ __global__ __launch_bounds__(64){kattr} void k_step_{k.kind}(double* __restrict_
     {norm}
     rn::wave_lds_sync();
     // masked-out filters (active[i] == 0) pass through untouched: x, P and z leave as they came, flag bit 4 is set
-    const bool on = lane < TF && (active == nullptr || (lane < cnt && active[base + lane] != 0));
+    const bool on = active == nullptr || (lane < cnt && active[base + lane] != 0);
     if (on) {{
       rn::regs_to_lds<{D}>(s_x, lane, x);
       rn::regs_to_lds<{EE}>(s_P, lane, P);
       rn::regs_to_lds<{Z}>(s_z, lane, z);
     }}
     rn::wave_lds_sync();
-    rn::tile_l2g<{D}, TF>(gx + base * {D}, cnt, s_x, lane);
-    rn::tile_l2g<{EE}, TF>(gP + base * {EE}, cnt, s_P, lane);
-    rn::tile_l2g<{Z}, TF>(gz + base * {Z}, cnt, s_z, lane);
+    rn::tile_l2g<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_l2g<{EE}>(gP + base * {EE}, cnt, s_P, lane);
+    rn::tile_l2g<{Z}>(gz + base * {Z}, cnt, s_z, lane);
     if (flags != nullptr && lane < cnt) {{
       double acc = 0.0;
 #pragma unroll
@@ -386,12 +383,18 @@ __global__ __launch_bounds__(64){kattr} void k_step_{k.kind}(double* __restrict_
   return "\n".join(out)
 
 
+def run_unroll(spec):
+  """Steps of the schedule per iteration of the fused run's loop (= depth of its observation prefetch ring)."""
+  zmax = max(k.zdim for k in spec.kinds)
+  return 8 if zmax <= 2 else 4          # observation rows in flight per wavefront (zmax doubles of staging registers per lane each)
+
+
 def run_kernel(spec, norm):
   """T steps per launch: x and P stay in VGPRs, only z (in) / y (out) and the optional trace touch HBM."""
   D, E = spec.dim_x, spec.dim_err
   EE = E * E
   zmax = max(k.zdim for k in spec.kinds)
-  KP = 8 if zmax <= 2 else 4          # observation rows in flight per wavefront (zmax doubles of staging registers per lane each)
+  KP = run_unroll(spec)
   cases = []
   EAM = max([int(sp.Matrix(k.ea_sym).shape[0]) for k in spec.kinds if k.ea_sym is not None] + [0])
   for k in spec.kinds:
@@ -413,36 +416,34 @@ def run_kernel(spec, norm):
         }}""")
   return f"""
 // ---- fused multi-step run: kinds[t], dts[t] shared by all filters; z is (T, n, {zmax}) in: z, out: y -----------
-template <int TF>
 __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __restrict__ gP, const double* __restrict__ gQ,
     const int32_t* __restrict__ kinds, const double* __restrict__ dts, const int64_t T, double* __restrict__ gz,
     const double* __restrict__ gR, const int64_t n, const int norm_quats, uint8_t* __restrict__ flags,
     double* __restrict__ tx, double* __restrict__ tP, const double* __restrict__ gea, const int32_t* __restrict__ augs) {{
   (void)gea; (void)augs;      // lane-per-filter models are never MSCKF models (those use the lane-group family): no window shift here
-  __shared__ __attribute__((aligned(16))) double s_x[TF * {D | 1}];
-  __shared__ __attribute__((aligned(16))) double s_P[TF * {EE | 1}];
-  __shared__ __attribute__((aligned(16))) double s_z[TF * {zmax | 1}];
+  __shared__ __attribute__((aligned(16))) double s_x[64 * {D | 1}];
+  __shared__ __attribute__((aligned(16))) double s_P[64 * {EE | 1}];
+  __shared__ __attribute__((aligned(16))) double s_z[64 * {zmax | 1}];
   __shared__ __attribute__((aligned(16))) double s_Q[{EE}];
   const int lane = threadIdx.x;
-  const int ll = lane < TF ? lane : TF - 1;      // half tiles (TF = 32): lanes 32 .. 63 shadow the last filter and store nothing
   for (int i = lane; i < {EE}; i += 64) s_Q[i] = gQ[i];
-  const int64_t tiles = (n + TF - 1) / TF;
+  const int64_t tiles = (n + 63) >> 6;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
-    const int64_t base = tile * TF;
-    const int cnt = (n - base) < TF ? (int)(n - base) : TF;
-    rn::tile_g2l<{D}, TF>(gx + base * {D}, cnt, s_x, lane);
-    rn::tile_g2l<{EE}, TF>(gP + base * {EE}, cnt, s_P, lane);
-    rn::tile_g2l<{zmax}, TF>(gz + base * {zmax}, cnt, s_z, lane);
+    const int64_t base = tile << 6;
+    const int cnt = (n - base) < 64 ? (int)(n - base) : 64;
+    rn::tile_g2l<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_g2l<{EE}>(gP + base * {EE}, cnt, s_P, lane);
+    rn::tile_g2l<{zmax}>(gz + base * {zmax}, cnt, s_z, lane);
     rn::wave_lds_sync();
     double x[{D}], P[{EE}], z[{zmax}];
-    rn::lds_to_regs<{D}>(s_x, ll, x);
-    rn::lds_to_regs<{EE}>(s_P, ll, P);
+    rn::lds_to_regs<{D}>(s_x, lane, x);
+    rn::lds_to_regs<{EE}>(s_P, lane, P);
     // Observation prefetch, {KP} steps deep: a step of a small model takes a fraction of a microsecond, less than one HBM round
     // trip, so with the next step's row alone in flight every step waited for its observation (r3a counters of the 2-state
     // model: 59 % of the wave cycles in s_waitcnt, 13 % issuing).  ring[j] carries the row of the step t = j (mod {KP}); the
     // step loop is unrolled {KP} times so that the ring index is a compile-time constant (a runtime index would put the staging
     // registers into scratch memory).  Loads are issued unconditionally on a clamped row (see TilePrefetch).
-    rn::TilePrefetch<{zmax}, TF> ring[{KP}];
+    rn::TilePrefetch<{zmax}> ring[{KP}];
 #pragma unroll
     for (int u = 1; u < {KP}; u++) ring[u].issue(gz + ((u < T ? u : T - 1) * n + base) * {zmax}, cnt, lane);
     for (int64_t tb = 0; tb < T; tb += {KP}) {{
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
     for (int u = 0; u < {KP}; u++) {{
       const int64_t t = tb + u;
       if (t < T) {{
-      rn::lds_to_regs<{zmax}>(s_z, ll, z);
+      rn::lds_to_regs<{zmax}>(s_z, lane, z);
       rn::wave_lds_sync();
       ring[u].issue(gz + ((t + {KP} < T ? t + {KP} : T - 1) * n + base) * {zmax}, cnt, lane);
       const int kind = kinds[t];
@@ -464,15 +465,13 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       }}
       {norm}
       // y(t) and the optional trace go out through LDS as coalesced 16-byte stores
-      if (lane < TF) {{
-        rn::regs_to_lds<{zmax}>(s_z, lane, z);
-        if (tx != nullptr) rn::regs_to_lds<{D}>(s_x, lane, x);
-        if (tP != nullptr) rn::regs_to_lds<{EE}>(s_P, lane, P);
-      }}
+      rn::regs_to_lds<{zmax}>(s_z, lane, z);
+      if (tx != nullptr) rn::regs_to_lds<{D}>(s_x, lane, x);
+      if (tP != nullptr) rn::regs_to_lds<{EE}>(s_P, lane, P);
       rn::wave_lds_sync();
-      rn::tile_l2g<{zmax}, TF>(gz + (t * n + base) * {zmax}, cnt, s_z, lane);
-      if (tx != nullptr) rn::tile_l2g<{D}, TF>(tx + (t * n + base) * {D}, cnt, s_x, lane);
-      if (tP != nullptr) rn::tile_l2g<{EE}, TF>(tP + (t * n + base) * {EE}, cnt, s_P, lane);
+      rn::tile_l2g<{zmax}>(gz + (t * n + base) * {zmax}, cnt, s_z, lane);
+      if (tx != nullptr) rn::tile_l2g<{D}>(tx + (t * n + base) * {D}, cnt, s_x, lane);
+      if (tP != nullptr) rn::tile_l2g<{EE}>(tP + (t * n + base) * {EE}, cnt, s_P, lane);
       if (flags != nullptr && lane < cnt) flags[t * n + base + lane] = (uint8_t)fl;
       rn::wave_lds_sync();
       if (t + 1 < T) ring[(u + 1) % {KP}].commit(s_z, cnt, lane);
@@ -480,37 +479,27 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       }}
     }}
     }}
-    if (lane < TF) {{
-      rn::regs_to_lds<{D}>(s_x, lane, x);
-      rn::regs_to_lds<{EE}>(s_P, lane, P);
-    }}
+    rn::regs_to_lds<{D}>(s_x, lane, x);
+    rn::regs_to_lds<{EE}>(s_P, lane, P);
     rn::wave_lds_sync();
-    rn::tile_l2g<{D}, TF>(gx + base * {D}, cnt, s_x, lane);
-    rn::tile_l2g<{EE}, TF>(gP + base * {EE}, cnt, s_P, lane);
+    rn::tile_l2g<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_l2g<{EE}>(gP + base * {EE}, cnt, s_P, lane);
     rn::wave_lds_sync();
   }}
 }}
 """
 
 
-def _tf_dispatch(kernel_tmpl, args, probe):
-  """Launch text choosing 64- or 32-filter tiles (rn::tile_filters: half tiles when the batch leaves fewer than two wavefronts
-  per SIMD and the kernel's footprint lets wavefronts share one)."""
-  k64, k32 = kernel_tmpl.format(tf=64), kernel_tmpl.format(tf=32)
-  return f"""  static const int occ_ = rn::blocks_per_cu({probe.format(tf=32)});
-  if (rn::tile_filters(n, occ_) == 32) {{
-    hipLaunchKernelGGL(({k32}), dim3(rn::grid_for_tiles((n + 31) / 32)), dim3(64), 0, (hipStream_t)stream, {args});
-  }} else {{
-    hipLaunchKernelGGL(({k64}), dim3(rn::grid_for_tiles((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, {args});
-  }}"""
-
-
 def launch_run():
-  return _tf_dispatch("k_run<{tf}>", "x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P, ea, augment", "k_run<{tf}>")
+  return """  const int64_t tiles = (n + 63) >> 6;
+  hipLaunchKernelGGL(k_run, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P, ea, augment);"""
 
 
 def launch_predict():
-  return _tf_dispatch("k_predict<{tf}>", "x, P, Q, dt_vec, dt, n, norm_quats, active", "k_predict<{tf}>")
+  return """  const int64_t tiles = (n + 63) >> 6;
+  hipLaunchKernelGGL(k_predict, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     x, P, Q, dt_vec, dt, n, norm_quats, active);"""
 
 
 def launch_step(kind, do_predict):
@@ -519,4 +508,6 @@ def launch_step(kind, do_predict):
     args = "x, P, z, R, r_per_filter, ea, Q, dt_vec, dt, n, norm_quats, flags, active"
   else:
     args = "x, P, z, R, r_per_filter, ea, nullptr, nullptr, 0.0, n, norm_quats, flags, active"
-  return _tf_dispatch(f"k_step_{kind}<{tf}, {{tf}}>", args, f"k_step_{kind}<{tf}, {{tf}}>")
+  return f"""  const int64_t tiles = (n + 63) >> 6;
+  hipLaunchKernelGGL(k_step_{kind}<{tf}>, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     {args});"""

@@ -303,6 +303,7 @@ def kernels(spec):
 
 
 def run_kernel(spec):
+  from rednose_amd.codegen import tuning
   D, E = spec.dim_x, spec.dim_err
   EE = E * E
   GL, R, FPW = layout(spec)
@@ -381,13 +382,13 @@ def run_kernel(spec):
       }}"""
   # predict(dt = 0) is skipped only for models where it is symbolically the identity (FilterSpec.identity_at_dt0)
   id0_guard = "true" if not spec.identity_at_dt0() else "dt != 0.0"
+  nt_trace = "true" if tuning.current().nt_trace else "false"
   qd_decl = "\n".join(f"  const double qd{s} = gQ[((c + {GL * s}) < {E} ? (c + {GL * s}) : 0) * {E + 1}];" for s in range(R))
   qd_args = ", ".join(f"qd{s}" for s in range(R))
   decl_rows = "\n".join(f"    double row{s}[{E}];" for s in range(R))
   decl_idx = "\n".join(f"    const int rr{s} = c + {GL * s}; const bool ok{s} = live && rr{s} < {E}; const int rc{s} = rr{s} < {E} ? rr{s} : 0;" for s in range(R))
   load_rows = "\n".join(f"#pragma unroll\n    for (int j = 0; j < {E}; j++) row{s}[j] = sP[rc{s} * {E} + j];" for s in range(R))
   nlc = chr(10)
-  from rednose_amd.codegen import tuning
 
   def TL(ph):      # debug stamps (tuning knob wide_timeline; tools/timeline.py run): the last three steps, twenty stamps each
     if not tuning.current().wide_timeline:
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       if (tP != nullptr) {{
 {img}
         rn::wave_lds_sync();
-        rn::copy_l2g<FPWR * {EE}>(tP + (t * n + base) * {EE}, cnt * {EE}, s_P, lz);
+        rn::copy_l2g<FPWR * {EE}, {nt_trace}>(tP + (t * n + base) * {EE}, cnt * {EE}, s_P, lz);
       }}
       rn::wave_lds_sync();
       {TL(6)}

@@ -13,6 +13,7 @@ variants do not overwrite generated/).  What each alternative measured: profiles
   wide_lean_q  1 = the lean predict takes its column of Q from registers instead of an LDS copy
   small_waves  amdgpu_waves_per_eu on the lane-per-filter step kernels
   small_max_e  largest error-state count served lane-per-filter
+  nt_trace     1 = nontemporal stores for the fused run's covariance trace (lane-group models)
   rts3         1 = smoother of lane-group models in the fused run's layout (emit_rts3: 8 filters per wavefront), 0 = rn::k_rts_group
 """
 import os
@@ -31,6 +32,7 @@ class Tuning:
   small_waves: int = 0
   small_max_e: int = 7
   rts3: int = 1
+  nt_trace: int = 0          # 1 = the fused run's covariance trace leaves with nontemporal stores
   wide_timeline: int = 0     # debug: lane 0 of the first 256 workgroups stamps s_memtime / the 100 MHz wall clock at every phase boundary of
                              # the three-phase step kernels into a device buffer read back by {name}_debug_timeline (tools/timeline.py)
 

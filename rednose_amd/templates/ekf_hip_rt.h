@@ -17,7 +17,6 @@
 #include <utility>
 #include <stdint.h>
 #include <stdio.h>
-#include <stdlib.h>
 #include <string.h>
 
 namespace rn {
@@ -75,28 +74,6 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // one step are still in the SAME XCD's L2 when the next launch reads them.
 constexpr int MAX_GRID = 256 * 16;   // 16 single-wave workgroups per CU, then grid-stride
 
-// Filters per wavefront tile of the lane-per-filter kernels for a launch over n filters: 64, or 32 when 64-filter tiles would
-// leave fewer than two wavefronts per SIMD and the kernel's registers / LDS let two or more share one (`blocks_per_cu` from
-// hipOccupancyMaxActiveBlocksPerMultiprocessor, cached by the caller).  RN_TILE=64 / 32 forces either (A/B measurements).
-inline int tile_filters(int64_t n, int blocks_per_cu) {
-  static const int forced = [] { const char* e = getenv("RN_TILE"); return e ? atoi(e) : 0; }();
-  static const int64_t simds = [] {
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return (int64_t)4 * cus;
-  }();
-  if (forced == 64 || forced == 32) return forced;
-  return (((n + 63) >> 6) < 2 * simds && blocks_per_cu >= 8) ? 32 : 64;
-}
-
-template <class K>
-inline int blocks_per_cu(K kernel) {
-  int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 64, 0) != hipSuccess) nb = 0;
-  return nb;
-}
-
 inline int grid_for_tiles(int64_t tiles) {
   int64_t g = tiles < MAX_GRID ? tiles : MAX_GRID;
   if (g >= 8) g -= g % 8;
@@ -130,17 +107,13 @@ __device__ __forceinline__ void pin(double& v) { asm volatile("" : "+v"(v)); }
 template <int EPF>
 __device__ __forceinline__ constexpr int lds_stride() { return RN_LDS_PAD ? (EPF | 1) : EPF; }
 
-// Copy one tile (cnt <= TF filters x EPF doubles, contiguous in HBM) into this wave's LDS image.
+// Copy one tile (cnt <= 64 filters x EPF doubles, contiguous in HBM) into this wave's LDS image.
 // Full tiles move as 16-byte vectors, lane l taking vectors l, l+64, ... (1 KiB per wave-instruction).
-// TF = filters per tile: 64 (a lane per filter, every lane busy) or 32 -- half tiles, lanes 32..63 idle, for batches so small
-// that 64-filter tiles leave one wavefront per SIMD (65 536 filters = 1 024 tiles on 1 024 SIMDs): two half-empty wavefronts per
-// SIMD overlap each other's load -> compute -> store latency, which a lone full wavefront cannot.
-template <int EPF, int TF = WAVE>
+template <int EPF>
 __device__ __forceinline__ void tile_g2l(const double* __restrict__ g, int cnt, double* lds, int lane) {
-  static_assert(TF % 2 == 0, "tiles hold an even number of filters");
-  constexpr int NV = (TF / 2) * EPF;                // double2 vectors in a full tile
+  constexpr int NV = 32 * EPF;                      // double2 vectors in a full tile
   constexpr int STR = lds_stride<EPF>();
-  if (cnt == TF) {
+  if (cnt == WAVE) {
     const double2* __restrict__ g2 = reinterpret_cast<const double2*>(g);
     double2 v[(NV + WAVE - 1) / WAVE];
 #pragma unroll
@@ -171,11 +144,11 @@ __device__ __forceinline__ void tile_g2l(const double* __restrict__ g, int cnt, 
   }
 }
 
-template <int EPF, int TF = WAVE>
+template <int EPF>
 __device__ __forceinline__ void tile_l2g(double* __restrict__ g, int cnt, const double* lds, int lane) {
-  constexpr int NV = (TF / 2) * EPF;
+  constexpr int NV = 32 * EPF;
   constexpr int STR = lds_stride<EPF>();
-  if (cnt == TF) {
+  if (cnt == WAVE) {
     double2* __restrict__ g2 = reinterpret_cast<double2*>(g);
 #pragma unroll
     for (int i = 0; i < (NV + WAVE - 1) / WAVE; i++) {
@@ -207,22 +180,21 @@ __device__ __forceinline__ void tile_l2g(double* __restrict__ g, int cnt, const 
 // loads on purpose: with a 16-byte path for full tiles next to an 8-byte path for ragged ones the staging arrays were
 // assigned under different conditions, hipcc kept the struct in scratch memory, and every step of the fused run then went
 // through 48 bytes of scratch per lane (a scratch access costs a wavefront that is alone on its SIMD about a microsecond).
-template <int EPF, int TF = WAVE>
+template <int EPF>
 struct TilePrefetch {
   static constexpr int STR = RN_LDS_PAD ? (EPF | 1) : EPF;
-  static constexpr int NS = (TF * EPF + WAVE - 1) / WAVE;      // doubles per lane
-  double s[NS];
+  double s[EPF];
   __device__ __forceinline__ void issue(const double* __restrict__ g, int cnt, int lane) {
     const int last = cnt * EPF - 1;
 #pragma unroll
-    for (int i = 0; i < NS; i++) {
+    for (int i = 0; i < EPF; i++) {
       const int idx = lane + i * WAVE;
       s[i] = g[idx <= last ? idx : last];
     }
   }
   __device__ __forceinline__ void commit(double* lds, int cnt, int lane) const {
 #pragma unroll
-    for (int i = 0; i < NS; i++) {
+    for (int i = 0; i < EPF; i++) {
       const int e = lane + i * WAVE;
       if (e < cnt * EPF) {
         const int f = e / EPF, k = e - f * EPF;
@@ -258,16 +230,22 @@ __device__ __forceinline__ void copy_g2l(const double* __restrict__ g, int nd, d
   if ((nd & 1) && lane == 0) lds[nd - 1] = g[nd - 1];
 }
 
-template <int MAXD>
+// NT = true: nontemporal stores, for data that is written once and read much later (the filtered trace of a fused run: tens of
+// gigabytes between its write and the smoother's read) -- it should not displace the working set from the L2.
+template <int MAXD, bool NT = false>
 __device__ __forceinline__ void copy_l2g(double* __restrict__ g, int nd, const double* lds, int lane) {
+  typedef double v2d_ __attribute__((ext_vector_type(2)));
   constexpr int IT = (MAXD / 2 + WAVE - 1) / WAVE;
   const int nv = nd >> 1;
-  double2* __restrict__ g2 = reinterpret_cast<double2*>(g);
-  const double2* l2 = reinterpret_cast<const double2*>(lds);
+  v2d_* __restrict__ g2 = reinterpret_cast<v2d_*>(g);
+  const v2d_* l2 = reinterpret_cast<const v2d_*>(lds);
 #pragma unroll
   for (int i = 0; i < IT; i++) {
     const int idx = lane + i * WAVE;
-    if (idx < nv) g2[idx] = l2[idx];
+    if (idx < nv) {
+      if constexpr (NT) __builtin_nontemporal_store(l2[idx], g2 + idx);
+      else g2[idx] = l2[idx];
+    }
   }
   if ((nd & 1) && lane == 0) g[nd - 1] = lds[nd - 1];
 }
@@ -324,13 +302,13 @@ __device__ __forceinline__ void async_wait() {
 
 // tile_g2l with direct HBM -> LDS transfers for full tiles (no VGPR staging, no ds_write); the caller must
 // async_wait() before the wave_lds_sync() that precedes the first read of the image.
-template <int EPF, int TF = WAVE>
+template <int EPF>
 __device__ __forceinline__ void tile_g2l_async(const double* __restrict__ g, int cnt, double* lds, int lane) {
 #if RN_LDS_PAD
-  tile_g2l<EPF, TF>(g, cnt, lds, lane);
+  tile_g2l<EPF>(g, cnt, lds, lane);
 #else
-  constexpr int NV = (TF / 2) * EPF;
-  if (cnt == TF) {
+  constexpr int NV = 32 * EPF;
+  if (cnt == WAVE) {
 #pragma unroll
     for (int i = 0; i < (NV + WAVE - 1) / WAVE; i++) {
       const int idx = lane + i * WAVE;
@@ -339,7 +317,7 @@ __device__ __forceinline__ void tile_g2l_async(const double* __restrict__ g, int
       }
     }
   } else {
-    tile_g2l<EPF, TF>(g, cnt, lds, lane);
+    tile_g2l<EPF>(g, cnt, lds, lane);
   }
 #endif
 }

@@ -337,7 +337,8 @@ def test_config4_resynchronised_backward_steps():
   100 steps keep the filtered trace, the GPU smooths it; then every backward step k is recomputed on the host from the GPU's
   OWN smoothed estimate of step k + 1 and the filtered pair of step k (numpy restatement of ekf_sym.py:651-690 over the
   oracle's f / F / err / inv_err), so no error is carried from step to step.  What is left is the conditioning of the one
-  solve per step: the bound is 1e-10 of the row maximum or 20 cond(Pk1_k) eps, whichever is larger."""
+  solve per step and the asymmetry of the inputs (the fused forward run and the smoother use P = P^T where the reference's dense
+  products do not): the bound is the largest of 1e-10 of the row maximum, 20 cond(Pk1_k) eps and 50 x the relative asymmetry."""
   torch, L, f, o, rng, x0, hacc = _setup("live_maha", 256, 77)
   n, Tw = 256, 100
   kinds, ts = _schedule(T_FULL)
@@ -362,8 +363,11 @@ def test_config4_resynchronised_backward_steps():
       P1k = Fk @ P[k, j] @ Fk.T + dt * L.Q
       if k == Tw - 2:      # recursion start: the newest smoothed estimate is the predicted pair (normalised in place, :665-667)
         assert_close(Xs[Tw - 1, j], x1k, rtol=1e-12, floor=1e-13, what="newest smoothed state")
-        # (entries of P span 1e-6 ... 1e2 and F P F^T mixes rows: the scale of the rounding error is the largest entry of the matrix)
-        assert np.abs(Pss[Tw - 1, j] - P1k).max() <= 1e-11 * np.abs(P1k).max(), "newest smoothed covariance"
+        # (entries of P span 1e-6 ... 1e2 and F P F^T mixes rows: the scale of the rounding error is the largest entry of the matrix;
+        # the forward run's covariances are symmetric only up to ~1e-9 -- it uses P = P^T in its predict, DESIGN.md section 3 -- and
+        # the smoother's predict takes P^T where numpy takes P, so the asymmetry of the input is part of the bound)
+        asym0 = np.abs(P1k - P1k.T).max()
+        assert np.abs(Pss[Tw - 1, j] - P1k).max() <= 1e-11 * np.abs(P1k).max() + 2 * asym0, "newest smoothed covariance"
       x1n, P1n = Xs[k + 1, j], Pss[k + 1, j]                 # the GPU's own values: every step is checked on its own
       Ck = np.linalg.solve(P1k, Fk @ P[k, j].T).T
       delta = np.zeros(22); xkn = np.zeros(23)
@@ -373,7 +377,8 @@ def test_config4_resynchronised_backward_steps():
         xkn[3:7] /= np.linalg.norm(xkn[3:7])                 # returned states other than the oldest are normalised
       Pkn = P[k, j] + Ck @ (P1n - P1k) @ Ck.T
       ex = float(_rel(Xs[k, j][None], xkn[None])[0]); eP = float(_rel(Pss[k, j][None], Pkn[None])[0])
-      bound = max(1e-10, 20 * np.linalg.cond(P1k) * 2.2e-16)
+      asym = max(np.abs(P[k, j] - P[k, j].T).max() / np.abs(P[k, j]).max(), np.abs(P1n - P1n.T).max() / np.abs(P1n).max())
+      bound = max(1e-10, 20 * np.linalg.cond(P1k) * 2.2e-16, 50 * asym)
       worst_x, worst_P, worst_ratio = max(worst_x, ex), max(worst_P, eP), max(worst_ratio, max(ex, eP) / bound)
       assert ex <= bound and eP <= bound, f"filter {j} backward step {k}: x {ex:.2e} P {eP:.2e} bound {bound:.2e}"
   _report("config4_resynchronised_backward", filters=n, steps=Tw - 1, x_err_max=worst_x, P_err_max=worst_P, worst_error_over_bound=worst_ratio)
