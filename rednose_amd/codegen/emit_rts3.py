@@ -345,10 +345,10 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
     head = lrow(i + 1, f"f{i + 1}") if i + 1 < E else []
     body = []
     for s in S:
-      body.append(f"      double ft{s}_{i} = y{s}[{i}], fu{s}_{i} = 0.0;")
+      body.append(f"      double ft{s}_{i} = y{s}[{i}], fu{s}_{i} = 0.0, fv{s}_{i} = 0.0, fw{s}_{i} = 0.0;")
     for m in range(i):
-      body.append("      " + " ".join(f"f{'u' if m & 1 else 't'}{s}_{i} = fma(-y{s}[{m}], f{i}[{m}], f{'u' if m & 1 else 't'}{s}_{i});" for s in S))
-    body.append("      " + " ".join(f"y{s}[{i}] = (ft{s}_{i} + fu{s}_{i}) * f{i}_il;" for s in S))
+      body.append("      " + " ".join(f"f{'tuvw'[m & 3]}{s}_{i} = fma(-y{s}[{m}], f{i}[{m}], f{'tuvw'[m & 3]}{s}_{i});" for s in S))
+    body.append("      " + " ".join(f"y{s}[{i}] = ((ft{s}_{i} + fu{s}_{i}) + (fv{s}_{i} + fw{s}_{i})) * f{i}_il;" for s in S))
     _region(b, head, body, [f"y{s}[{i}]" for s in S])
   b.extend(lrow(E - 1, f"g{E - 1}"))
   for m in range(E - 1, -1, -1):
@@ -402,7 +402,14 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
   halves = [list(range(0, H2)), list(range(H2, E))]
 
   def product(coef, out, src_index, tmp, opname):
+    """out_s[j] = sum_kk coef_s[kk] * src(j, kk), FOUR partial sums per row slot (12 independent chains for 3 slots: a dependent
+    fp64 FMA issues ~40 cycles after its predecessor when the wavefront is alone on its SIMD, two sums per slot left the chains
+    24 cycles apart)."""
     pieces = [(j, h) for j in range(E) for h in (0, 1)]
+    NP = 4
+
+    def acc(s_, j, kk):
+      return f"{out}{s_}[{j}]" if kk % NP == 0 else f"{tmp}{kk % NP}_{s_}_{j}"
 
     def loads(pc):
       j, h = pc
@@ -412,18 +419,16 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
       head = loads(pieces[pi + 1]) if pi + 1 < len(pieces) else []
       body = []
       if h == 0:
-        body.append("      " + " ".join(f"double {tmp}{s}_{j} = 0.0;" for s in S))
+        body.append("      " + " ".join(f"double {tmp}{q}_{s}_{j} = 0.0;" for s in S for q in range(1, NP)))
       for kk in halves[h]:
-        first = (kk == 0)
         body.append("      " + " ".join(
-          (f"{out}{s}[{j}] = {coef}{s}[{kk}]*{opname}{j}_{kk};" if first else
-           (f"{out}{s}[{j}] = fma({coef}{s}[{kk}], {opname}{j}_{kk}, {out}{s}[{j}]);" if kk % 2 == 0 else
-            f"{tmp}{s}_{j} = fma({coef}{s}[{kk}], {opname}{j}_{kk}, {tmp}{s}_{j});")) for s in S))
+          (f"{out}{s}[{j}] = {coef}{s}[{kk}]*{opname}{j}_{kk};" if kk == 0 else
+           f"{acc(s, j, kk)} = fma({coef}{s}[{kk}], {opname}{j}_{kk}, {acc(s, j, kk)});") for s in S))
       pins = [f"{out}{s}[{j}]" for s in S]
       if h == 1:
-        body.append("      " + " ".join(f"{out}{s}[{j}] += {tmp}{s}_{j};" for s in S))
+        body.append("      " + " ".join(f"{out}{s}[{j}] = ({out}{s}[{j}] + {tmp}1_{s}_{j}) + ({tmp}2_{s}_{j} + {tmp}3_{s}_{j});" for s in S))
       else:
-        pins += [f"{tmp}{s}_{j}" for s in S]
+        pins += [f"{tmp}{q}_{s}_{j}" for s in S for q in range(1, NP)]
       _region(b, head, body, pins)
 
   product("y", "a", lambda j, kk: f"sD[{sym(j, kk)}]", "h", "d")
