@@ -266,28 +266,28 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
   A(f"        for (int i = 0; i < {D}; i++) sxn[i] = xv[i];")
   A("      }")
   A("      rn::wave_lds_sync();")
-  A("      {")
+  A('      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the previous step\'s output stores have reached the L2')
+  A(f"      {rows_decl('pn')}      // rows of Pk1_n, read back from Ps[k + 1] (L2-served: nontemporal, not this CU's L1 -- another lane stored them)")
+  for s in S:
+    if E % 2 == 0:
+      A("      {")
+      A("        typedef double rts3_v2d __attribute__((ext_vector_type(2)));")
+      A(f"        const rts3_v2d* pn_ = reinterpret_cast<const rts3_v2d*>(Ps + (((k + 1) * n + base + gg) * {EE} + rc{s} * {E}));")
+      A("#pragma unroll")
+      A(f"        for (int j = 0; j < {E // 2}; j++) {{ const rts3_v2d v_ = __builtin_nontemporal_load(pn_ + j); pn{s}[2 * j] = v_.x; pn{s}[2 * j + 1] = v_.y; }}")
+      A("      }")
+    else:
+      A("#pragma unroll")
+      A(f"      for (int j = 0; j < {E}; j++) pn{s}[j] = __builtin_nontemporal_load(Ps + (((k + 1) * n + base + gg) * {EE} + rc{s} * {E}) + j);")
+  A("      {      // issued AFTER those loads: the wait for them then leaves these stores in flight (vmcnt retires in order)")
   A("        int lo = lane;")
   A('        asm volatile("" : "+v"(lo));')
   A(f"        for (int i = lo; i < cnt * {D}; i += 64) xs[((k + 1) * n + base) * {D} + i] = s_xn[i];      // smoothed state of step k + 1 (after its renormalisation)")
   A("      }")
-  A('      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the previous step\'s output stores have reached the L2')
   for s in S:
-    A("      {")
-    A(f"        double pn[{E}];")
-    if E % 2 == 0:
-      A("        typedef double rts3_v2d __attribute__((ext_vector_type(2)));")
-      A(f"        const rts3_v2d* pn_ = reinterpret_cast<const rts3_v2d*>(Ps + (((k + 1) * n + base + gg) * {EE} + rc{s} * {E}));")
-      A("#pragma unroll")
-      A(f"        for (int j = 0; j < {E // 2}; j++) {{ const rts3_v2d v_ = __builtin_nontemporal_load(pn_ + j); pn[2 * j] = v_.x; pn[2 * j + 1] = v_.y; }}      // L2-served (not this CU's L1: another lane stored these rows)")
-    else:
-      A(f"        const double* pn_ = Ps + (((k + 1) * n + base + gg) * {EE} + rc{s} * {E});")
-      A("#pragma unroll")
-      A(f"        for (int j = 0; j < {E}; j++) pn[j] = __builtin_nontemporal_load(pn_ + j);      // L2-served (not this CU's L1: another lane stored these rows)")
     A("#pragma unroll")
-    A(f"        for (int j = 0; j < {E}; j++) {{")
-    A(f"          if (ok{s} && j <= rr{s}) {{ sD[tb{s} + j] = pn[j] - a{s}[j]; sL[tb{s} + j] = a{s}[j]; }}")
-    A("        }")
+    A(f"      for (int j = 0; j < {E}; j++) {{")
+    A(f"        if (ok{s} && j <= rr{s}) {{ sD[tb{s} + j] = pn{s}[j] - a{s}[j]; sL[tb{s} + j] = a{s}[j]; }}")
     A("      }")
   A("      rn::wave_lds_sync();")
   A("      RN_RTS_STAMP(4);")
@@ -380,17 +380,7 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
   for s in S:
     A(f"        if (ok{s}) sdv[rr{s}] = dx{s};")
   A("      }")
-  A("      rn::wave_lds_sync();")
-  A("      if (lead) {")
-  A(f"        double xa[{D}], xnew[{D}], delta[{E}];")
-  A("#pragma unroll")
-  A(f"        for (int i = 0; i < {D}; i++) xa[i] = sxk[i];")
-  A("#pragma unroll")
-  A(f"        for (int i = 0; i < {E}; i++) delta[i] = sdv[i];")
-  A("        err_fun(xa, delta, xnew);")
-  A("#pragma unroll")
-  A(f"        for (int i = 0; i < {D}; i++) sxn[i] = xnew[i];       // xk_n: becomes xk1_n of the next (older) step")
-  A("      }")
+  A("      rn::wave_lds_sync();      // (xk_n = err(xk_k, Ck delta) is formed by the lead lanes in phase J, under the latency of its loads)")
   A("      RN_RTS_STAMP(7);")
   A("      // ---- H. T = Ck D in dot form: entry j of a row of T is that row of Ck against row j of the symmetric D (its packed")
   A("      // triangle is read both ways); each finished column of T is final, only Ck's rows stay live as coefficients ----")
@@ -459,6 +449,16 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
     A(f"        rts3_d2 v[{IT}];")
     A("#pragma unroll")
     A(f"        for (int it = 0; it < {IT}; it++) {{ const int idx = le + 64 * it; v[it] = in2[idx < nv ? idx : nv - 1]; }}")
+    A("        if (lead) {      // state update, second half (see phase G): one lane per filter, while the loads above are in flight")
+    A(f"          double xa[{D}], xnew[{D}], delta[{E}];")
+    A("#pragma unroll")
+    A(f"          for (int i = 0; i < {D}; i++) xa[i] = sxk[i];")
+    A("#pragma unroll")
+    A(f"          for (int i = 0; i < {E}; i++) delta[i] = sdv[i];")
+    A("          err_fun(xa, delta, xnew);")
+    A("#pragma unroll")
+    A(f"          for (int i = 0; i < {D}; i++) sxn[i] = xnew[i];       // xk_n: becomes xk1_n of the next (older) step")
+    A("        }")
     A("#pragma unroll")
     A(f"        for (int it = 0; it < {IT}; it++) {{")
     A("          const int idx = le + 64 * it;")
@@ -476,6 +476,16 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
     A(f"        double v[{IT}];")
     A("#pragma unroll")
     A(f"        for (int it = 0; it < {IT}; it++) {{ const int idx = le + 64 * it; v[it] = in1[idx < nv ? idx : nv - 1]; }}")
+    A("        if (lead) {      // state update, second half (see phase G): one lane per filter, while the loads above are in flight")
+    A(f"          double xa[{D}], xnew[{D}], delta[{E}];")
+    A("#pragma unroll")
+    A(f"          for (int i = 0; i < {D}; i++) xa[i] = sxk[i];")
+    A("#pragma unroll")
+    A(f"          for (int i = 0; i < {E}; i++) delta[i] = sdv[i];")
+    A("          err_fun(xa, delta, xnew);")
+    A("#pragma unroll")
+    A(f"          for (int i = 0; i < {D}; i++) sxn[i] = xnew[i];       // xk_n: becomes xk1_n of the next (older) step")
+    A("        }")
     A("#pragma unroll")
     A(f"        for (int it = 0; it < {IT}; it++) {{")
     A("          const int idx = le + 64 * it;")
