@@ -286,7 +286,7 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
   A("      }")
   for s in S:
     A("#pragma unroll")
-    A(f"      for (int j = 0; j < {E}; j++) {{")
+    A(f"      for (int j = 0; j < {min(E, GL * s + GL)}; j++) {{      // (columns beyond the slot's last row are above the diagonal for every lane)")
     A(f"        if (ok{s} && j <= rr{s}) {{ sD[tb{s} + j] = pn{s}[j] - a{s}[j]; sL[tb{s} + j] = a{s}[j]; }}")
     A("      }")
   A("      rn::wave_lds_sync();")
@@ -296,21 +296,25 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
   A("      // sums over the columns before j depend on nothing column j produces: they are emitted inside column j's region, so they")
   A("      // issue while column j's reciprocal square root (a chain of dependent fp64 operations) is in flight.  The diagonal of")
   A("      // the packed factor ends up holding the RECIPROCAL pivots (the only thing the substitutions need of it). ----")
+  def below(j):      # row slots that hold a row >= j (slot s holds rows GL s .. GL s + GL - 1): the others' entries of column j are
+    return [s for s in S if GL * s + GL - 1 >= j]      # upper-triangle junk that nothing reads -- no instruction is emitted for them
   A(f"      double pv_0 = sL[{tri(0, 0)}], pw_0 = 0.0;")
   for s in S:
     A(f"      double t{s}_0 = a{s}[0], u{s}_0 = 0.0;")
   for j in range(E):
     body = []
+    Sj = below(j)
     if j >= 1:        # the last term: entry j - 1 of the pivot row exists since the previous region's store
       m = j - 1
       tg = "w" if m & 1 else "v"
       body.append(f"      {{ const double ql = sL[{tri(j, m)}]; p{tg}_{j} = fma(-ql, ql, p{tg}_{j});" +
-                  "".join(f" {'u' if m & 1 else 't'}{s}_{j} = fma(-a{s}[{m}], ql, {'u' if m & 1 else 't'}{s}_{j});" for s in S) + " }")
+                  "".join(f" {'u' if m & 1 else 't'}{s}_{j} = fma(-a{s}[{m}], ql, {'u' if m & 1 else 't'}{s}_{j});" for s in Sj) + " }")
     body.append(f"      const double il_{j} = rn::fast_rsqrt(pv_{j} + pw_{j});")
     if j + 1 < E:     # early part of column j + 1: entries 0 .. j - 1 of its pivot row are final
       jn = j + 1
+      Sn = below(jn)
       body.append(f"      double pv_{jn} = sL[{tri(jn, jn)}], pw_{jn} = 0.0;")
-      for s in S:
+      for s in Sn:
         body.append(f"      double t{s}_{jn} = a{s}[{jn}], u{s}_{jn} = 0.0;")
       if j >= 1:
         body.append(f"      {{ double q[{j}];")
@@ -319,14 +323,14 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
         for m in range(j):
           tg = "w" if m & 1 else "v"
           body.append(f"        p{tg}_{jn} = fma(-q[{m}], q[{m}], p{tg}_{jn});" +
-                      "".join(f" {'u' if m & 1 else 't'}{s}_{jn} = fma(-a{s}[{m}], q[{m}], {'u' if m & 1 else 't'}{s}_{jn});" for s in S))
+                      "".join(f" {'u' if m & 1 else 't'}{s}_{jn} = fma(-a{s}[{m}], q[{m}], {'u' if m & 1 else 't'}{s}_{jn});" for s in Sn))
         body.append("      }")
-    for s in S:
+    for s in Sj:
       body.append(f"      a{s}[{j}] = (rr{s} == {j}) ? il_{j} : (t{s}_{j} + u{s}_{j}) * il_{j};")
       body.append(f"      if (ok{s} && rr{s} >= {j}) sL[tb{s} + {j}] = a{s}[{j}];")
-    pins = [f"a{s}[{j}]" for s in S]
+    pins = [f"a{s}[{j}]" for s in Sj]
     if j + 1 < E:
-      pins += [f"t{s}_{j + 1}" for s in S] + [f"u{s}_{j + 1}" for s in S] + [f"pv_{j + 1}", f"pw_{j + 1}"]
+      pins += [f"t{s}_{j + 1}" for s in below(j + 1)] + [f"u{s}_{j + 1}" for s in below(j + 1)] + [f"pv_{j + 1}", f"pw_{j + 1}"]
     _region(b, [], body, pins)
   A("      RN_RTS_STAMP(5);")
   A("      // ---- F. Ck^T = Pk1_k^-1 M, i.e. every row slot solves with its own right-hand side (row of A).  Forward substitution in")
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
   H2 = (E + 1) // 2
   halves = [list(range(0, H2)), list(range(H2, E))]
 
-  def product(coef, out, src_index, tmp, opname):
+  def product(coef, out, src_index, tmp, opname, slots=lambda j: list(S)):
     """out_s[j] = sum_kk coef_s[kk] * src(j, kk), FOUR partial sums per row slot (12 independent chains for 3 slots: a dependent
     fp64 FMA issues ~40 cycles after its predecessor when the wavefront is alone on its SIMD, two sums per slot left the chains
     24 cycles apart)."""
@@ -408,17 +412,18 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
     for pi, (j, h) in enumerate(pieces):
       head = loads(pieces[pi + 1]) if pi + 1 < len(pieces) else []
       body = []
+      Sj = slots(j)
       if h == 0:
-        body.append("      " + " ".join(f"double {tmp}{q}_{s}_{j} = 0.0;" for s in S for q in range(1, NP)))
+        body.append("      " + " ".join(f"double {tmp}{q}_{s}_{j} = 0.0;" for s in Sj for q in range(1, NP)))
       for kk in halves[h]:
         body.append("      " + " ".join(
           (f"{out}{s}[{j}] = {coef}{s}[{kk}]*{opname}{j}_{kk};" if kk == 0 else
-           f"{acc(s, j, kk)} = fma({coef}{s}[{kk}], {opname}{j}_{kk}, {acc(s, j, kk)});") for s in S))
-      pins = [f"{out}{s}[{j}]" for s in S]
+           f"{acc(s, j, kk)} = fma({coef}{s}[{kk}], {opname}{j}_{kk}, {acc(s, j, kk)});") for s in Sj))
+      pins = [f"{out}{s}[{j}]" for s in Sj]
       if h == 1:
-        body.append("      " + " ".join(f"{out}{s}[{j}] = ({out}{s}[{j}] + {tmp}1_{s}_{j}) + ({tmp}2_{s}_{j} + {tmp}3_{s}_{j});" for s in S))
+        body.append("      " + " ".join(f"{out}{s}[{j}] = ({out}{s}[{j}] + {tmp}1_{s}_{j}) + ({tmp}2_{s}_{j} + {tmp}3_{s}_{j});" for s in Sj))
       else:
-        pins += [f"{tmp}{q}_{s}_{j}" for s in S for q in range(1, NP)]
+        pins += [f"{tmp}{q}_{s}_{j}" for s in Sj for q in range(1, NP)]
       _region(b, head, body, pins)
 
   product("y", "a", lambda j, kk: f"sD[{sym(j, kk)}]", "h", "d")
@@ -426,11 +431,32 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
   A("      // ---- I. U = T Ck^T: rows of Ck are broadcast from the image (full layout again: factor and D are dead), dot form ----")
   rows_to_image("y")
   A("      rn::wave_lds_sync();")
-  product("a", "y", lambda j, kk: f"sI[{j * E + kk}]", "e", "c")
+  # U = Ck D Ck^T is symmetric (D is, up to rounding): a row slot forms only the columns up to its last row -- whole slots drop out
+  # of the later columns' regions -- and the missing upper-right blocks are mirrored inside the image in phase J
+  product("a", "y", lambda j, kk: f"sI[{j * E + kk}]", "e", "c", slots=below)
   A("      RN_RTS_STAMP(9);")
   A("      // ---- J. Pk_n = Pk_k + U leaves: U's rows through the image, then one coalesced read-add-write over the tile's records ----")
-  rows_to_image("y")
+  for s in S:
+    ncol = min(E, GL * s + GL)        # columns this slot formed
+    A(f"      if (ok{s}) {{")
+    A("#pragma unroll")
+    A(f"        for (int j = 0; j < {ncol}; j++) sI[rr{s} * {E} + j] = y{s}[j];")
+    A("      }")
   A("      rn::wave_lds_sync();")
+  if any(min(E, GL * s + GL) < E for s in S):
+    A("      {      // upper-right blocks: U[r][j] = U[j][r] for the columns beyond a slot's last row")
+    for s in S:
+      ncol = min(E, GL * s + GL)
+      if ncol < E:
+        A(f"        if (ok{s}) {{")
+        A(f"          double m_[{E - ncol}];")
+        A("#pragma unroll")
+        A(f"          for (int j = {ncol}; j < {E}; j++) m_[j - {ncol}] = sI[j * {E} + rr{s}];")
+        A("#pragma unroll")
+        A(f"          for (int j = {ncol}; j < {E}; j++) sI[rr{s} * {E} + j] = m_[j - {ncol}];")
+        A("        }")
+    A("      }")
+    A("      rn::wave_lds_sync();")
   A("      if (k > 0) {")
   A("#pragma unroll")
   A(f"        for (int it = 0; it < {XT}; it++) {{ const int i = lane + 64 * it; xnext[it] = xf[((k - 1) * n + base) * {D} + (i < cnt * {D} ? i : 0)]; }}")
