@@ -29,9 +29,10 @@ SMALL_MAX_E = 7    # lane-per-filter register budget: x, P and the update's temp
 #   rts_one_wave       the smoother spilled under the two-wavefronts-per-SIMD budget -> full register file
 #   no_rts             the smoother still touches scratch -> library without batch_rts (forward filter unaffected)
 #   no_rts3            the smoother in the fused run's layout (emit_rts3) spilled -> rn::k_rts_group
+#   no_run_blk         the blocked fused run of a lane-per-filter model (emit_small.run_kernel_blk) spilled -> k_run serves untraced runs too
 #   no_run             the fused multi-step run of a model above 32 error states touches scratch -> library without batch_run
 #                      (status ERR_UNSUPPORTED, the step-granular entry points cover such models)
-FALLBACKS = ("force_wide", "no_model_defaults", "no_rts3", "rts_one_wave", "no_rts", "no_run")
+FALLBACKS = ("force_wide", "no_model_defaults", "no_rts3", "rts_one_wave", "no_rts", "no_run", "no_run_blk")
 _active = frozenset()      # fallbacks of the emit() call in progress
 
 
@@ -124,7 +125,7 @@ def _emit(spec):
   else:
     fam_mod = types.SimpleNamespace(
       kernels=lambda sp_: emit_small.kernels(sp_) + "\n" + emit_small.maha_kernels(sp_),
-      launch_predict=emit_small.launch_predict, launch_step=emit_small.launch_step, launch_run=emit_small.launch_run,
+      launch_predict=emit_small.launch_predict, launch_step=emit_small.launch_step, launch_run=lambda: emit_small.launch_run(spec),
       launch_maha=emit_small.launch_maha)
 
   hdr = ["#pragma once", "#include <stdint.h>", "#ifdef __cplusplus", 'extern "C" {', "#endif"]
@@ -358,7 +359,8 @@ int {name}_batch_predict_update_{k.kind}{sfx}(double *x, double *P, const double
   zmax = max(k.zdim for k in spec.kinds)
   abi.append(f"int {name}_zmax(void) {{ return {zmax}; }}")
   hdr.append(f"int {name}_zmax(void);")
-  unroll = emit_small.run_unroll(spec) if fam == "small" else 1
+  # steps per loop iteration of the kernel an untraced batch_run launches (instruction accounting of bench.py)
+  unroll = (emit_small.run_block(spec) or emit_small.run_unroll(spec)) if fam == "small" else 1
   abi.append(f"int {name}_run_unroll(void) {{ return {unroll}; }}")
   hdr.append(f"int {name}_run_unroll(void);")
   abi.append(f"""int {name}_batch_run(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts, int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, double *trace_x, double *trace_P, const double *ea, const int32_t *augment, void *stream) {{

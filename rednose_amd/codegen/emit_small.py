@@ -380,13 +380,32 @@ __global__ __launch_bounds__(64){kattr} void k_step_{k.kind}(double* __restrict_
 }}
 """)
   out.append(run_kernel(spec, norm))
+  if run_block(spec) > 0:
+    out.append(run_kernel_blk(spec, norm))
   return "\n".join(out)
 
 
 def run_unroll(spec):
-  """Steps of the schedule per iteration of the fused run's loop (= depth of its observation prefetch ring)."""
+  """Steps of the schedule per iteration of the traced fused run's loop (= depth of its observation prefetch ring)."""
   zmax = max(k.zdim for k in spec.kinds)
   return 8 if zmax <= 2 else 4          # observation rows in flight per wavefront (zmax doubles of staging registers per lane each)
+
+
+def run_block(spec):
+  """Steps per block of the untraced fused run (k_run_blk): observation rows of one block are in flight while the previous block is
+  computed, so a block has to outlast one HBM round trip (~2 us); a step of the 2-state model takes ~0.1 us, of a 6-state model
+  ~1 us.  Bounded by the staging registers (2 x K x zmax doubles per lane) and the code size (the K steps are unrolled)."""
+  from rednose_amd.codegen import emit
+  forced = -1 if "no_run_blk" in emit._active else tuning.current().run_block      # pylint: disable=protected-access
+  if forced:
+    return max(0, forced)
+  zmax = max(k.zdim for k in spec.kinds)
+  # measured (tools/ab_run.cpp, 65 536 filters, one wavefront per SIMD): 2-state model 8 / 16 / 32 / 64 steps per block ->
+  # 322 / 331 / 273 / 233 G steps/s (the traced kernel's structure: 138); 6-state model 2 / 4 / 8 -> 42.1 / 40.5 / 42.2 (31.5)
+  K = 16 if spec.dim_err <= 2 else 8
+  while K > 2 and (K * zmax > 32 or K * len(spec.kinds) > 16):      # staging registers; code size (K steps x every kind, unrolled)
+    K //= 2
+  return K
 
 
 def run_kernel(spec, norm):
@@ -490,10 +509,189 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
 """
 
 
-def launch_run():
-  return """  const int64_t tiles = (n + 63) >> 6;
+def run_kernel_blk(spec, norm):
+  """The fused run without trace (tx == tP == nullptr), restructured around what the counters of k_run show for small models: the
+  arithmetic of a step is tens of fp64 instructions, the step took thousands of cycles, because every step (a) waited for its own
+  y store to retire -- vmcnt counts loads and stores in issue order, and the wait for the prefetched observation row behind the
+  (conditional) stores degrades to vmcnt(0) --, (b) waited twice for scalar loads (kind / dt, then R), and (c) crossed the LDS
+  three times (row in, y out, Q).  Here a wavefront works in blocks of K steps entirely in registers:
+    * lane l reads / writes its own filter's observation row directly (zmax doubles per step, contiguous per lane);
+    * the K rows of block b + 1, and the block's schedule (dt, kind: lane u of a schedule register holds step u of the block; R: the block's
+      K x zmax^2 doubles spread over the lanes; all broadcast with v_readlane when the step runs), are loaded while block b is computed -- ONE vmcnt(0) per block;
+    * y (which replaces z in its registers) and the flags of block b are stored at the start of block b + 1, AFTER that wait, so no
+      load the wavefront is waiting for ever queues behind a store it has just issued.
+  Same arithmetic as k_run (predict_regs / update_*_regs); results agree to the last bits (FMA contraction may differ per kernel)."""
+  D, E = spec.dim_x, spec.dim_err
+  EE = E * E
+  zmax = max(k.zdim for k in spec.kinds)
+  ZZ = zmax * zmax
+  K = run_block(spec)
+  NR = (K * ZZ + 63) // 64
+  EAM = max([int(sp.Matrix(k.ea_sym).shape[0]) for k in spec.kinds if k.ea_sym is not None] + [0])
+  cases = []
+  for k in spec.kinds:
+    Z = k.zdim
+    ea, guard = "", ""
+    if k.ea_sym is not None:
+      ea = f", gea + ((int64_t)t * n + base + lc) * {EAM}"
+      guard = "            if (gea == nullptr) { fl = 8; break; }\n"
+    cases.append(f"""          case {k.kind}: {{
+{guard}            double zk[{Z}], Rk[{Z * Z}];
+#pragma unroll
+            for (int i = 0; i < {Z}; i++) zk[i] = cur[u][i];
+#pragma unroll
+            for (int i = 0; i < {Z * Z}; i++) Rk[i] = lane_bcast(Rv[(u * {ZZ} + i) >> 6], (u * {ZZ} + i) & 63);
+            fl = update_{k.kind}_regs(x, P, zk, Rk{ea});
+#pragma unroll
+            for (int i = 0; i < {Z}; i++) cur[u][i] = zk[i];
+            break;
+          }}""")
+  # rows are addressed by pointer increments (one 64-bit multiply per block, none per row): a row past the end of the schedule
+  # re-reads row T - 1 (the increment is zero there), so the loads stay unconditional
+  issue = f"""{{
+      const int64_t tb0_ = TB_ < T ? TB_ : T - 1;
+      const int64_t ts_ = TB_ + (lane < {K} ? lane : {K - 1});
+      const int64_t tsc_ = ts_ < T ? ts_ : T - 1;
+      dtn = dts[tsc_];
+      kn = kinds[tsc_];
+#pragma unroll
+      for (int r = 0; r < {NR}; r++) {{           // R of the block's steps, flat: lane l of register r holds double r * 64 + l
+        const int64_t ri_ = tb0_ * {ZZ} + r * 64 + lane;
+        Rn[r] = gR[ri_ < T * {ZZ} ? ri_ : T * {ZZ} - 1];
+      }}
+      const double* zp_ = zrow + tb0_ * rowstride;
+      const int64_t left_ = T - 1 - tb0_;          // rows of the schedule after row tb0_
+#pragma unroll
+      for (int u = 0; u < {K}; u++) {{
+#pragma unroll
+        for (int i = 0; i < {zmax}; i++) nxt[u][i] = zp_[i];
+        zp_ += (u < left_) ? rowstride : 0;
+      }}
+    }}"""
+  store = f"""#pragma unroll
+          for (int i = 0; i < {zmax}; i++) yp_[i] = cur[u][i];
+          if (flags != nullptr) fp_[0] = (uint8_t)flb[u];
+          yp_ += rowstride;
+          fp_ += n;"""
+  return f"""
+__device__ __forceinline__ double lane_bcast(const double v, const int l) {{      // lane l's value in every lane (l uniform): two v_readlane_b32
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}}
+__device__ __forceinline__ void pin_i(int& v) {{ asm volatile("" : "+v"(v)); }}
+
+// ---- fused multi-step run without trace: blocks of {K} steps in registers (see emit_small.run_kernel_blk) -------------------
+__global__ __launch_bounds__(64) void k_run_blk(double* __restrict__ gx, double* __restrict__ gP, const double* __restrict__ gQ,
+    const int32_t* __restrict__ kinds, const double* __restrict__ dts, const int64_t T, double* gz,
+    const double* __restrict__ gR, const int64_t n, const int norm_quats, uint8_t* __restrict__ flags,
+    const double* __restrict__ gea) {{
+  (void)gea;
+  __shared__ __attribute__((aligned(16))) double s_x[64 * {D | 1}];
+  __shared__ __attribute__((aligned(16))) double s_P[64 * {EE | 1}];
+  __shared__ __attribute__((aligned(16))) double s_Q[{EE}];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < {EE}; i += 64) s_Q[i] = gQ[i];
+  const int64_t tiles = (n + 63) >> 6;
+  const int64_t rowstride = n * {zmax};               // doubles between the rows of one filter in consecutive steps
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
+    const int64_t base = tile << 6;
+    const int cnt = (n - base) < 64 ? (int)(n - base) : 64;
+    rn::tile_g2l<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_g2l<{EE}>(gP + base * {EE}, cnt, s_P, lane);
+    rn::wave_lds_sync();
+    double x[{D}], P[{EE}];
+    rn::lds_to_regs<{D}>(s_x, lane, x);
+    rn::lds_to_regs<{EE}>(s_P, lane, P);
+    // lanes past the end of a ragged tile compute on a copy of the last filter's rows and store nothing
+    const int lc = lane < cnt ? lane : cnt - 1;
+    const bool live = lane < cnt;
+    double* zrow = gz + (base + lc) * {zmax};
+    double cur[{K}][{zmax}], nxt[{K}][{zmax}], Rv[{NR}], Rn[{NR}], dtv, dtn;
+    int flb[{K}], kv, kn;
+    {issue.replace("TB_", "((int64_t)0)")}
+    for (int64_t tb = 0; tb < T; tb += {K}) {{
+      // everything in flight lands: this block's rows and schedule (and the stores issued one block ago)
+#pragma unroll
+      for (int u = 0; u < {K}; u++) {{
+#pragma unroll
+        for (int i = 0; i < {zmax}; i++) rn::pin(nxt[u][i]);
+      }}
+      rn::pin(dtn);
+      pin_i(kn);
+#pragma unroll
+      for (int r = 0; r < {NR}; r++) rn::pin(Rn[r]);
+      if (tb > 0 && live) {{
+        double* yp_ = zrow + (tb - {K}) * rowstride;
+        uint8_t* fp_ = flags + (tb - {K}) * n + base + lane;
+#pragma unroll
+        for (int u = 0; u < {K}; u++) {{
+{store}
+        }}
+      }}
+#pragma unroll
+      for (int u = 0; u < {K}; u++) {{
+#pragma unroll
+        for (int i = 0; i < {zmax}; i++) cur[u][i] = nxt[u][i];
+      }}
+      dtv = dtn;
+      kv = kn;
+#pragma unroll
+      for (int r = 0; r < {NR}; r++) Rv[r] = Rn[r];
+      {issue.replace("TB_", f"(tb + {K})")}
+#pragma unroll
+      for (int u = 0; u < {K}; u++) {{
+        const int64_t t = tb + u;
+        flb[u] = 0;
+        if (t < T) {{
+          const double dt = lane_bcast(dtv, u);
+          const int kind = __builtin_amdgcn_readlane(kv, u);
+          predict_regs(x, P, s_Q, dt);
+          {norm}
+          int fl = 0;
+          switch (kind) {{
+{chr(10).join(cases)}
+            default: fl = 8; break;      // kind not available in the fused run (unknown, or it takes extra arguments)
+          }}
+          {norm}
+          flb[u] = fl;
+        }}
+      }}
+    }}
+    if (live) {{
+      const int64_t tl = ((T - 1) / {K}) * {K};          // first step of the last block
+      double* yp_ = zrow + tl * rowstride;
+      uint8_t* fp_ = flags + tl * n + base + lane;
+#pragma unroll
+      for (int u = 0; u < {K}; u++) {{
+        if (tl + u < T) {{
+{store}
+        }}
+      }}
+    }}
+    rn::regs_to_lds<{D}>(s_x, lane, x);
+    rn::regs_to_lds<{EE}>(s_P, lane, P);
+    rn::wave_lds_sync();
+    rn::tile_l2g<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_l2g<{EE}>(gP + base * {EE}, cnt, s_P, lane);
+    rn::wave_lds_sync();
+  }}
+}}
+"""
+
+
+def launch_run(spec=None):
+  blk = spec is not None and run_block(spec) > 0
+  if not blk:
+    return """  const int64_t tiles = (n + 63) >> 6;
   hipLaunchKernelGGL(k_run, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
                      x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P, ea, augment);"""
+  return """  const int64_t tiles = (n + 63) >> 6;
+  if (trace_x == nullptr && trace_P == nullptr) {
+    hipLaunchKernelGGL(k_run_blk, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                       x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, ea);
+  } else {
+    hipLaunchKernelGGL(k_run, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                       x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P, ea, augment);
+  }"""
 
 
 def launch_predict():

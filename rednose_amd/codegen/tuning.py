@@ -14,6 +14,7 @@ variants do not overwrite generated/).  What each alternative measured: profiles
   small_waves  amdgpu_waves_per_eu on the lane-per-filter step kernels
   small_max_e  largest error-state count served lane-per-filter
   nt_trace     1 = nontemporal stores for the fused run's covariance trace (lane-group models)
+  run_block    steps per block of the lane-per-filter fused run without trace (0 = auto by model size, -1 = that kernel is not emitted)
   rts3         1 = smoother of lane-group models in the fused run's layout (emit_rts3: 8 filters per wavefront), 0 = rn::k_rts_group
 """
 import os
@@ -31,6 +32,7 @@ class Tuning:
   wide_lean_q: int = 0
   small_waves: int = 0
   small_max_e: int = 7
+  run_block: int = 0
   rts3: int = 1
   nt_trace: int = 1          # the fused run's covariance trace leaves with nontemporal stores (config 4 forward: 23.5 vs 24.5 ms per chunk, same call)
   wide_timeline: int = 0     # debug: lane 0 of the first 256 workgroups stamps s_memtime / the 100 MHz wall clock at every phase boundary of

@@ -71,6 +71,8 @@ def gen_code(folder, name, f_sym, dt_sym, x_sym, obs_eqs, dim_x, dim_err, eskf_p
 
     usage, bad = build()
     if not os.environ.get("RN_ALLOW_SPILLS"):
+      if "k_run_blk" in bad:
+        usage, bad = fall_back("no_run_blk", "the blocked fused run spills registers: the traced kernel serves untraced runs too")
       if bad and rn_emit.family(spec, ()) == "small":
         usage, bad = fall_back("force_wide", f"lane-per-filter kernels {bad} spill registers: regenerating in the lane-group family")
       if "k_rts3" in bad:
@@ -969,9 +971,9 @@ class BatchedEKF:
     zs = self._dev(zs, (T, nb, zmax))
     if isinstance(Rs, dict) or Rs is None:
       table = np.zeros((T, zmax * zmax))
-      for t, k in enumerate(kinds.tolist()):
+      for k in set(kinds.tolist()):          # one masked assignment per kind (a Python loop over T steps costs a millisecond per 2 000)
         Rk = np.atleast_2d(np.asarray((Rs or {})[k], dtype=np.float64))
-        table[t, :Rk.size] = Rk.reshape(-1)
+        table[kinds == k, :Rk.size] = Rk.reshape(-1)
     else:
       table = np.asarray(Rs, dtype=np.float64).reshape(T, zmax * zmax)
     Rd = self._dev(table)
