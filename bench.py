@@ -69,9 +69,12 @@ def measured_traffic(label, lib_name, gen):
   return rec["hbm_bytes_per_launch"]
 
 
-def fp64_valu_instructions(lib, kernel="k_run"):
-  """fp64 VALU instructions in the body of a kernel of a generated library (llvm-objdump): for the single-kind lane-per-filter
-  models timed below that is, to a few per cent, the count per filter-step of the fused run (its t-loop is the body)."""
+def fp64_valu_instructions(lib, kernel="k_run", unroll=1):
+  """fp64 VALU instructions per filter-step of the fused run of a single-kind lane-per-filter model, from the disassembly
+  (llvm-objdump) of the kernel an untraced batch_run launches: every v_*_f64 instruction of the kernel divided by the number of
+  step bodies it contains.  The step loop is unrolled (`unroll` = {name}_run_unroll()) and hipcc may peel or unswitch it on top
+  of that, so the bodies are counted: a step body holds as many v_rcp_f64 (one per pivot of S) as the model's step kernel
+  k_step_*<true>, which holds exactly one body."""
   objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
   if not os.path.exists(objdump):
     return None
@@ -86,19 +89,27 @@ def fp64_valu_instructions(lib, kernel="k_run"):
     os.unlink(fb)
   except Exception:      # pylint: disable=broad-except
     return None
-  # an untraced run of a lane-per-filter model launches k_run_blk when the library has it (emit_small.run_kernel_blk)
-  names = [m.group(1) for m in re.finditer(r"^[0-9a-f]+ <(.*)>:", dis, re.M)]
-  want = "k_run_blk" if kernel == "k_run" and any("k_run_blk" in nm for nm in names) else kernel
-  counts, cur = {}, None
+  f64, rcp, cur = {}, {}, None
   for line in dis.split("\n"):
     m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
     if m:
-      cur = m.group(1) if want in m.group(1) and (want != "k_run" or "k_run_blk" not in m.group(1)) else None
+      cur = m.group(1)
       continue
     if cur is not None and re.search(r"\bv_\w+_f64", line):
-      counts[cur] = counts.get(cur, 0) + 1
+      f64[cur] = f64.get(cur, 0) + 1
+      if "v_rcp_f64" in line:
+        rcp[cur] = rcp.get(cur, 0) + 1
+  # an untraced run of a lane-per-filter model launches k_run_blk when the library has it (emit_small.run_kernel_blk)
+  want = "k_run_blk" if kernel == "k_run" and any("k_run_blk" in nm for nm in f64) else kernel
+  mine = [nm for nm in f64 if want in nm and (want != "k_run" or "k_run_blk" not in nm)]
   fp64_valu_instructions.kernel = want
-  return max(counts.values()) if counts else None
+  if not mine:
+    return None
+  nm = max(mine, key=lambda k_: f64[k_])
+  step = [k_ for k_ in f64 if "k_step_" in k_ and "ILb1E" in k_]          # k_step_<kind><true>
+  per_body = min((rcp.get(k_, 0) for k_ in step), default=0)
+  bodies = rcp.get(nm, 0) // per_body if per_body and rcp.get(nm, 0) % per_body == 0 and rcp.get(nm, 0) else max(1, unroll)
+  return f64[nm] / max(1, bodies)
 
 
 def cpu_baseline(name, kind, K6, batch, budget_s=5.0, suffix="", cflags=None):
@@ -322,10 +333,8 @@ def fused_run_extra(torch, model, n, T, dev):
   assert torch.isfinite(f.x).all()
   moved = 8.0 * (2 * Z) * n * T + 8.0 * 2 * (D + E * E) * n
   rate = n * T / (best * 1e-3)
-  insts = fp64_valu_instructions(os.path.join(gen, f"lib{M.name}.so"))
+  insts = fp64_valu_instructions(os.path.join(gen, f"lib{M.name}.so"), unroll=getattr(f._lib, f"{M.name}_run_unroll")())      # pylint: disable=protected-access
   kname = getattr(fp64_valu_instructions, "kernel", "k_run")
-  if insts:         # the kernel's loop body holds run_unroll steps (one block of the blocked kernel / the prefetch ring of the traced one)
-    insts = insts / max(1, getattr(f._lib, f"{M.name}_run_unroll")())      # pylint: disable=protected-access
   roof = {"bound": "fp64-valu", "achieved": None, "peak": FP64_VALU_LANE_OPS / 1e12, "unit": "T fp64 lane-instructions/s", "frac": None,
           "fp64_valu_instructions_per_filter_step": insts, "hbm_GBs": moved / (best * 1e-3) / 1e9, "hbm_frac": moved / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
           "kernel": kname, "traffic": measured_traffic(f"{model}_fused_b{n}", M.name, gen)}

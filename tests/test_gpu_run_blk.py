@@ -44,7 +44,8 @@ def _make(gen, model, n):
     M = getattr(R, f"Random{model[4:]}Kalman")
     D, name, Rs, Q = M.dim, M.name, {k: M.obs_noise[k] for k in (1, 2, 3)}, M.Q
     x0, P0 = M.initial_x, np.diag(M.initial_P_diag)
-  mk = lambda: BatchedEKF(gen, name, Q, x0, P0, D, D, batch=n)      # noqa: E731
+  extra = {"maha_test_kinds": [1]} if model == "kinematic6_maha" else {}
+  mk = lambda: BatchedEKF(gen, name, Q, x0, P0, D, D, batch=n, **extra)      # noqa: E731
   return mk, D, Rs, x0, P0
 
 
