@@ -92,6 +92,13 @@ int main(int argc, char** argv) {
   CK(hipMalloc((void**)&dP, sizeof(double) * n * EE));
   CK(hipMalloc((void**)&dz, sizeof(double) * T * n * Z));
   CK(hipMalloc((void**)&dfl, (size_t)T * n));
+  // AB_D2D=1: the observations are put in place by a device-to-device copy (what a Python caller's clone() does) instead of a
+  // host-to-device copy -- the lines are then dirty in the L2 / Infinity Cache when the run starts
+  double* dz0 = nullptr;
+  if (std::getenv("AB_D2D")) {
+    CK(hipMalloc((void**)&dz0, sizeof(double) * T * n * Z));
+    CK(hipMemcpy(dz0, z0.data(), sizeof(double) * T * n * Z, hipMemcpyHostToDevice));
+  }
   if (trace) {
     CK(hipMalloc((void**)&dtx, sizeof(double) * T * n * D));
     CK(hipMalloc((void**)&dtP, sizeof(double) * T * n * EE));
@@ -118,7 +125,8 @@ int main(int argc, char** argv) {
     for (int r = 0; r < reps + 1; r++) {            // first pass: warm-up and the results that are compared
       CK(hipMemcpy(dx, x0.data(), sizeof(double) * n * D, hipMemcpyHostToDevice));
       CK(hipMemcpy(dP, P0.data(), sizeof(double) * n * EE, hipMemcpyHostToDevice));
-      CK(hipMemcpy(dz, z0.data(), sizeof(double) * T * n * Z, hipMemcpyHostToDevice));
+      if (dz0) CK(hipMemcpy(dz, dz0, sizeof(double) * T * n * Z, hipMemcpyDeviceToDevice));
+      else CK(hipMemcpy(dz, z0.data(), sizeof(double) * T * n * Z, hipMemcpyHostToDevice));
       CK(hipMemset(dfl, 0xEE, (size_t)T * n));
       CK(hipDeviceSynchronize());
       CK(hipEventRecord(e0, nullptr));
