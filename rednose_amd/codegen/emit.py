@@ -375,7 +375,7 @@ int {name}_batch_predict_update_{k.kind}{sfx}(double *x, double *P, const double
 
   if has_rts:
     if use_rts3:
-      launch = emit_rts3.launch()
+      launch = emit_rts3.launch(spec)
     elif group_rts:
       GLr = 16 if M <= 16 else (32 if M <= 32 else 64)
       launch = f"""  const int64_t tiles = (n + {64 // GLr - 1}) / {64 // GLr};

@@ -110,14 +110,28 @@ def sym(i, j):
   return tri(i, j) if j <= i else tri(j, i)
 
 
-def kernel(spec):
+def layout(spec):
+  """The fused run's layout (emit_wide3.layout) unless the experiment knob rts3_gl asks for wider lane groups -- fewer filters and
+  rows per wavefront, so that two wavefronts fit a SIMD's registers and a CU's LDS (rts3_lb = 2)."""
   from rednose_amd.codegen import emit_wide3 as w3
+  from rednose_amd.codegen import tuning
+  gl = tuning.current().rts3_gl
+  if not gl:
+    return w3.layout(spec)
+  return gl, -(-spec.dim_err // gl), 64 // gl
+
+
+def kernel(spec):
+  from rednose_amd.codegen import emit_wide3 as w3      # noqa: F401
+  from rednose_amd.codegen import tuning
   D, E = spec.dim_x, spec.dim_err
   EE = E * E
   TRI = E * (E + 1) // 2
   IMG = max(EE, 2 * TRI)
   IMG += IMG & 1
-  GL, R, FPW = w3.layout(spec)
+  GL, R, FPW = layout(spec)
+  lb = tuning.current().rts3_lb
+  bounds = f"__launch_bounds__(64, {lb})" if lb else "__launch_bounds__(64)"
   scal, lay = _scal_text(spec)
   _, Fs = _tables(spec)
   quat = "".join(f" rn::normalize_quat<{D}>(xv, {q});" for q in spec.quaternion_idxs)
@@ -141,7 +155,7 @@ def kernel(spec):
   A(f"constexpr int RTS3_IMG = {IMG};      // doubles of LDS image per filter: a full E x E matrix, or two packed triangles")
   A(scal)
   A(f"""
-__global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, const double* __restrict__ Pf, const double* __restrict__ ts,
+__global__ {bounds} void k_rts3(const double* __restrict__ xf, const double* __restrict__ Pf, const double* __restrict__ ts,
     const int64_t T, const double* __restrict__ gQ, const int64_t n, const int norm_quats, double* __restrict__ xs,
     double* __restrict__ Ps, const double* __restrict__ xl, const double* __restrict__ Pl) {{
   __shared__ __attribute__((aligned(16))) double s_I[{FPW} * RTS3_IMG + 2];      // the one matrix image per filter (see emit_rts3.py)
@@ -529,8 +543,13 @@ __global__ __launch_bounds__(64) void k_rts3(const double* __restrict__ xf, cons
   return "\n".join(b)
 
 
-def launch():
-  from rednose_amd.codegen import emit_wide3 as w3  # noqa: F401  (FPWR of the fused run is this kernel's filters per wavefront)
+def launch(spec=None):
+  from rednose_amd.codegen import tuning
+  if spec is not None and tuning.current().rts3_gl:
+    fpw = layout(spec)[2]
+    return f"""  const int64_t tiles = (n + {fpw - 1}) / {fpw};
+  hipLaunchKernelGGL(k_rts3, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     xf, Pf, ts, T, Q, n, norm_quats, xs, Ps, x_last, P_last);"""
   return """  const int64_t tiles = (n + FPWR - 1) / FPWR;
   hipLaunchKernelGGL(k_rts3, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
                      xf, Pf, ts, T, Q, n, norm_quats, xs, Ps, x_last, P_last);"""
