@@ -1,14 +1,5 @@
-"""`EKF_sym_pyx` under the module path the reference's models import it from.
-
-The reference has two orchestrators with one API: the pure-Python `EKF_sym` (rednose/helpers/ekf_sym.py:220-690) and the
-Cython wrapper of the C++ `EKFSym` (rednose/helpers/ekf_sym_pyx.pyx:85-196, ekf_sym.cc), which its example filters use
-(`from rednose.helpers.ekf_sym_pyx import EKF_sym_pyx`).  Here both names are the same class: the orchestration already
-follows the C++ order (quaternions renormalised after predict AND after every update, ekf_sym.cc:207,213), and it is
-feature-complete where the Cython class raises NotImplementedError (augment, get_augment_times, rts_smooth, maha_test:
-ekf_sym_pyx.pyx:182-192).  Constructor: (gen_dir, name, Q, x_initial, P_initial, dim_main, dim_main_err, N=0,
-dim_augment=0, dim_augment_err=0, maha_test_kinds=[], quaternion_idxs=[], global_vars=[], max_rewind_age=1.0,
-logger=None) -- ekf_sym_pyx.pyx:87-90.
-"""
+"""`EKF_sym_pyx` under the module path the reference's models import it from (ekf_sym_pyx.pyx:85-196): the same orchestrator as
+`EKF_sym`, with the Cython class's constructor signature (ekf_sym_pyx.pyx:87-90)."""
 import logging
 
 from rednose_amd.helpers.ekf_sym import EKF_sym
