@@ -1,0 +1,413 @@
+"""The arithmetic the lane-per-filter emitter generates (emit_small.predict_regs / update_*_regs: the device functions every kernel of
+that family calls -- step kernels, fused runs, the gate) compiled FOR THE HOST and checked against the oracle, without a GPU.
+
+The generated functions are plain C++ over register arrays (all sparsity resolved at generation time) plus three templates of
+the runtime header (LDL^T factorisation and substitutions of the Z x Z innovation covariance).  Here their text is wrapped in a
+translation unit in which `__device__` is empty and the device reciprocal (v_rcp_f64 + two Newton steps, ~1 ulp) is 1.0 / d, built
+with g++ and driven through ctypes on seeded random filters; the oracle (reference-generated sympy C + C restatement of ekf_c.c)
+runs the same fused predict + update.  What this pins on every CPU run: the emitter's algebra (F P F^T + dt Q with structural
+zeros dropped, the rank-Z Joseph form, the gate's R *= 1e16 path and its flag), for linear, nonlinear and affine models."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+HDR = os.path.join(os.path.dirname(__file__), "..", "rednose_amd", "templates", "ekf_hip_rt.h")
+pytestmark = pytest.mark.timeout(600, method="thread")      # the lane emulations below wait on barriers: a mismatch must fail, not hang
+
+
+def _function_text(text, name):
+  """Text of the (template) function `name` of the runtime header, from its `template <...>` line to its closing brace."""
+  at = text.index(f" {name}(")
+  start = text.rfind("template <", 0, at)
+  depth, i = 0, text.index("{", at)
+  while True:
+    depth += {"{": 1, "}": -1}.get(text[i], 0)
+    i += 1
+    if depth == 0:
+      return text[start:i]
+
+
+def _host_library(tmp_path, spec):
+  from rednose_amd.codegen import emit_small
+  hdr = open(HDR, encoding="utf-8").read()
+  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "normalize_quat"))
+  D, E = spec.dim_x, spec.dim_err
+  body = [emit_small.predict_regs(spec)[0]] + [emit_small.update_regs(spec, k)[0] for k in spec.kinds]
+  quat = "".join(f" rn::normalize_quat<{D}>(x, {q});" for q in spec.quaternion_idxs)
+  entry = []
+  for k in spec.kinds:
+    Z = k.zdim
+    assert k.ea_sym is None, "kinds with extra arguments are lane-group (MSCKF) kinds"
+    entry.append(f"""
+extern "C" int host_step_{k.kind}(double* gx, double* gP, const double* Q, double dt, double* gz, const double* gR) {{
+  double x[{D}], P[{E * E}], z[{Z}], R[{Z * Z}];
+  for (int i = 0; i < {D}; i++) x[i] = gx[i];
+  for (int i = 0; i < {E * E}; i++) P[i] = gP[i];
+  for (int i = 0; i < {Z}; i++) z[i] = gz[i];
+  for (int i = 0; i < {Z * Z}; i++) R[i] = gR[i];
+  predict_regs(x, P, Q, dt);{quat}
+  const int fl = update_{k.kind}_regs(x, P, z, R);{quat}
+  for (int i = 0; i < {D}; i++) gx[i] = x[i];
+  for (int i = 0; i < {E * E}; i++) gP[i] = P[i];
+  for (int i = 0; i < {Z}; i++) gz[i] = z[i];
+  return fl;
+}}""")
+  src = "\n".join(["#include <cmath>", "#include <cstdint>", "#define __device__", "#define __forceinline__ inline",
+                   "namespace rn {", "inline double fast_recip(const double d) { return 1.0 / d; }      // device: v_rcp_f64 + two Newton steps",
+                   helpers, "}  // namespace rn"] + body + entry)
+  cpp, lib = tmp_path / f"{spec.name}_host.cpp", tmp_path / f"lib{spec.name}_host.so"
+  cpp.write_text(src, encoding="utf-8")
+  res = subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", str(cpp), "-o", str(lib)], capture_output=True, text=True)
+  assert res.returncode == 0, res.stderr[-3000:]
+  return ctypes.CDLL(str(lib))
+
+
+def _model(name):
+  if name == "kinematic":
+    from examples.kinematic_kf import KinematicKalman as M
+    return M, M.model(), {}
+  if name in ("kinematic6", "kinematic6_maha"):
+    from examples.kinematic6_kf import Kinematic6Kalman as M
+    mdl = M.model()
+    mdl["name"] = name
+    return M, mdl, ({"maha_test_kinds": [1]} if name.endswith("maha") else {})
+  import examples.random_kf as R
+  M = getattr(R, {"rand3": "Random3Kalman", "rand5": "Random5Kalman", "randaff5": "RandomAffine5Kalman"}[name])
+  return M, M.model(), {}
+
+
+@pytest.mark.parametrize("name", ["kinematic", "kinematic6", "kinematic6_maha", "rand3", "rand5", "randaff5"])
+def test_generated_lane_per_filter_arithmetic_on_the_host(tmp_path, name):
+  from oracle_lib import OracleLib
+  from rednose_amd.codegen.spec import build_spec
+  M, mdl, kw = _model(name)
+  spec = build_spec(**mdl, **kw)
+  assert re.fullmatch(r"[a-z0-9_]+", spec.name)
+  lib = _host_library(tmp_path, spec)
+  o = OracleLib(name)
+  D, E = spec.dim_x, spec.dim_err
+  rng = np.random.default_rng(len(name) + D)
+  n = 40
+  x_init = np.asarray(getattr(M, "initial_x", np.zeros(D)), dtype=np.float64)
+  P_init = np.diag(getattr(M, "initial_P_diag", np.ones(E)))
+  Q = np.ascontiguousarray(M.Q, dtype=np.float64)
+  dp = ctypes.POINTER(ctypes.c_double)
+  gated = 0
+  for k in spec.kinds:
+    Z = k.zdim
+    R = np.ascontiguousarray(np.atleast_2d(M.obs_noise[k.kind]), dtype=np.float64)
+    x0 = x_init[None] + rng.normal(size=(n, D)) * 0.3
+    A = rng.normal(size=(n, E, E)) * 0.2
+    P0 = P_init[None] + A @ A.transpose(0, 2, 1)
+    # a few far-off observations: with a gated kind some filters take the R *= 1e16 path (flag 1), the others do not
+    z0 = rng.normal(size=(n, Z)) * np.where(rng.uniform(size=(n, 1)) < 0.3, 40.0, 0.5)
+    for dt in (0.0, 0.02):
+      xr, Pr, zr = x0.copy(), P0.copy(), z0.copy()
+      fr = np.zeros(n, dtype=np.uint8)
+      o.batch_step(k.kind, xr, Pr, zr, R, Q, dt, flags=fr)
+      xh, Ph, zh = x0.copy(), P0.copy(), z0.copy()
+      fh = np.zeros(n, dtype=np.uint8)
+      fn = getattr(lib, f"host_step_{k.kind}")
+      fn.argtypes = [dp, dp, dp, ctypes.c_double, dp, dp]
+      for i in range(n):
+        fh[i] = fn(xh[i].ctypes.data_as(dp), Ph[i].ctypes.data_as(dp), Q.ctypes.data_as(dp), dt, zh[i].ctypes.data_as(dp), R.ctypes.data_as(dp))
+      what = f"{name} kind {k.kind} dt {dt}"
+      assert np.array_equal(fh & 1, fr & 1), what + " gate flags"
+      gated += int((fh & 1).sum())
+      assert_close(xh, xr, rtol=1e-11, floor=1e-13, what=what + " x")
+      assert_close(Ph.reshape(n, -1), Pr.reshape(n, -1), rtol=1e-11, floor=1e-13, what=what + " P")
+      assert_close(zh, zr, rtol=1e-11, atol=1e-13 * max(1.0, np.abs(z0).max()), what=what + " y")
+  assert (gated > 0) == name.endswith("maha")
+
+
+# ---- lane-group family: the three phases of the step kernels (emit_wide2) emulated lane by lane ---------------------------------
+# Phase 1 / 3 functions (scal_*) are scalar code per filter.  The matrix-phase functions (mat_predict, mat_update_*) are written
+# for the lanes of one filter's group working on ONE image of P in LDS, ordered only by rn::wave_lds_sync(): no cross-lane
+# instruction at all.  On the host every lane is a thread and wave_lds_sync() a barrier over the group, the LDS arrays are plain
+# shared arrays -- the text that runs is the text the kernels inline, under the model's own tuning defaults (live: the
+# register-lean structure with rows of P in LDS).
+
+
+def _wide_host_library(tmp_path, spec):
+  from rednose_amd.codegen import emit_wide2, tuning
+  hdr = open(HDR, encoding="utf-8").read()
+  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "normalize_quat"))
+  with tuning.using_model(spec):
+    text, lay = emit_wide2.device_functions(spec)
+    GL = emit_wide2.group_lanes(spec)
+  D, E = spec.dim_x, spec.dim_err
+  kinds = [k for k in spec.kinds if k.He_sym is None and k.ea_sym is None]
+  want = {"scal_predict", "scal_keep", "scal_inject", "mat_predict"} | {f"scal_obs_{k.kind}" for k in kinds} | {f"mat_update_{k.kind}" for k in kinds}
+  fns = []
+  for fn in re.split(r"\n(?=(?:template <[^\n]*>\n)?__device__ )", text):
+    m = re.search(r"__device__ \w+ \w+ (\w+)\(", fn)
+    if m and m.group(1) in want:
+      fns.append(fn)
+      want.discard(m.group(1))
+  assert not want, want
+  predict_sig = next(f for f in fns if " mat_predict(" in f).split("{")[0]
+  q_arg = "Q" if "const double* sQ" in predict_sig else "qcol"
+  entry = []
+  for k in kinds:
+    Z = k.zdim
+    entry.append(f"""
+struct Job{k.kind} {{ double* sP; const double* Q; const double* R; double* sl; double* sG; double* sK; int c; int do_pred; }};
+static void* lane_{k.kind}(void* p) {{
+  const Job{k.kind}& j = *static_cast<Job{k.kind}*>(p);
+  const bool act = j.c < {E};
+  const int cc = act ? j.c : 0;
+  double qcol[{E}];
+  for (int i = 0; i < {E}; i++) qcol[i] = j.Q[i * {E} + cc];
+  const double* Q = j.Q; (void)Q; (void)qcol;
+  if (j.do_pred) mat_predict(j.sP, {q_arg}, j.sl, cc, act);
+  mat_update_{k.kind}(j.sP, j.R, j.sl, j.sl, j.sG, j.sK, cc, act);
+  return nullptr;
+}}
+extern "C" int host_wide_step_{k.kind}(double* x, double* P, const double* Q, double dt, double* z, const double* R, int norm_quats, int do_pred) {{
+  static double sl[{lay.SLOT + 8}], sP[{E * E + 2}], sG[{Z * E + 2}], sK[{Z * E + 2}];
+  g_sync_on = false;
+  if (do_pred) scal_predict(x, dt, sl, norm_quats); else scal_keep(x, sl, norm_quats);
+  scal_obs_{k.kind}(sl, z);
+  for (int i = 0; i < {E * E}; i++) sP[i] = P[i];
+  pthread_barrier_init(&g_bar, nullptr, {GL});
+  g_sync_on = true;
+  pthread_t th[{GL}];
+  Job{k.kind} jobs[{GL}];
+  for (int c = 0; c < {GL}; c++) {{ jobs[c] = Job{k.kind}{{sP, Q, R, sl, sG, sK, c, do_pred}}; pthread_create(&th[c], nullptr, lane_{k.kind}, &jobs[c]); }}
+  for (int c = 0; c < {GL}; c++) pthread_join(th[c], nullptr);
+  pthread_barrier_destroy(&g_bar);
+  g_sync_on = false;
+  const int fl = scal_inject(sl, x, norm_quats) | (int)sl[{lay.OFF_FL}];
+  for (int i = 0; i < {Z}; i++) z[i] = sl[{lay.OFF_Y} + i];
+  for (int i = 0; i < {E * E}; i++) P[i] = sP[i];
+  return fl;
+}}""")
+  src = "\n".join(["#include <cmath>", "#include <cstdint>", "#include <pthread.h>", "#define __device__", "#define __forceinline__ inline",
+                   "#define __noinline__", "static pthread_barrier_t g_bar;", "static bool g_sync_on = false;", "namespace rn {",
+                   "inline void wave_lds_sync() { if (g_sync_on) pthread_barrier_wait(&g_bar); }      // device: a compiler fence inside one wavefront",
+                   "inline double fast_recip(const double d) { return 1.0 / d; }", helpers, "}  // namespace rn"] + fns + entry)
+  cpp, lib = tmp_path / f"{spec.name}_wide_host.cpp", tmp_path / f"lib{spec.name}_wide_host.so"
+  cpp.write_text(src, encoding="utf-8")
+  res = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", str(cpp), "-o", str(lib)], capture_output=True, text=True)
+  assert res.returncode == 0, res.stderr[-3000:]
+  return ctypes.CDLL(str(lib)), kinds
+
+
+def _wide_model(name):
+  if name in ("live", "live_maha"):
+    from examples.live_kf import LiveKalman as M, ObservationKind as LK
+    mdl = M.model() if hasattr(M, "model") else None
+    return M, mdl, ({"maha_test_kinds": [LK.ECEF_POS]} if name == "live_maha" else {}), 3
+  if name == "kinematic9":
+    from examples.kinematic9_kf import Kinematic9Kalman as M
+    return M, M.model(), {}, -1
+  import examples.random_kf as R
+  M = getattr(R, f"Random{name[4:]}Kalman")
+  return M, M.model(), {}, -1
+
+
+@pytest.mark.parametrize("name", ["kinematic9", "rand11", "rand24", "live", "live_maha"])
+def test_generated_lane_group_step_on_the_host(tmp_path, name):
+  from oracle_lib import OracleLib
+  from rednose_amd.codegen.spec import build_spec
+  M, mdl, kw, quat_idx = _wide_model(name)
+  if mdl is None:
+    pytest.skip("model definition not exposed as a dict")
+  mdl = dict(mdl)
+  mdl["name"] = name
+  spec = build_spec(**mdl, **kw)
+  lib, kinds = _wide_host_library(tmp_path, spec)
+  o = OracleLib(name)
+  D, E = spec.dim_x, spec.dim_err
+  rng = np.random.default_rng(E)
+  n = 6
+  x_init = np.asarray(M.initial_x, dtype=np.float64)
+  P_init = np.diag(M.initial_P_diag)
+  Q = np.ascontiguousarray(M.Q, dtype=np.float64)
+  dp = ctypes.POINTER(ctypes.c_double)
+  gated = 0
+  for k in kinds:
+    Z = k.zdim
+    R = np.ascontiguousarray(np.atleast_2d(M.obs_noise.get(k.kind, 0.01 * np.eye(Z))), dtype=np.float64)      # (live defines no noise for its camera kinds)
+    x0 = np.tile(x_init, (n, 1))
+    x0 += rng.normal(size=(n, D)) * 0.01 * np.maximum(1.0, np.abs(x_init))[None] * (np.abs(x_init)[None] < 10.0)      # not the ECEF position: metres
+    A = rng.normal(size=(n, E, E)) * 0.1 * np.sqrt(np.diag(P_init))[None, :, None]
+    P0 = P_init[None] + A @ A.transpose(0, 2, 1)
+    # observations near their prediction (h(x0) through the oracle), a third of them far off so that a gated kind splits
+    hx = np.zeros((n, Z))
+    for i in range(n):
+      xq = x0[i].copy()
+      if quat_idx >= 0:
+        xq[quat_idx:quat_idx + 4] /= np.linalg.norm(xq[quat_idx:quat_idx + 4])
+      o.call(f"h_{k.kind}", xq, np.zeros(4), hx[i])
+    sig = np.sqrt(np.diag(R))[None]
+    far = rng.uniform(size=(n, 1)) < 0.34        # (far against the PRIOR spread too: the position prior of live is 10 km wide)
+    z0 = hx + rng.normal(size=(n, Z)) * sig + far * rng.normal(size=(n, Z)) * 40.0 * np.sqrt(P_init.max())
+    for dt in (0.0, 0.01):
+      xr, Pr, zr = x0.copy(), P0.copy(), z0.copy()
+      fr = np.zeros(n, dtype=np.uint8)
+      o.batch_step(k.kind, xr, Pr, zr, R, Q, dt, quat_idx=quat_idx, flags=fr)
+      xh, Ph, zh = x0.copy(), P0.copy(), z0.copy()
+      fh = np.zeros(n, dtype=np.uint8)
+      fn = getattr(lib, f"host_wide_step_{k.kind}")
+      fn.argtypes = [dp, dp, dp, ctypes.c_double, dp, dp, ctypes.c_int, ctypes.c_int]
+      do_pred = int(not (dt == 0.0 and spec.identity_at_dt0()))
+      for i in range(n):
+        fh[i] = fn(xh[i].ctypes.data_as(dp), Ph[i].ctypes.data_as(dp), Q.ctypes.data_as(dp), dt, zh[i].ctypes.data_as(dp), R.ctypes.data_as(dp),
+                   int(quat_idx >= 0), do_pred)
+      what = f"{name} kind {k.kind} dt {dt}"
+      assert np.array_equal(fh & 1, fr & 1), what + " gate flags"
+      gated += int((fh & 1).sum())
+      assert_close(xh, xr, rtol=1e-10, floor=1e-12, what=what + " x")
+      assert_close(Ph.reshape(n, -1), Pr.reshape(n, -1), rtol=1e-9, floor=1e-11, what=what + " P")
+      assert_close(zh, zr, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(z0).max()), what=what + " y")
+  assert (gated > 0) == (name == "live_maha")
+
+
+# ---- lane-group fused run (emit_wide3): GL lanes x R rows per filter, rows of P in registers for T steps ----------------------------
+# Same emulation (a thread per lane of one filter's group, wave_lds_sync() = barrier); the rows stay in each lane's "registers"
+# (thread-local arrays) from step to step like in k_run, only x / P / z move through the shared images.  Both predict variants
+# (general Q read through a pointer, diagonal Q in registers) run the same schedule.
+
+
+def _run_host_library(tmp_path, spec):
+  from rednose_amd.codegen import emit_wide2 as w2, emit_wide3 as w3, tuning
+  hdr = open(HDR, encoding="utf-8").read()
+  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "normalize_quat"))
+  D, E = spec.dim_x, spec.dim_err
+  kinds = [k for k in spec.kinds if k.He_sym is None and k.ea_sym is None]
+  with tuning.using_model(spec):
+    GL, R, _ = w3.layout(spec)
+    scal_text, lay = w2.device_functions(spec, lay_cls=w3.RunLayout, sfx="_r")
+    fns = [scal_text, w3.predict_fn(spec), w3.predict_fn(spec, qdiag=True)] + [w3.update_fn(spec, k) for k in kinds]
+  zmax = max(k.zdim for k in spec.kinds)
+  rows = ", ".join(f"row{s}" for s in range(R))
+  idx = ", ".join(f"rr{s}, rc{s}, ok{s}" for s in range(R))
+  decl = "\n".join(f"  const int rr{s} = j.c + {GL * s}; const bool ok{s} = rr{s} < {E}; const int rc{s} = ok{s} ? rr{s} : 0;\n"
+                   f"  double row{s}[{E}]; for (int q = 0; q < {E}; q++) row{s}[q] = j.sP[rc{s} * {E} + q];" for s in range(R))
+  back = "\n".join(f"    if (ok{s}) for (int q = 0; q < {E}; q++) j.sP[rr{s} * {E} + q] = row{s}[q];" for s in range(R))
+  qd = ", ".join(f"j.Q[rc{s} * {E + 1}]" for s in range(R))
+  scal_cases = "\n".join(f"        case {k.kind}: scal_obs_{k.kind}_r(j.sl, j.sl + {lay.OFF_Y}); break;" for k in kinds)
+  mat_cases = "\n".join(f"      case {k.kind}: update_{k.kind}_rows({rows}, j.R + t * {zmax * zmax}, j.sP, j.sG, j.sl, j.sl, {idx}); break;" for k in kinds)
+  src = "\n".join(["#include <cmath>", "#include <cstdint>", "#include <pthread.h>", "#define __device__", "#define __forceinline__ inline",
+                   "#define __noinline__", "static pthread_barrier_t g_bar;",
+                   "static thread_local bool t_scalar = false;      // inside a scalar-phase function (one lane): its fences are not barriers",
+                   "namespace rn {", "inline void wave_lds_sync() { if (!t_scalar) pthread_barrier_wait(&g_bar); }", "inline void pin(double&) {}",
+                   "inline double fast_recip(const double d) { return 1.0 / d; }", helpers, "}  // namespace rn"] + fns + [f"""
+struct Job {{ double* x; double* sP; const double* Q; const double* R; const int* kinds; const double* dts; double* z; int T; double* sl; double* sG;
+             unsigned char* flags; int c; int norm_quats; int qdiag; int skip_dt0; }};
+static void* lane(void* p) {{
+  const Job& j = *static_cast<Job*>(p);
+{decl}
+  for (int t = 0; t < j.T; t++) {{
+    const double dt = j.dts[t];
+    const bool do_pred = !(j.skip_dt0 && dt == 0.0);
+    if (j.c == 0) {{
+      t_scalar = true;
+      for (int i = 0; i < {zmax}; i++) j.sl[{lay.OFF_Y} + i] = j.z[t * {zmax} + i];
+      if (do_pred) scal_predict_r(j.sl + {lay.OFF_X}, dt, j.sl, j.norm_quats); else scal_keep_r(j.sl + {lay.OFF_X}, j.sl, j.norm_quats);
+      t_scalar = false;
+    }}
+    rn::wave_lds_sync();
+    if (do_pred) {{
+      if (j.qdiag) predict_rows_qd({rows}, j.sP, {qd}, j.sl, {idx});
+      else predict_rows({rows}, j.sP, j.Q, j.sl, {idx});
+    }}
+    if (j.c == 0) {{
+      t_scalar = true;
+      switch (j.kinds[t]) {{
+{scal_cases}
+        default: break;
+      }}
+      t_scalar = false;
+    }}
+    rn::wave_lds_sync();
+    switch (j.kinds[t]) {{
+{mat_cases}
+      default: break;
+    }}
+    if (j.c == 0) {{
+      t_scalar = true;
+      j.flags[t] = (unsigned char)(scal_inject_r(j.sl, j.sl + {lay.OFF_X}, j.norm_quats) | (int)j.sl[{lay.OFF_FL}]);
+      for (int i = 0; i < {zmax}; i++) j.z[t * {zmax} + i] = j.sl[{lay.OFF_Y} + i];
+      t_scalar = false;
+    }}
+    rn::wave_lds_sync();
+  }}
+{back}
+  return nullptr;
+}}
+extern "C" void host_run(double* x, double* P, const double* Q, const double* R, const int* kinds, const double* dts, double* z, int T,
+                         unsigned char* flags, int norm_quats, int qdiag, int skip_dt0) {{
+  static double sl[{lay.SLOT + 8}], sP[{E * E + 2}], sG[{zmax * E + 8}];
+  for (int i = 0; i < {D}; i++) sl[{lay.OFF_X} + i] = x[i];
+  for (int i = 0; i < {E * E}; i++) sP[i] = P[i];
+  pthread_barrier_init(&g_bar, nullptr, {GL});
+  pthread_t th[{GL}];
+  Job jobs[{GL}];
+  for (int c = 0; c < {GL}; c++) {{ jobs[c] = Job{{x, sP, Q, R, kinds, dts, z, T, sl, sG, flags, c, norm_quats, qdiag, skip_dt0}}; pthread_create(&th[c], nullptr, lane, &jobs[c]); }}
+  for (int c = 0; c < {GL}; c++) pthread_join(th[c], nullptr);
+  pthread_barrier_destroy(&g_bar);
+  for (int i = 0; i < {D}; i++) x[i] = sl[{lay.OFF_X} + i];
+  for (int i = 0; i < {E * E}; i++) P[i] = sP[i];
+}}"""])
+  cpp, lib = tmp_path / f"{spec.name}_run_host.cpp", tmp_path / f"lib{spec.name}_run_host.so"
+  cpp.write_text(src, encoding="utf-8")
+  res = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", str(cpp), "-o", str(lib)], capture_output=True, text=True)
+  assert res.returncode == 0, res.stderr[-3000:]
+  return ctypes.CDLL(str(lib)), kinds, zmax
+
+
+@pytest.mark.parametrize("name,qdiag", [("kinematic9", 1), ("rand11", 0), ("live", 1), ("live", 0)])
+def test_generated_lane_group_fused_run_on_the_host(tmp_path, name, qdiag):
+  from oracle_lib import OracleLib
+  from rednose_amd.codegen.spec import build_spec
+  M, mdl, kw, quat_idx = _wide_model(name)
+  mdl = dict(mdl)
+  mdl["name"] = name
+  spec = build_spec(**mdl, **kw)
+  lib, kinds, zmax = _run_host_library(tmp_path, spec)
+  o = OracleLib(name)
+  D, E = spec.dim_x, spec.dim_err
+  rng = np.random.default_rng(E + qdiag)
+  Q = np.ascontiguousarray(M.Q, dtype=np.float64)
+  assert not qdiag or np.count_nonzero(Q - np.diag(np.diag(Q))) == 0
+  T = 3 * len(kinds)
+  sched = np.array([kinds[t % len(kinds)].kind for t in range(T)], dtype=np.int32)
+  dts = np.array([0.0 if t % 3 == 1 else 0.01 for t in range(T)])       # a second observation at the same time stamp every third step
+  Rt = np.zeros((T, zmax * zmax))
+  zs = np.zeros((T, zmax))
+  x_init = np.asarray(M.initial_x, dtype=np.float64)
+  # away from the initial state itself: live's speed observation has the Jacobian v / |v|, undefined at rest
+  x0 = x_init + rng.normal(size=D) * 0.01 * np.maximum(1.0, np.abs(x_init)) * (np.abs(x_init) < 10.0)
+  if quat_idx >= 0:
+    x0[quat_idx:quat_idx + 4] /= np.linalg.norm(x0[quat_idx:quat_idx + 4])
+  A = rng.normal(size=(E, E)) * 0.1 * np.sqrt(M.initial_P_diag)[:, None]
+  P0 = np.diag(M.initial_P_diag) + A @ A.T
+  zdim = {k.kind: k.zdim for k in kinds}
+  for t, kd in enumerate(sched):
+    Z = zdim[int(kd)]
+    Rk = np.atleast_2d(M.obs_noise.get(int(kd), 0.01 * np.eye(Z)))
+    Rt[t, :Z * Z] = Rk.reshape(-1)
+    hx = np.zeros(Z)
+    o.call(f"h_{int(kd)}", x0.copy(), np.zeros(4), hx)
+    zs[t, :Z] = hx + rng.normal(size=Z) * np.sqrt(np.diag(Rk))
+  xr, Pr, zr = x0[None].copy(), P0[None].copy(), zs[:, None, :].copy()
+  o.batch_run(sched, dts, xr, Pr, zr, Rt, Q, quat_idx=quat_idx)
+  xh, Ph, zh = x0.copy(), P0.copy(), zs.copy()
+  fl = np.zeros(T, dtype=np.uint8)
+  dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+  lib.host_run.argtypes = [dp, dp, dp, dp, ip, dp, dp, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte)] + [ctypes.c_int] * 3
+  lib.host_run(xh.ctypes.data_as(dp), Ph.ctypes.data_as(dp), Q.ctypes.data_as(dp), Rt.ctypes.data_as(dp), sched.ctypes.data_as(ip),
+               dts.ctypes.data_as(dp), zh.ctypes.data_as(dp), T, fl.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), int(quat_idx >= 0), qdiag, 1)
+  assert not fl.any()
+  what = f"{name} fused run of {T} steps (qdiag={qdiag})"
+  assert_close(xh[None], xr, rtol=1e-9, floor=1e-11, what=what + " x")
+  assert_close(Ph.reshape(1, -1), Pr.reshape(1, -1), rtol=1e-8, floor=1e-10, what=what + " P")
+  assert_close(zh.reshape(1, -1), zr.reshape(1, -1), rtol=1e-8, atol=1e-10 * max(1.0, np.abs(zs).max()), what=what + " y")
