@@ -411,3 +411,184 @@ def test_generated_lane_group_fused_run_on_the_host(tmp_path, name, qdiag):
   assert_close(xh[None], xr, rtol=1e-9, floor=1e-11, what=what + " x")
   assert_close(Ph.reshape(1, -1), Pr.reshape(1, -1), rtol=1e-8, floor=1e-10, what=what + " P")
   assert_close(zh.reshape(1, -1), zr.reshape(1, -1), rtol=1e-8, atol=1e-10 * max(1.0, np.abs(zs).max()), what=what + " y")
+
+
+# ---- lane-per-filter KERNELS on the host: tile loops, LDS staging, block indexing of the fused runs, masks, flags ------------------
+# The whole text of emit_small.kernels() -- k_predict, k_step_*<DO_PREDICT>, k_run, k_run_blk with the device functions they
+# inline -- compiled for the host: a workgroup is 64 threads, threadIdx / blockIdx / gridDim are thread-local, __shared__ arrays are
+# function-static (built with -fno-gnu-unique: statics of templates would otherwise be shared by every such library in the process),
+# rn::wave_lds_sync() is a barrier, the asynchronous HBM -> LDS tile copy is the synchronous one, and
+# __builtin_amdgcn_readlane exchanges through a 64-entry array between two barriers.  Workgroups run one after the other.
+
+_KERNEL_PRELUDE = r"""
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <pthread.h>
+#define __device__
+#define __forceinline__ inline
+#define __global__
+#define __launch_bounds__(...)
+#define __shared__ static
+#define RN_LDS_PAD 0
+struct double2 { double x, y; };
+struct Dim3 { int x; };
+static thread_local Dim3 threadIdx, blockIdx, gridDim;
+static pthread_barrier_t g_bar;
+static int g_xchg[64];
+inline int __builtin_amdgcn_readlane(int v, int l) {
+  g_xchg[threadIdx.x] = v;
+  pthread_barrier_wait(&g_bar);
+  const int r = g_xchg[l];
+  pthread_barrier_wait(&g_bar);
+  return r;
+}
+inline int __double2hiint(double d) { int64_t b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }
+inline int __double2loint(double d) { int64_t b; std::memcpy(&b, &d, 8); return (int)(b & 0xffffffff); }
+inline double __hiloint2double(int hi, int lo) { const int64_t b = ((int64_t)hi << 32) | (uint32_t)lo; double d; std::memcpy(&d, &b, 8); return d; }
+namespace rn {
+constexpr int WAVE = 64;
+inline void wave_lds_sync() { pthread_barrier_wait(&g_bar); }
+inline void async_wait() {}
+inline void pin(double&) {}
+inline double fast_recip(const double d) { return 1.0 / d; }
+"""
+
+
+def _kernel_host_library(tmp_path, spec):
+  from rednose_amd.codegen import emit_small
+  hdr = open(HDR, encoding="utf-8").read()
+  names = ("lds_stride", "tile_g2l", "tile_l2g", "lds_to_regs", "regs_to_lds", "spd_factor", "spd_forward", "spd_solve", "normalize_quat")
+  helpers = "\n".join(_function_text(hdr, f) for f in names)
+  at = hdr.index("struct TilePrefetch")
+  prefetch = hdr[hdr.rfind("template <", 0, at):hdr.index("};", at) + 2]
+  text = emit_small.kernels(spec)
+  text = text.replace('asm volatile("" : "+v"(v));', ";")        # pin_i: a register constraint of the device
+  D, E = spec.dim_x, spec.dim_err
+  zmax = max(k.zdim for k in spec.kinds)
+  k0 = spec.kinds[0]
+  launch = f"""
+template <class F> static void run_grid(int grid, F body) {{
+  struct Arg {{ F* body; int lane, block, grid; }};
+  for (int b = 0; b < grid; b++) {{
+    pthread_barrier_init(&g_bar, nullptr, 64);
+    pthread_t th[64];
+    Arg args[64];
+    for (int l = 0; l < 64; l++) {{
+      args[l] = Arg{{&body, l, b, grid}};
+      pthread_create(&th[l], nullptr, [](void* p) -> void* {{
+        Arg& a = *static_cast<Arg*>(p);
+        threadIdx.x = a.lane; blockIdx.x = a.block; gridDim.x = a.grid;
+        (*a.body)();
+        return nullptr;
+      }}, &args[l]);
+    }}
+    for (int l = 0; l < 64; l++) pthread_join(th[l], nullptr);
+    pthread_barrier_destroy(&g_bar);
+  }}
+}}
+extern "C" __attribute__((visibility("default"))) void host_run(int blocked, int grid, double* x, double* P, const double* Q, const int32_t* kinds, const double* dts, int64_t T, double* z,
+                         const double* R, int64_t n, int norm_quats, uint8_t* flags, double* tx, double* tP) {{
+  if (blocked) run_grid(grid, [&] {{ k_run_blk(x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, nullptr); }});
+  else run_grid(grid, [&] {{ k_run(x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, tx, tP, nullptr, nullptr); }});
+}}
+extern "C" __attribute__((visibility("default"))) void host_step(int grid, double* x, double* P, double* z, const double* R, int r_per_filter, const double* Q, const double* dt_vec, double dt,
+                          int64_t n, int norm_quats, uint8_t* flags, const uint8_t* active) {{
+  run_grid(grid, [&] {{ k_step_{k0.kind}<true>(x, P, z, R, r_per_filter, nullptr, Q, dt_vec, dt, n, norm_quats, flags, active); }});
+}}
+"""
+  src = "\n".join([_KERNEL_PRELUDE, helpers, prefetch,
+                   "template <int EPF> inline void tile_g2l_async(const double* g, int cnt, double* lds, int lane) { tile_g2l<EPF>(g, cnt, lds, lane); }",
+                   "}  // namespace rn", text, launch])
+  cpp, lib = tmp_path / f"{spec.name}_kernels_host.cpp", tmp_path / f"lib{spec.name}_kernels_host.so"
+  cpp.write_text(src, encoding="utf-8")
+  res = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fno-gnu-unique", "-fvisibility=hidden", "-Wno-unknown-pragmas", "-Wno-attributes", str(cpp), "-o", str(lib)],
+                       capture_output=True, text=True)
+  assert res.returncode == 0, res.stderr[-4000:]
+  return ctypes.CDLL(str(lib)), zmax
+
+
+@pytest.mark.parametrize("name", ["kinematic", "kinematic6_maha", "rand3"])
+def test_lane_per_filter_kernels_on_the_host(tmp_path, name):
+  """k_run_blk and k_run (with trace) against the oracle's batch_run and each other: ragged last tile, a grid smaller than the tile
+  count (grid-stride loop), schedule lengths around the block size, several kinds, gate flags, guard rows around z and the flags;
+  then the step kernel with an `active` mask."""
+  from oracle_lib import OracleLib
+  from rednose_amd.codegen import emit_small
+  from rednose_amd.codegen.spec import build_spec
+  M, mdl, kw = _model(name)
+  spec = build_spec(**mdl, **kw)
+  lib, zmax = _kernel_host_library(tmp_path, spec)
+  o = OracleLib(name)
+  D, E = spec.dim_x, spec.dim_err
+  K = emit_small.run_block(spec)
+  rng = np.random.default_rng(E)
+  n, grid = 150, 2                                       # three tiles (the last with 22 filters) on two workgroups
+  Q = np.ascontiguousarray(M.Q, dtype=np.float64)
+  x_init = np.asarray(getattr(M, "initial_x", np.zeros(D)), dtype=np.float64)
+  P_init = np.diag(getattr(M, "initial_P_diag", np.ones(E)))
+  kset = [k.kind for k in spec.kinds]
+  zdim = {k.kind: k.zdim for k in spec.kinds}
+  dp, ip, bp = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_ubyte)
+  lib.host_run.argtypes = [ctypes.c_int, ctypes.c_int, dp, dp, dp, ip, dp, ctypes.c_int64, dp, dp, ctypes.c_int64, ctypes.c_int, bp, dp, dp]
+  ptr = lambda a, t=dp: a.ctypes.data_as(t)      # noqa: E731
+  for T in (1, K - 1, K, 2 * K + 1):
+    if T < 1:
+      continue
+    sched = np.array([kset[t % len(kset)] for t in range(T)], dtype=np.int32)
+    dts = rng.uniform(0.005, 0.03, size=T)
+    Rt = np.zeros((T, zmax * zmax))
+    for t, kd in enumerate(sched):
+      Rk = np.atleast_2d(M.obs_noise[int(kd)])
+      Rt[t, :Rk.size] = Rk.reshape(-1)
+    x0 = x_init[None] + rng.normal(size=(n, D)) * 0.3
+    A = rng.normal(size=(n, E, E)) * 0.2
+    P0 = P_init[None] + A @ A.transpose(0, 2, 1)
+    zs = rng.normal(size=(T, n, zmax)) * np.where(rng.uniform(size=(T, n, 1)) < 0.2, 40.0, 0.5)
+    xr, Pr, zr = x0.copy(), P0.copy(), zs.copy()
+    fr = np.zeros((T, n), dtype=np.uint8)
+    o.batch_run(sched, dts, xr, Pr, zr, Rt, Q, flags=fr)
+    got = {}
+    for blocked in (1, 0):
+      xh, Ph = x0.copy(), P0.copy()
+      zg = np.full((T + 2, n, zmax), 777.0); zg[1:T + 1] = zs
+      fg = np.full((T + 2, n), 99, dtype=np.uint8)
+      tx, tP = np.zeros((T, n, D)), np.zeros((T, n, E, E))
+      lib.host_run(blocked, grid, ptr(xh), ptr(Ph), ptr(Q), ptr(sched, ip), ptr(dts), T, ptr(zg[1]), ptr(Rt), n, 0, ptr(fg[1], bp),
+                   None if blocked else ptr(tx), None if blocked else ptr(tP))
+      what = f"{name} T={T} {'k_run_blk' if blocked else 'k_run'}"
+      assert (zg[0] == 777.0).all() and (zg[T + 1] == 777.0).all() and (fg[0] == 99).all() and (fg[T + 1] == 99).all(), what + " guard rows"
+      assert np.array_equal(fg[1:T + 1] & 1, fr & 1), what + " flags"
+      assert_close(xh, xr, rtol=1e-9, floor=1e-11, what=what + " x")
+      assert_close(Ph.reshape(n, -1), Pr.reshape(n, -1), rtol=1e-9, floor=1e-11, what=what + " P")
+      for t in range(T):      # y of a kind with Z < zmax: the padding columns pass through
+        Z = zdim[int(sched[t])]
+        assert_close(zg[1 + t][:, :Z], zr[t][:, :Z], rtol=1e-9, atol=1e-11 * max(1.0, np.abs(zs).max()), what=what + f" y[{t}]")
+        assert np.array_equal(zg[1 + t][:, Z:], zs[t][:, Z:]), what + " padding columns"
+      if not blocked:
+        assert np.array_equal(tx[-1], xh) and np.array_equal(tP[-1], Ph), what + " last trace row"
+      got[blocked] = (xh, Ph, zg, fg)
+    for a, b in zip(got[1], got[0]):                       # same device functions, same compiler here: identical
+      assert np.array_equal(a, b), f"{name} T={T}: blocked and traced kernels differ"
+    if name.endswith("maha") and T >= K:
+      assert (fr & 1).any() and not (fr & 1).all()
+  # step kernel: masked-out filters pass through bit for bit with flag 16, the others match the oracle
+  k0 = spec.kinds[0]
+  Z = k0.zdim
+  R = np.ascontiguousarray(np.atleast_2d(M.obs_noise[k0.kind]), dtype=np.float64)
+  x0 = x_init[None] + rng.normal(size=(n, D)) * 0.3
+  A = rng.normal(size=(n, E, E)) * 0.2
+  P0 = P_init[None] + A @ A.transpose(0, 2, 1)
+  z0 = rng.normal(size=(n, Z))
+  act = (rng.uniform(size=n) < 0.6).astype(np.uint8)
+  dtv = rng.uniform(0.0, 0.03, size=n)
+  xr, Pr, zr = x0.copy(), P0.copy(), z0.copy()
+  o.batch_step(k0.kind, xr, Pr, zr, R, Q, dtv)
+  xh, Ph, zh, fl = x0.copy(), P0.copy(), z0.copy(), np.full(n, 99, dtype=np.uint8)
+  lib.host_step.argtypes = [ctypes.c_int, dp, dp, dp, dp, ctypes.c_int, dp, dp, ctypes.c_double, ctypes.c_int64, ctypes.c_int, bp, bp]
+  lib.host_step(grid, ptr(xh), ptr(Ph), ptr(zh), ptr(R), 0, ptr(Q), ptr(dtv), 0.0, n, 0, ptr(fl, bp), ptr(act, bp))
+  on = act != 0
+  assert np.array_equal(xh[~on], x0[~on]) and np.array_equal(Ph[~on], P0[~on]) and np.array_equal(zh[~on], z0[~on]) and (fl[~on] == 16).all()
+  assert_close(xh[on], xr[on], rtol=1e-11, floor=1e-13, what=f"{name} masked step x")
+  assert_close(Ph[on].reshape(int(on.sum()), -1), Pr[on].reshape(int(on.sum()), -1), rtol=1e-11, floor=1e-13, what=f"{name} masked step P")
+  assert_close(zh[on], zr[on], rtol=1e-11, atol=1e-13 * max(1.0, np.abs(z0).max()), what=f"{name} masked step y")
