@@ -18,7 +18,7 @@ import pytest
 from conftest import assert_close
 
 HDR = os.path.join(os.path.dirname(__file__), "..", "rednose_amd", "templates", "ekf_hip_rt.h")
-pytestmark = pytest.mark.timeout(600, method="thread")      # the lane emulations below wait on barriers: a mismatch must fail, not hang
+pytestmark = pytest.mark.timeout(180, method="thread")      # the lane emulations below wait on barriers: a mismatch must fail, not hang
 
 
 def _function_text(text, name):
@@ -420,6 +420,28 @@ def test_generated_lane_group_fused_run_on_the_host(tmp_path, name, qdiag):
 # rn::wave_lds_sync() is a barrier, the asynchronous HBM -> LDS tile copy is the synchronous one, and
 # __builtin_amdgcn_readlane exchanges through a 64-entry array between two barriers.  Workgroups run one after the other.
 
+_RUN_GRID = r"""
+template <class F> static void run_grid(int grid, F body) {
+  struct Arg { F* body; int lane, block, grid; };
+  for (int b = 0; b < grid; b++) {
+    pthread_barrier_init(&g_bar, nullptr, 64);
+    pthread_t th[64];
+    Arg args[64];
+    for (int l = 0; l < 64; l++) {
+      args[l] = Arg{&body, l, b, grid};
+      pthread_create(&th[l], nullptr, [](void* p) -> void* {
+        Arg& a = *static_cast<Arg*>(p);
+        threadIdx.x = a.lane; blockIdx.x = a.block; gridDim.x = a.grid;
+        (*a.body)();
+        return nullptr;
+      }, &args[l]);
+    }
+    for (int l = 0; l < 64; l++) pthread_join(th[l], nullptr);
+    pthread_barrier_destroy(&g_bar);
+  }
+}
+"""
+
 _KERNEL_PRELUDE = r"""
 #include <cmath>
 #include <cstdint>
@@ -468,25 +490,7 @@ def _kernel_host_library(tmp_path, spec):
   zmax = max(k.zdim for k in spec.kinds)
   k0 = spec.kinds[0]
   launch = f"""
-template <class F> static void run_grid(int grid, F body) {{
-  struct Arg {{ F* body; int lane, block, grid; }};
-  for (int b = 0; b < grid; b++) {{
-    pthread_barrier_init(&g_bar, nullptr, 64);
-    pthread_t th[64];
-    Arg args[64];
-    for (int l = 0; l < 64; l++) {{
-      args[l] = Arg{{&body, l, b, grid}};
-      pthread_create(&th[l], nullptr, [](void* p) -> void* {{
-        Arg& a = *static_cast<Arg*>(p);
-        threadIdx.x = a.lane; blockIdx.x = a.block; gridDim.x = a.grid;
-        (*a.body)();
-        return nullptr;
-      }}, &args[l]);
-    }}
-    for (int l = 0; l < 64; l++) pthread_join(th[l], nullptr);
-    pthread_barrier_destroy(&g_bar);
-  }}
-}}
+{_RUN_GRID}
 extern "C" __attribute__((visibility("default"))) void host_run(int blocked, int grid, double* x, double* P, const double* Q, const int32_t* kinds, const double* dts, int64_t T, double* z,
                          const double* R, int64_t n, int norm_quats, uint8_t* flags, double* tx, double* tP) {{
   if (blocked) run_grid(grid, [&] {{ k_run_blk(x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, nullptr); }});
@@ -592,3 +596,113 @@ def test_lane_per_filter_kernels_on_the_host(tmp_path, name):
   assert_close(xh[on], xr[on], rtol=1e-11, floor=1e-13, what=f"{name} masked step x")
   assert_close(Ph[on].reshape(int(on.sum()), -1), Pr[on].reshape(int(on.sum()), -1), rtol=1e-11, floor=1e-13, what=f"{name} masked step P")
   assert_close(zh[on], zr[on], rtol=1e-11, atol=1e-13 * max(1.0, np.abs(z0).max()), what=f"{name} masked step y")
+
+
+# ---- lane-group STEP KERNELS on the host (emit_wide2.kernels: k_predict, k_step_*<DO_PREDICT>) -------------------------------------
+# The whole kernels -- tile loop, scalar phase lane per filter, groups of filters through the matrix phase, error injection, masks,
+# flags -- with a workgroup as 64 threads.  The block copies between HBM and LDS are restated here by what they move (the device
+# versions differ in how: 16-byte vectors, asynchronous HBM -> LDS transfers); everything else is the generated text.
+
+_WIDE_COPIES = r"""
+template <int MAXD> inline void copy_g2l(const double* g, int nd, double* lds, int lane) { for (int i = lane; i < nd; i += 64) lds[i] = g[i]; }
+template <int MAXD, bool NT = false> inline void copy_l2g(double* g, int nd, const double* lds, int lane) { for (int i = lane; i < nd; i += 64) g[i] = lds[i]; }
+template <int MAXD> inline void async_copy_g2l(const double* g, int nd, double* lds, int lane) { copy_g2l<MAXD>(g, nd, lds, lane); }
+inline int odd_start(const double* g) { return (int)(((uintptr_t)g >> 3) & 1); }
+template <int MAXD> inline void async_copy_g2l_any(const double* g, int nd, double* lds, int lane) {      // image shifted by one double for odd starts
+  const int sh = odd_start(g);
+  for (int i = lane; i < nd; i += 64) lds[sh + i] = g[i];
+}
+template <int MAXD> inline void copy_l2g_any(double* g, int nd, const double* lds, int sh, int lane) { for (int i = lane; i < nd; i += 64) g[i] = lds[sh + i]; }
+inline void sched_barrier_(int) {}
+"""
+
+
+def _wide_kernel_host_library(tmp_path, spec):
+  from rednose_amd.codegen import emit_wide2, tuning
+  hdr = open(HDR, encoding="utf-8").read()
+  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "normalize_quat"))
+  with tuning.using_model(spec):
+    text = emit_wide2.kernels(spec)
+    FT = emit_wide2.tile_filters(spec)
+  text = re.sub(r'asm volatile\("" : "\+v"\((\w+)\)( :: "memory")?\);', ";", text)
+  text = text.replace("__builtin_amdgcn_sched_barrier", "rn::sched_barrier_")
+  # the scalar-phase functions run on the lanes that own a filter only; their wave_lds_sync() calls are scheduling boundaries for
+  # hipcc (a fence inside one wavefront), not rendezvous points -- as barriers they would wait for lanes that never come
+  text = re.sub(r"(\w+ scal_\w+\(.*?\n}\n)", lambda m: m.group(1).replace("rn::wave_lds_sync();", ";"), text, flags=re.S)
+  kinds = [k for k in spec.kinds if k.He_sym is None and k.ea_sym is None]
+  entries = []
+  for k in kinds:
+    entries.append(f"""
+extern "C" __attribute__((visibility("default"))) void host_wide_kernel_{k.kind}(int grid, int do_predict, double* x, double* P, double* z, const double* R,
+    int r_per_filter, const double* Q, const double* dt_vec, double dt, int64_t n, int norm_quats, uint8_t* flags, const uint8_t* active) {{
+  if (do_predict) run_grid(grid, [&] {{ k_step_{k.kind}<true>(x, P, z, R, r_per_filter, nullptr, Q, dt_vec, dt, n, norm_quats, flags, active); }});
+  else run_grid(grid, [&] {{ k_step_{k.kind}<false>(x, P, z, R, r_per_filter, nullptr, nullptr, nullptr, 0.0, n, norm_quats, flags, active); }});
+}}""")
+  prelude = _KERNEL_PRELUDE.replace("inline void pin(double&) {}", "inline void pin(double&) {}\n" + _WIDE_COPIES)
+  src = "\n".join([prelude, helpers, "}  // namespace rn", text, _RUN_GRID] + entries)
+  cpp, lib = tmp_path / f"{spec.name}_wide_kernels_host.cpp", tmp_path / f"lib{spec.name}_wide_kernels_host.so"
+  cpp.write_text(src, encoding="utf-8")
+  res = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fno-gnu-unique", "-fvisibility=hidden", "-Wno-unknown-pragmas", "-Wno-attributes",
+                        str(cpp), "-o", str(lib)], capture_output=True, text=True)
+  assert res.returncode == 0, res.stderr[-4000:]
+  return ctypes.CDLL(str(lib)), kinds, FT
+
+
+@pytest.mark.parametrize("name", ["kinematic9", "rand11", "live_maha"])
+def test_lane_group_step_kernels_on_the_host(tmp_path, name):
+  """k_step_*<true> / <false> of the lane-group family against the oracle: a batch that is not a multiple of the tile (ragged last
+  tile, odd filter counts in the last group), fewer workgroups than tiles, per-filter dt, a mask, gate flags."""
+  from oracle_lib import OracleLib
+  from rednose_amd.codegen.spec import build_spec
+  M, mdl, kw, quat_idx = _wide_model(name)
+  mdl = dict(mdl)
+  mdl["name"] = name
+  spec = build_spec(**mdl, **kw)
+  lib, kinds, FT = _wide_kernel_host_library(tmp_path, spec)
+  o = OracleLib(name)
+  D, E = spec.dim_x, spec.dim_err
+  rng = np.random.default_rng(E)
+  n, grid = 2 * FT + max(1, FT // 2) + (FT > 2), 2               # two full tiles and a ragged third one, on two workgroups
+  Q = np.ascontiguousarray(M.Q, dtype=np.float64)
+  x_init = np.asarray(M.initial_x, dtype=np.float64)
+  P_init = np.diag(M.initial_P_diag)
+  dp, bp = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_ubyte)
+  ptr = lambda a, t=dp: a.ctypes.data_as(t)      # noqa: E731
+  gated = 0
+  for k in kinds[:3] + [k_ for k_ in kinds[3:] if k_.maha_test]:      # (every kind runs in the function-level test above)
+    Z = k.zdim
+    R = np.ascontiguousarray(np.atleast_2d(M.obs_noise.get(k.kind, 0.01 * np.eye(Z))), dtype=np.float64)
+    x0 = np.tile(x_init, (n, 1)) + rng.normal(size=(n, D)) * 0.01 * np.maximum(1.0, np.abs(x_init))[None] * (np.abs(x_init)[None] < 10.0)
+    A = rng.normal(size=(n, E, E)) * 0.1 * np.sqrt(np.diag(P_init))[None, :, None]
+    P0 = P_init[None] + A @ A.transpose(0, 2, 1)
+    hx = np.zeros((n, Z))
+    for i in range(n):
+      xq = x0[i].copy()
+      if quat_idx >= 0:
+        xq[quat_idx:quat_idx + 4] /= np.linalg.norm(xq[quat_idx:quat_idx + 4])
+      o.call(f"h_{k.kind}", xq, np.zeros(4), hx[i])
+    far = rng.uniform(size=(n, 1)) < 0.34
+    z0 = hx + rng.normal(size=(n, Z)) * np.sqrt(np.diag(R))[None] + far * rng.normal(size=(n, Z)) * 40.0 * np.sqrt(P_init.max())
+    fn = getattr(lib, f"host_wide_kernel_{k.kind}")
+    fn.argtypes = [ctypes.c_int, ctypes.c_int, dp, dp, dp, dp, ctypes.c_int, dp, dp, ctypes.c_double, ctypes.c_int64, ctypes.c_int, bp, bp]
+    for mode in ("scalar dt", "dt = 0", "per-filter dt + mask", "update only"):
+      dtv = rng.uniform(0.0, 0.02, size=n)
+      act = (rng.uniform(size=n) < 0.6).astype(np.uint8)
+      xr, Pr, zr = x0.copy(), P0.copy(), z0.copy()
+      fr = np.zeros(n, dtype=np.uint8)
+      dt_o = {"scalar dt": 0.01, "dt = 0": 0.0, "per-filter dt + mask": dtv, "update only": 0.0}[mode]
+      o.batch_step(k.kind, xr, Pr, zr, R, Q, dt_o, quat_idx=quat_idx, flags=fr, do_predict=mode != "update only")
+      xh, Ph, zh, fl = x0.copy(), P0.copy(), z0.copy(), np.full(n, 99, dtype=np.uint8)
+      masked = mode == "per-filter dt + mask"
+      fn(grid, int(mode != "update only"), ptr(xh), ptr(Ph), ptr(zh), ptr(R), 0, ptr(Q), ptr(dtv) if masked else None,
+         0.01 if mode == "scalar dt" else 0.0, n, int(quat_idx >= 0), ptr(fl, bp), ptr(act, bp) if masked else None)
+      on = (act != 0) if masked else np.ones(n, dtype=bool)
+      what = f"{name} kind {k.kind} {mode}"
+      assert np.array_equal(xh[~on], x0[~on]) and np.array_equal(Ph[~on], P0[~on]) and np.array_equal(zh[~on], z0[~on]) and (fl[~on] == 16).all(), what + " masked-out filters"
+      assert np.array_equal(fl[on] & 1, fr[on] & 1), what + " gate flags"
+      gated += int((fl[on] & 1).sum())
+      m = int(on.sum())
+      assert_close(xh[on], xr[on], rtol=1e-10, floor=1e-12, what=what + " x")
+      assert_close(Ph[on].reshape(m, -1), Pr[on].reshape(m, -1), rtol=1e-9, floor=1e-11, what=what + " P")
+      assert_close(zh[on], zr[on], rtol=1e-10, atol=1e-12 * max(1.0, np.abs(z0).max()), what=what + " y")
+  assert (gated > 0) == (name == "live_maha")
