@@ -382,6 +382,8 @@ __global__ __launch_bounds__(64){kattr} void k_step_{k.kind}(double* __restrict_
   out.append(run_kernel(spec, norm))
   if run_block(spec) > 0:
     out.append(run_kernel_blk(spec, norm))
+    if tuning.current().run_block_trace:
+      out.append(run_kernel_blk(spec, norm, trace=True))
   return "\n".join(out)
 
 
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
 """
 
 
-def run_kernel_blk(spec, norm):
+def run_kernel_blk(spec, norm, trace=False):
   """The fused run without trace (tx == tP == nullptr), restructured around what the counters of k_run show for small models: the
   arithmetic of a step is tens of fp64 instructions, the step took thousands of cycles, because every step (a) waited for its own
   y store to retire -- vmcnt counts loads and stores in issue order, and the wait for the prefetched observation row behind the
@@ -520,7 +522,11 @@ def run_kernel_blk(spec, norm):
       K x zmax^2 doubles spread over the lanes; all broadcast with v_readlane when the step runs), are loaded while block b is computed -- ONE vmcnt(0) per block;
     * y (which replaces z in its registers) and the flags of block b are stored at the start of block b + 1, AFTER that wait, so no
       load the wavefront is waiting for ever queues behind a store it has just issued.
-  Same arithmetic as k_run (predict_regs / update_*_regs); results agree to the last bits (FMA contraction may differ per kernel)."""
+  Same arithmetic as k_run (predict_regs / update_*_regs); results agree to the last bits (FMA contraction may differ per kernel).
+
+  trace=True (experiment knob run_block_trace, off): the same structure writing the filtered trace -- every step's x / P leave through
+  the LDS image as coalesced stores that nothing waits for until the next block starts (k_run_blk_tr; the traced k_run pays the
+  per-step store wait this kernel was written to remove)."""
   D, E = spec.dim_x, spec.dim_err
   EE = E * E
   zmax = max(k.zdim for k in spec.kinds)
@@ -573,17 +579,31 @@ def run_kernel_blk(spec, norm):
           if (flags != nullptr) fp_[0] = (uint8_t)flb[u];
           yp_ += rowstride;
           fp_ += n;"""
-  return f"""
-__device__ __forceinline__ double lane_bcast(const double v, const int l) {{      // lane l's value in every lane (l uniform): two v_readlane_b32
+  helpers = "" if trace else """
+__device__ __forceinline__ double lane_bcast(const double v, const int l) {      // lane l's value in every lane (l uniform): two v_readlane_b32
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}}
-__device__ __forceinline__ void pin_i(int& v) {{ asm volatile("" : "+v"(v)); }}
-
-// ---- fused multi-step run without trace: blocks of {K} steps in registers (see emit_small.run_kernel_blk) -------------------
-__global__ __launch_bounds__(64) void k_run_blk(double* __restrict__ gx, double* __restrict__ gP, const double* __restrict__ gQ,
+}
+__device__ __forceinline__ void pin_i(int& v) { asm volatile("" : "+v"(v)); }
+"""
+  title = (f"// ---- fused multi-step run with the filtered trace: blocks of {K} steps, no store is waited for inside a block -----------------"
+           if trace else
+           f"// ---- fused multi-step run without trace: blocks of {K} steps in registers (see emit_small.run_kernel_blk) -------------------")
+  kname = "k_run_blk_tr" if trace else "k_run_blk"
+  targs = ",\n    double* __restrict__ tx, double* __restrict__ tP" if trace else ""
+  tstore = f"""
+          // filtered pair of step t: through the LDS image, coalesced; the stores drain under the following steps
+          rn::regs_to_lds<{D}>(s_x, lane, x);
+          rn::regs_to_lds<{EE}>(s_P, lane, P);
+          rn::wave_lds_sync();
+          if (tx != nullptr) rn::tile_l2g<{D}>(tx + (t * n + base) * {D}, cnt, s_x, lane);
+          if (tP != nullptr) rn::tile_l2g<{EE}>(tP + (t * n + base) * {EE}, cnt, s_P, lane);
+          rn::wave_lds_sync();""" if trace else ""
+  return f"""{helpers}
+{title}
+__global__ __launch_bounds__(64) void {kname}(double* __restrict__ gx, double* __restrict__ gP, const double* __restrict__ gQ,
     const int32_t* __restrict__ kinds, const double* __restrict__ dts, const int64_t T, double* gz,
     const double* __restrict__ gR, const int64_t n, const int norm_quats, uint8_t* __restrict__ flags,
-    const double* __restrict__ gea) {{
+    const double* __restrict__ gea{targs}) {{
   (void)gea;
   __shared__ __attribute__((aligned(16))) double s_x[64 * {D | 1}];
   __shared__ __attribute__((aligned(16))) double s_P[64 * {EE | 1}];
@@ -652,7 +672,7 @@ __global__ __launch_bounds__(64) void k_run_blk(double* __restrict__ gx, double*
             default: fl = 8; break;      // kind not available in the fused run (unknown, or it takes extra arguments)
           }}
           {norm}
-          flb[u] = fl;
+          flb[u] = fl;{tstore}
         }}
       }}
     }}
@@ -684,13 +704,18 @@ def launch_run(spec=None):
     return """  const int64_t tiles = (n + 63) >> 6;
   hipLaunchKernelGGL(k_run, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
                      x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P, ea, augment);"""
+  traced = """    hipLaunchKernelGGL(k_run, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                       x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P, ea, augment);"""
+  if tuning.current().run_block_trace:
+    traced = """    (void)augment;
+    hipLaunchKernelGGL(k_run_blk_tr, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                       x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, ea, trace_x, trace_P);"""
   return """  const int64_t tiles = (n + 63) >> 6;
   if (trace_x == nullptr && trace_P == nullptr) {
     hipLaunchKernelGGL(k_run_blk, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
                        x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, ea);
   } else {
-    hipLaunchKernelGGL(k_run, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
-                       x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P, ea, augment);
+""" + traced + """
   }"""
 
 

@@ -14,6 +14,7 @@ variants do not overwrite generated/).  What each alternative measured: profiles
   small_waves  amdgpu_waves_per_eu on the lane-per-filter step kernels
   small_max_e  largest error-state count served lane-per-filter
   nt_trace     1 = nontemporal stores for the fused run's covariance trace (lane-group models)
+  run_block_trace  1 = traced runs of lane-per-filter models use the blocked structure too (k_run_blk_tr; verified on the host only so far)
   run_block    steps per block of the lane-per-filter fused run without trace (0 = auto by model size, -1 = that kernel is not emitted)
   rts3_gl      lanes per filter of the emit_rts3 smoother (0 = the fused run's layout); rts3_lb: second argument of its __launch_bounds__
   rts3         1 = smoother of lane-group models in the fused run's layout (emit_rts3: 8 filters per wavefront), 0 = rn::k_rts_group
@@ -34,6 +35,7 @@ class Tuning:
   small_waves: int = 0
   small_max_e: int = 7
   run_block: int = 0
+  run_block_trace: int = 0
   rts3: int = 1
   rts3_gl: int = 0
   rts3_lb: int = 0

@@ -489,6 +489,11 @@ def _kernel_host_library(tmp_path, spec):
   D, E = spec.dim_x, spec.dim_err
   zmax = max(k.zdim for k in spec.kinds)
   k0 = spec.kinds[0]
+  blk_tr = """
+extern "C" __attribute__((visibility("default"))) void host_run_blk_tr(int grid, double* x, double* P, const double* Q, const int32_t* kinds, const double* dts, int64_t T,
+    double* z, const double* R, int64_t n, int norm_quats, uint8_t* flags, double* tx, double* tP) {
+  run_grid(grid, [&] { k_run_blk_tr(x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, nullptr, tx, tP); });
+}""" if "void k_run_blk_tr(" in text else ""
   launch = f"""
 {_RUN_GRID}
 extern "C" __attribute__((visibility("default"))) void host_run(int blocked, int grid, double* x, double* P, const double* Q, const int32_t* kinds, const double* dts, int64_t T, double* z,
@@ -496,6 +501,7 @@ extern "C" __attribute__((visibility("default"))) void host_run(int blocked, int
   if (blocked) run_grid(grid, [&] {{ k_run_blk(x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, nullptr); }});
   else run_grid(grid, [&] {{ k_run(x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, tx, tP, nullptr, nullptr); }});
 }}
+{blk_tr}
 extern "C" __attribute__((visibility("default"))) void host_step(int grid, double* x, double* P, double* z, const double* R, int r_per_filter, const double* Q, const double* dt_vec, double dt,
                           int64_t n, int norm_quats, uint8_t* flags, const uint8_t* active) {{
   run_grid(grid, [&] {{ k_step_{k0.kind}<true>(x, P, z, R, r_per_filter, nullptr, Q, dt_vec, dt, n, norm_quats, flags, active); }});
@@ -596,6 +602,50 @@ def test_lane_per_filter_kernels_on_the_host(tmp_path, name):
   assert_close(xh[on], xr[on], rtol=1e-11, floor=1e-13, what=f"{name} masked step x")
   assert_close(Ph[on].reshape(int(on.sum()), -1), Pr[on].reshape(int(on.sum()), -1), rtol=1e-11, floor=1e-13, what=f"{name} masked step P")
   assert_close(zh[on], zr[on], rtol=1e-11, atol=1e-13 * max(1.0, np.abs(z0).max()), what=f"{name} masked step y")
+
+
+def test_blocked_traced_run_on_the_host(tmp_path, monkeypatch):
+  """The experiment kernel k_run_blk_tr (knob run_block_trace): the blocked structure writing the filtered trace, bit for bit against
+  the traced k_run on ragged tiles and schedule lengths around the block size, gate flags included."""
+  from rednose_amd.codegen import emit_small
+  from rednose_amd.codegen.spec import build_spec
+  monkeypatch.setenv("RN_TUNE", "run_block_trace=1")
+  for name in ("kinematic", "kinematic6_maha"):
+    M, mdl, kw = _model(name)
+    spec = build_spec(**mdl, **kw)
+    lib, zmax = _kernel_host_library(tmp_path, spec)
+    D, E = spec.dim_x, spec.dim_err
+    K = emit_small.run_block(spec)
+    rng = np.random.default_rng(E + 3)
+    n, grid = 150, 2
+    Q = np.ascontiguousarray(M.Q, dtype=np.float64)
+    dp, ip, bp = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_ubyte)
+    ptr = lambda a, t=dp: a.ctypes.data_as(t)      # noqa: E731
+    lib.host_run.argtypes = [ctypes.c_int, ctypes.c_int, dp, dp, dp, ip, dp, ctypes.c_int64, dp, dp, ctypes.c_int64, ctypes.c_int, bp, dp, dp]
+    lib.host_run_blk_tr.argtypes = [ctypes.c_int, dp, dp, dp, ip, dp, ctypes.c_int64, dp, dp, ctypes.c_int64, ctypes.c_int, bp, dp, dp]
+    kd = spec.kinds[0]
+    Rk = np.atleast_2d(M.obs_noise[kd.kind])
+    for T in (1, K - 1, K, 2 * K + 1):
+      sched = np.full(T, kd.kind, dtype=np.int32)
+      dts = rng.uniform(0.005, 0.03, size=T)
+      Rt = np.tile(Rk.reshape(1, -1), (T, 1))
+      x0 = np.asarray(getattr(M, "initial_x", np.zeros(D)))[None] + rng.normal(size=(n, D)) * 0.3
+      A = rng.normal(size=(n, E, E)) * 0.2
+      P0 = np.diag(getattr(M, "initial_P_diag", np.ones(E)))[None] + A @ A.transpose(0, 2, 1)
+      zs = rng.normal(size=(T, n, zmax)) * np.where(rng.uniform(size=(T, n, 1)) < 0.2, 40.0, 0.5)
+      out = []
+      for which in ("k_run", "k_run_blk_tr"):
+        xh, Ph, zh = x0.copy(), P0.copy(), zs.copy()
+        fl = np.full((T, n), 99, dtype=np.uint8)
+        tx, tP = np.full((T + 2, n, D), 5.0), np.full((T + 2, n, E, E), 5.0)
+        if which == "k_run":
+          lib.host_run(0, grid, ptr(xh), ptr(Ph), ptr(Q), ptr(sched, ip), ptr(dts), T, ptr(zh), ptr(Rt), n, 0, ptr(fl, bp), ptr(tx[1]), ptr(tP[1]))
+        else:
+          lib.host_run_blk_tr(grid, ptr(xh), ptr(Ph), ptr(Q), ptr(sched, ip), ptr(dts), T, ptr(zh), ptr(Rt), n, 0, ptr(fl, bp), ptr(tx[1]), ptr(tP[1]))
+        assert (tx[0] == 5.0).all() and (tx[T + 1] == 5.0).all() and (tP[0] == 5.0).all() and (tP[T + 1] == 5.0).all()
+        out.append((xh, Ph, zh, fl, tx, tP))
+      for a, b in zip(*out):
+        assert np.array_equal(a, b), f"{name} T={T}"
 
 
 # ---- lane-group STEP KERNELS on the host (emit_wide2.kernels: k_predict, k_step_*<DO_PREDICT>) -------------------------------------
