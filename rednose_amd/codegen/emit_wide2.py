@@ -169,6 +169,26 @@ def _slotted(smat, var_list, off):
   return m
 
 
+def _in_registers(smat, name):
+  """-> (copy of `smat` whose named entries are `name[i]`, C statements loading them from where the original read them).  Used by
+  the experiment knob wide_lean_coef: every coefficient is read from the slot ONCE, all reads issued before the first use."""
+  m = SMat(smat.rows, smat.cols)
+  src = []
+  for i in range(smat.rows):
+    for j in range(smat.cols):
+      e = smat.e[i][j]
+      if e is not None and e[0] == 'var':
+        if e[1] not in src:
+          src.append(e[1])
+        m.e[i][j] = ('var', f"{name}[{src.index(e[1])}]")
+      else:
+        m.e[i][j] = e
+  if not src:
+    return m, []
+  loads = [f"double {name}[{len(src)}];"] + [f"{name}[{i}] = {v};" for i, v in enumerate(src)] + ["__builtin_amdgcn_sched_barrier(0);"]
+  return m, loads
+
+
 def _lean_update(k, Hs, lay, E, rows_in_regs=False):
   """Update with the Joseph correction Dm = K R - B He^T formed from Gt - K (He P He^T) (the same quantity, B = P - K G
   never materialised), only the columns of P that He touches read, and ONE pass over the lane's row:
@@ -183,6 +203,9 @@ def _lean_update(k, Hs, lay, E, rows_in_regs=False):
   Z = Zf - EADIM if feat else Zf
   used = sorted({kk for zi in range(Zf) for kk, _ in Hs.row_nz(zi)})
   b = [f"double R[{Z * Z}];", f"double* pr = sP + cc * {E};"]
+  if tuning.current().wide_lean_coef and not feat:
+    Hs, coef_loads = _in_registers(Hs, "hc")
+    b += coef_loads
   if rows_in_regs:
     b += [f"double row[{E}];", "#pragma unroll", f"for (int j = 0; j < {E}; j++) row[j] = pr[j];"]
     b += [f"const double col_{kk} = sP[{kk} * {E} + cc], row_{kk} = row[{kk}];" for kk in used]
@@ -353,14 +376,18 @@ def device_functions(spec, lay_cls=None, sfx=""):
   if lean_p:
     # rows, then columns, pass through ONE register array; every result goes straight back to LDS (in place: the lane's
     # own row / column is in registers, other lanes' are untouched), so nothing but the array stays live
-    b = [f"const double dt = sl[{lay.OFF_DT}];", f"double v[{E}];", "if (act) {", "#pragma unroll",
-         f"  for (int j = 0; j < {E}; j++) v[j] = sP[cc * {E} + j];"]
+    b = [f"const double dt = sl[{lay.OFF_DT}];", f"double v[{E}];"]
+    Fp = Fs
+    if tuning.current().wide_lean_coef:
+      Fp, coef_loads = _in_registers(Fs, "fc")
+      b += coef_loads
+    b += ["if (act) {", "#pragma unroll", f"  for (int j = 0; j < {E}; j++) v[j] = sP[cc * {E} + j];"]
     for i in range(E):
-      b.append(f"  sP[cc * {E} + {i}] = {sum_terms(term(cf, f'v[{kk}]') for kk, cf in Fs.row_nz(i))};")
+      b.append(f"  sP[cc * {E} + {i}] = {sum_terms(term(cf, f'v[{kk}]') for kk, cf in Fp.row_nz(i))};")
     b += ["}", "rn::wave_lds_sync();", "if (act) {", "#pragma unroll", f"  for (int k = 0; k < {E}; k++) v[k] = sP[k * {E} + cc];"]
     for i in range(E):
       qv = f"qcol[{i}]" if tuning.current().wide_lean_q else f"sQ[{i} * {E} + cc]"
-      b.append(f"  sP[{i} * {E} + cc] = {sum_terms(term(cf, f'v[{kk}]') for kk, cf in Fs.row_nz(i))} + dt*{qv};")
+      b.append(f"  sP[{i} * {E} + cc] = {sum_terms(term(cf, f'v[{kk}]') for kk, cf in Fp.row_nz(i))} + dt*{qv};")
     b += ["}", "rn::wave_lds_sync();"]
   else:
     b = [f"const double dt = sl[{lay.OFF_DT}];", f"double row[{E}], a[{E}], col[{E}];", "#pragma unroll",

@@ -189,7 +189,7 @@ extern "C" int host_wide_step_{k.kind}(double* x, double* P, const double* Q, do
   return fl;
 }}""")
   src = "\n".join(["#include <cmath>", "#include <cstdint>", "#include <pthread.h>", "#define __device__", "#define __forceinline__ inline",
-                   "#define __noinline__", "static pthread_barrier_t g_bar;", "static bool g_sync_on = false;", "namespace rn {",
+                   "#define __noinline__", "#define __builtin_amdgcn_sched_barrier(x)", "static pthread_barrier_t g_bar;", "static bool g_sync_on = false;", "namespace rn {",
                    "inline void wave_lds_sync() { if (g_sync_on) pthread_barrier_wait(&g_bar); }      // device: a compiler fence inside one wavefront",
                    "inline double fast_recip(const double d) { return 1.0 / d; }", helpers, "}  // namespace rn"] + fns + entry)
   cpp, lib = tmp_path / f"{spec.name}_wide_host.cpp", tmp_path / f"lib{spec.name}_wide_host.so"
@@ -268,6 +268,22 @@ def test_generated_lane_group_step_on_the_host(tmp_path, name):
       assert_close(Ph.reshape(n, -1), Pr.reshape(n, -1), rtol=1e-9, floor=1e-11, what=what + " P")
       assert_close(zh, zr, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(z0).max()), what=what + " y")
   assert (gated > 0) == (name == "live_maha")
+
+
+def test_lean_coefficient_batching_knob_on_the_host(tmp_path, monkeypatch):
+  """Experiment knob wide_lean_coef (slot coefficients of the lean matrix phase read once, up front): same results as the default
+  emission against the oracle, function level (all kinds of live) and kernel level (live_maha)."""
+  monkeypatch.setenv("RN_TUNE", "wide_lean_coef=1")
+  from rednose_amd.codegen import emit_wide2, tuning
+  from rednose_amd.codegen.spec import build_spec
+  M, mdl, kw, _ = _wide_model("live")
+  mdl = dict(mdl)
+  mdl["name"] = "live"
+  with tuning.using_model(build_spec(**mdl, **kw)):
+    text, _ = emit_wide2.device_functions(build_spec(**mdl, **kw))
+  assert "double fc[" in text and "double hc[" in text
+  test_generated_lane_group_step_on_the_host(tmp_path, "live")
+  test_lane_group_step_kernels_on_the_host(tmp_path, "live_maha")
 
 
 # ---- lane-group fused run (emit_wide3): GL lanes x R rows per filter, rows of P in registers for T steps ----------------------------
