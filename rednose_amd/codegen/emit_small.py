@@ -47,6 +47,12 @@ def predict_regs(spec):
   stmts, st = blk.lower()
   F = SMat.identity_padded(SMat.from_structure(M, M, st, fmtF), E)
 
+  # Experiment knob small_sym: P = P^T is taken for granted.  Only the upper triangle of P is read (U below), only the upper triangle of
+  # the result is formed, and the function ends by mirroring it -- register renames the compiler drops wherever the lower triangle is
+  # not consumed (the next function of the same kernel reads the upper triangle again).  -15 % fp64 instructions and 15 fewer live
+  # doubles for the 6-state model; results differ from the full product by the asymmetry of the input, i.e. by rounding.
+  sym = bool(tuning.current().small_sym)
+  U = (lambda i, j: f"P[{min(i, j) * E + max(i, j)}]") if sym else (lambda i, j: f"P[{i * E + j}]")      # noqa: E731
   body = list(stmts)
   # T = F P   (rows of F that are a bare unit diagonal alias the row of P)
   T = [[None] * E for _ in range(E)]
@@ -54,21 +60,23 @@ def predict_regs(spec):
     nz = F.row_nz(i)
     if len(nz) == 1 and nz[0][0] == i and nz[0][1][0] == 'one':
       for j in range(E):
-        T[i][j] = f"P[{i * E + j}]"
+        T[i][j] = U(i, j)
       continue
     for j in range(E):
-      body.append(f"const double T_{i}_{j} = {sum_terms(term(c, f'P[{k * E + j}]') for k, c in nz)};")
+      body.append(f"const double T_{i}_{j} = {sum_terms(term(c, U(k, j)) for k, c in nz)};")
       T[i][j] = f"T_{i}_{j}"
   # P' = T F^T + dt Q
   newP = []
   for i in range(E):
-    for j in range(E):
+    for j in range(i if sym else 0, E):
       s = sum_terms(term(c, T[i][k]) for k, c in F.row_nz(j))
       newP.append(f"const double Pn_{i}_{j} = {s} + dt*Q[{i * E + j}];")
   body += newP
   for i in range(E):
-    for j in range(E):
+    for j in range(i if sym else 0, E):
       body.append(f"P[{i * E + j}] = Pn_{i}_{j};")
+  if sym:
+    body += [f"P[{j * E + i}] = P[{i * E + j}];" for i in range(E) for j in range(i + 1, E)]
   for i in range(D):
     kind, val = st[f"xn_{i}"]
     body.append(f"x[{i}] = xn_{i};" if kind == 'expr' else f"x[{i}] = {float(val)!r};")
@@ -99,12 +107,14 @@ def update_regs(spec, k):
     kind, val = st[f"hx_{i}"]
     hx = f"hx_{i}" if kind == 'expr' else repr(float(val))
     b.append(f"const double y_{i} = z[{i}] - {hx};")
-  # G = He P ; Gt = He P^T
+  # G = He P ; Gt = He P^T   (knob small_sym: P = P^T, upper triangle only -- see predict_regs -- and Gt IS G)
+  sym = bool(tuning.current().small_sym)
+  U = (lambda i, j: f"P[{min(i, j) * E + max(i, j)}]") if sym else (lambda i, j: f"P[{i * E + j}]")      # noqa: E731
   for zi in range(Z):
     nz = He.row_nz(zi)
     for j in range(E):
-      b.append(f"const double G_{zi}_{j} = {sum_terms(term(c, f'P[{kk * E + j}]') for kk, c in nz)};")
-      b.append(f"const double Gt_{zi}_{j} = {sum_terms(term(c, f'P[{j * E + kk}]') for kk, c in nz)};")
+      b.append(f"const double G_{zi}_{j} = {sum_terms(term(c, U(kk, j)) for kk, c in nz)};")
+      b.append(f"const double Gt_{zi}_{j} = " + (f"G_{zi}_{j};" if sym else f"{sum_terms(term(c, f'P[{j * E + kk}]') for kk, c in nz)};"))
   # HPHt, S, Cholesky, optional gate
   b.append(f"double HPH[{Z * Z}], Rl[{Z * Z}], S[{Z * Z}], L[{Z * Z}], iL[{Z}];")
   for zi in range(Z):
@@ -142,9 +152,16 @@ def update_regs(spec, k):
     eblk.add(f"xi_{i}", sp.Matrix(spec.err_eqs[0])[i])
   estmts, est = eblk.lower()
   b += estmts
-  # B = P - K G (in place)
+  # B = P - K G (in place).  small_sym: B = (I - K He) P is NOT symmetric -- its upper triangle is needed for the result and the
+  # columns He touches for C below, all rows of those; an entry below the diagonal starts from its mirror image and lives in the
+  # (otherwise unused) lower half of the array until the final mirroring overwrites it.
+  hcols = sorted({j for zi in range(Z) for j, _ in He.row_nz(zi)})
+  if sym:       # the entries below the diagonal first: they start from upper-triangle values the in-place pass below overwrites
+    for i in range(E):
+      for j in (c_ for c_ in hcols if c_ < i):
+        b.append(f"P[{i * E + j}] = {U(i, j)} - (" + " + ".join(f"{K(i, zi)}*G_{zi}_{j}" for zi in range(Z)) + ");")
   for i in range(E):
-    for j in range(E):
+    for j in range(i if sym else 0, E):
       b.append(f"P[{i * E + j}] -= " + " + ".join(f"{K(i, zi)}*G_{zi}_{j}" for zi in range(Z)) + ";")
   # C = B He^T, D = K R - C
   for i in range(E):
@@ -153,8 +170,10 @@ def update_regs(spec, k):
       kr = " + ".join(f"{K(i, w)}*Rl[{w * Z + zi}]" for w in range(Z))
       b.append(f"const double Dm_{i}_{zi} = ({kr}) - ({c});")
   for i in range(E):
-    for j in range(E):
+    for j in range(i if sym else 0, E):
       b.append(f"P[{i * E + j}] += " + " + ".join(f"Dm_{i}_{zi}*{K(j, zi)}" for zi in range(Z)) + ";")
+  if sym:
+    b += [f"P[{j * E + i}] = P[{i * E + j}];" for i in range(E) for j in range(i + 1, E)]
   for i in range(D):
     kind, val = est[f"xi_{i}"]
     b.append(f"x[{i}] = xi_{i};" if kind == 'expr' else f"x[{i}] = {float(val)!r};")

@@ -14,6 +14,8 @@ variants do not overwrite generated/).  What each alternative measured: profiles
                where each is used (experiment: candidates section of profiles/tuning_notes.md)
   wide_lean_unroll  unroll factor of the lean update's in-place row pass (2: a few dozen live registers; more: its LDS reads overlap)
   wide_lean_q  1 = the lean predict takes its column of Q from registers instead of an LDS copy
+  small_sym    1 = lane-per-filter arithmetic on the upper triangle of P (P = P^T taken for granted, mirrored at the end of predict /
+               update): experiment, see emit_small.predict_regs
   small_waves  amdgpu_waves_per_eu on the lane-per-filter step kernels
   small_max_e  largest error-state count served lane-per-filter
   nt_trace     1 = nontemporal stores for the fused run's covariance trace (lane-group models)
@@ -39,6 +41,7 @@ class Tuning:
   wide_lean_unroll: int = 2
   small_waves: int = 0
   small_max_e: int = 7
+  small_sym: int = 0
   run_block: int = 0
   run_block_trace: int = 0
   rts3: int = 1

@@ -904,3 +904,19 @@ def test_lane_group_fused_run_kernel_on_the_host(tmp_path, name):
 # that inside its scheduling regions.  Threads and barriers at rn::wave_lds_sync() do not reproduce it: a first attempt matched the
 # reference's recursion exactly for the newest two estimates and raced on the older ones.  The fused-run test above
 # repeats its launch and compares bit for bit: the kernels emulated here do not depend on that.
+
+
+def test_symmetric_arithmetic_knob_on_the_host(tmp_path, monkeypatch):
+  """Experiment knob small_sym (lane-per-filter arithmetic on the upper triangle of P): against the oracle at function level for every
+  small model (the oracle's inputs are symmetric, so only rounding differs), and through the whole kernels; the results are exactly
+  symmetric."""
+  monkeypatch.setenv("RN_TUNE", "small_sym=1")
+  from rednose_amd.codegen import emit_small
+  from rednose_amd.codegen.spec import build_spec
+  M, mdl, kw = _model("kinematic6")
+  text = emit_small.update_regs(build_spec(**mdl, **kw), build_spec(**mdl, **kw).kinds[0])[0]
+  assert "const double Gt_0_0 = G_0_0;" in text
+  for name in ("kinematic", "kinematic6", "kinematic6_maha", "rand3", "rand5", "randaff5"):
+    test_generated_lane_per_filter_arithmetic_on_the_host(tmp_path, name)
+  for name in ("kinematic", "kinematic6_maha", "rand3"):
+    test_lane_per_filter_kernels_on_the_host(tmp_path, name)
