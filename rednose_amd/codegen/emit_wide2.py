@@ -209,6 +209,8 @@ def _lean_update(k, Hs, lay, E, rows_in_regs=False):
   if rows_in_regs:
     b += [f"double row[{E}];", "#pragma unroll", f"for (int j = 0; j < {E}; j++) row[j] = pr[j];"]
     b += [f"const double col_{kk} = sP[{kk} * {E} + cc], row_{kk} = row[{kk}];" for kk in used]
+  elif tuning.current().wide_lean_sym and not feat:
+    b += [f"const double row_{kk} = pr[{kk}], col_{kk} = row_{kk};      // P = P^T: column cc of P is the lane's own row" for kk in used]
   else:
     b += [f"const double col_{kk} = sP[{kk} * {E} + cc], row_{kk} = pr[{kk}];" for kk in used]
   if feat:

@@ -12,6 +12,7 @@ variants do not overwrite generated/).  What each alternative measured: profiles
   wide_lean    1 = covariance rows stay in LDS (register-lean structure, two wavefronts per SIMD)
   wide_lean_coef  1 = the lean matrix phase reads its slot coefficients (non-zeros of F, of He) into registers once, up front, instead of
                where each is used (experiment: candidates section of profiles/tuning_notes.md)
+  wide_lean_sym  1 = the lean update takes G = He P from the lane's own ROW of P (P = P^T): no strided column reads (experiment)
   wide_lean_unroll  unroll factor of the lean update's in-place row pass (2: a few dozen live registers; more: its LDS reads overlap)
   wide_lean_q  1 = the lean predict takes its column of Q from registers instead of an LDS copy
   small_sym    1 = lane-per-filter arithmetic on the upper triangle of P (P = P^T taken for granted, mirrored at the end of predict /
@@ -38,6 +39,7 @@ class Tuning:
   wide_lean: int = 0
   wide_lean_q: int = 0
   wide_lean_coef: int = 0
+  wide_lean_sym: int = 0
   wide_lean_unroll: int = 2
   small_waves: int = 0
   small_max_e: int = 7

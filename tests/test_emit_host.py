@@ -271,9 +271,10 @@ def test_generated_lane_group_step_on_the_host(tmp_path, name):
 
 
 def test_lean_coefficient_batching_knob_on_the_host(tmp_path, monkeypatch):
-  """Experiment knob wide_lean_coef (slot coefficients of the lean matrix phase read once, up front): same results as the default
-  emission against the oracle, function level (all kinds of live) and kernel level (live_maha)."""
-  monkeypatch.setenv("RN_TUNE", "wide_lean_coef=1")
+  """Experiment knobs of the lean matrix phase together -- slot coefficients read once, up front (wide_lean_coef); G taken from the
+  lane's own row of P (wide_lean_sym); the row pass fully unrolled -- against the oracle, function level (all kinds of live) and
+  kernel level (live_maha)."""
+  monkeypatch.setenv("RN_TUNE", "wide_lean_coef=1,wide_lean_sym=1,wide_lean_unroll=22")
   from rednose_amd.codegen import emit_wide2, tuning
   from rednose_amd.codegen.spec import build_spec
   M, mdl, kw, _ = _wide_model("live")
@@ -281,7 +282,7 @@ def test_lean_coefficient_batching_knob_on_the_host(tmp_path, monkeypatch):
   mdl["name"] = "live"
   with tuning.using_model(build_spec(**mdl, **kw)):
     text, _ = emit_wide2.device_functions(build_spec(**mdl, **kw))
-  assert "double fc[" in text and "double hc[" in text
+  assert "double fc[" in text and "double hc[" in text and "P = P^T: column cc of P is the lane's own row" in text and "#pragma unroll 22" in text
   test_generated_lane_group_step_on_the_host(tmp_path, "live")
   test_lane_group_step_kernels_on_the_host(tmp_path, "live_maha")
 
