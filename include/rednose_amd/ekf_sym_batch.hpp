@@ -175,6 +175,17 @@ class EKFSymBatch {
     pf_init();
     PerFilter& s = pf_;
     const int K = rewind_to_keep_;
+    // everything that can be refused is refused HERE, before the rings, the filter times or x / P are touched: a call that throws
+    // leaves the object as it was.  (Kinds with different extra-argument counts are refused once, in pf_init; a pending observation
+    // was accepted by these same checks when it first arrived.)
+    if (s.ead_of.at(kind) > 0 && ea_dev == nullptr)
+      throw std::runtime_error("rednose_amd: kind " + std::to_string(kind) + " takes extra arguments: ea_dev is null");
+    for (int64_t i = 0; i < n_; i++) {
+      const bool on = active_host ? active_host[i] != 0 : true;
+      if (on && K <= 0 && !std::isnan(s.ft[i]) && t_host[i] < s.ft[i])
+        throw std::runtime_error("rednose_amd: dt < 0 for a filter and no rewind ring (rewind_to_keep = 0)");
+    }
+    rtable_gc();
     std::vector<uint8_t> act(n_, 1), restore(n_, 0);
     if (active_host) act.assign(active_host, active_host + n_);
     std::fill(s.ignored.begin(), s.ignored.end(), 0);
@@ -235,16 +246,23 @@ class EKFSymBatch {
         hip(hipMemcpy2DAsync(s.zpack, sizeof(double) * Zk, s.stage_z[cur], sizeof(double) * s.zmax, sizeof(double) * Zk, n_,
                              hipMemcpyDeviceToDevice, stream_), "pack z");
         upload(s.Rn, Rn.data(), sizeof(double) * Rn.size());
-        const int ek = sym<int (*)(int)>("kind_eadim")(k);
-        if (ek != 0 && ek != s.ead) throw std::runtime_error("rednose_amd: kinds with different extra-argument counts are not supported by the per-filter ring");
+        const int ek = s.ead_of.at(k);
         masked_step(tq, ra, k, Zk, s.zpack, s.Rn, 1, nullptr, ek ? s.stage_ea[cur] : nullptr, rq);
       }
       cur ^= 1;
+    }
+    // flag bit 5 (include/rednose_amd_filter.h): "observation too old for this filter's ring, ignored" -- on top of bit 4, which
+    // the kernel set for every filter that was not active in the launch
+    if (flags_dev != nullptr && n_ignored > 0) {
+      static const uint8_t k_ignored = 16 | 32;
+      for (int64_t i = 0; i < n_; i++)
+        if (s.ignored[i]) hip(hipMemcpyAsync(flags_dev + i, &k_ignored, 1, hipMemcpyHostToDevice, stream_), "flag ignored");
     }
     return n_ignored;
   }
   const std::vector<double>& filter_times() const { return pf_.ft; }          // NaN: the filter has not stepped yet
   const std::vector<uint8_t>& ignored() const { return pf_.ignored; }         // 1: the last per-filter call ignored this filter's observation
+  size_t noise_table_size() const { return pf_.rtable.size(); }              // distinct R matrices kept for the per-filter rings (bounded: rtable_gc)
 
   // MSCKF window shift on every filter (libraries generated with msckf_params only)
   void augment() {
@@ -339,7 +357,9 @@ class EKFSymBatch {
     std::vector<int32_t> head, len;          // circular ring position per filter
     std::vector<double> rt;                  // (K, N) checkpoint times
     std::vector<int32_t> rkind, rridx;       // (K, N) observation kind / index into rtable
-    std::vector<std::vector<double>> rtable; // distinct noise matrices seen so far (row-major Z x Z)
+    std::vector<std::vector<double>> rtable; // distinct noise matrices referenced by live ring slots (row-major Z x Z), see rtable_gc
+    size_t rtable_gc_at = 64;
+    std::map<int, int> ead_of;               // extra arguments per kind
     double *ring_x = nullptr, *ring_P = nullptr, *ring_z = nullptr, *ring_ea = nullptr;      // (K, N, rec) device
     double *dt = nullptr, *Rn = nullptr, *zpack = nullptr;
     double* stage_z[2] = {nullptr, nullptr};
@@ -356,8 +376,12 @@ class EKFSymBatch {
     if (s.ready) return;
     for (auto& kv : zdim_) {
       s.zmax = std::max(s.zmax, kv.second);
-      s.ead = std::max(s.ead, sym<int (*)(int)>("kind_eadim")(kv.first));
+      s.ead_of[kv.first] = sym<int (*)(int)>("kind_eadim")(kv.first);
+      s.ead = std::max(s.ead, s.ead_of[kv.first]);
     }
+    for (auto& kv : s.ead_of)
+      if (kv.second != 0 && kv.second != s.ead)
+        throw std::runtime_error("rednose_amd: kinds with different extra-argument counts are not supported by the per-filter ring");
     s.ft.assign(n_, filter_time_);
     s.ignored.assign(n_, 0);
     s.head.assign(n_, 0);
@@ -391,6 +415,24 @@ class EKFSymBatch {
   // one array of a checkpoint, every filter at its own ring position (slot vector and mask already on the device)
   void ring_copy(double* ring, int64_t ring_stride, double* flat, int64_t flat_stride, int64_t rec, bool to_ring) {
     check(ring_copy_(ring, ring_stride, flat, flat_stride, rec, pf_.slot, pf_.act, n_, to_ring ? 1 : 0, stream_), "batch_ring_copy");
+  }
+  // The table of distinct noise matrices would grow without bound under a time-varying R (one entry per call).  Entries that no
+  // live ring slot references any more are dropped once the table has doubled since the last sweep: O(K N) then, amortised O(1).
+  void rtable_gc() {
+    PerFilter& s = pf_;
+    if (s.rtable.size() < s.rtable_gc_at) return;
+    const int K = rewind_to_keep_;
+    std::vector<int> remap(s.rtable.size(), -1);
+    std::vector<std::vector<double>> kept;
+    for (int64_t i = 0; i < n_ && K > 0; i++) {
+      for (int32_t j = 0; j < s.len[i]; j++) {
+        int32_t& r = s.rridx[(size_t)((s.head[i] + j) % K) * n_ + i];
+        if (remap[r] < 0) { remap[r] = (int)kept.size(); kept.push_back(std::move(s.rtable[r])); }
+        r = remap[r];
+      }
+    }
+    s.rtable.swap(kept);
+    s.rtable_gc_at = std::max<size_t>(64, 2 * s.rtable.size());
   }
   int rtable_index(const double* R, int Z) {
     for (size_t i = 0; i < pf_.rtable.size(); i++)

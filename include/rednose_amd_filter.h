@@ -21,6 +21,24 @@
  *     {name}_last_error() / {name}_last_error_string() report the last failure of the calling thread,
  *     including failures inside the void section-1 functions.
  *   - there is no CPU implementation behind any of these symbols.
+ *
+ * Asymmetric covariances.  The reference never symmetrises P: its predict and update multiply with both halves, and its
+ * innovation covariance S = H P H^T + R is solved as a general matrix (ekf_c.c:24,100-101,115) -- a P that is not exactly
+ * symmetric (its own Joseph form leaves ~1e-12 of asymmetry after a few thousand steps) is a legal input.  What each entry
+ * point does with one (tests/test_gpu_asymmetric.py feeds SPD + a skew part through every one of them):
+ *   - step-granular entry points -- the section-1 functions, batch_predict, batch_update_k, batch_predict_update_k, their
+ *     _masked twins, batch_maha_k -- follow the reference entry for entry: both halves of P, S factored as a general matrix
+ *     (L D U, no pivoting).  Same input, same result as the oracle to 1e-10 of the row maximum, symmetric or not.
+ *   - batch_run keeps P in registers for T steps with arithmetic that uses P = P^T (one transposition per predict, the gain
+ *     taken from the rows).  It reads (P + P^T) / 2 of the caller's matrix, ONCE, when the state enters the registers; the
+ *     result is the reference's on THAT matrix, to rounding.  Against the reference run on the asymmetric matrix itself the
+ *     difference is first order in (P - P^T) / 2, like any perturbation of P0 of that size.  The final P and the covariance
+ *     trace come back symmetric to rounding (lane-per-filter models: exactly).
+ *   - batch_rts factors the predicted covariance by Cholesky and keeps Pk1_n - Pk1_k as a packed triangle.  It reads the
+ *     LOWER triangle (diagonal included) of every covariance it is given -- Pf[k], P_last -- mirrored, for the gain Ck and
+ *     the correction Ck (Pk1_n - Pk1_k) Ck^T; the filtered covariance itself enters the sum as given:
+ *     Ps[k] = Pf[k] + correction.  On a trace written by batch_run (symmetric to rounding) that is the reference's
+ *     rts_smooth to rounding.
  */
 #ifndef REDNOSE_AMD_FILTER_H
 #define REDNOSE_AMD_FILTER_H
@@ -84,6 +102,8 @@ extern "C" {
 #define RN_DECLARE_BATCH_RUN(name)                                                                               \
   int RN_FN(name, zmax)(void);                        /* largest Z over the kinds: row stride of z in batch_run  */  \
   int RN_FN(name, run_unroll)(void);                  /* steps per iteration of batch_run's loop (instruction accounting) */ \
+  int RN_FN(name, has_batch_run)(void);               /* 0: the fused kernel of this model did not fit the register file -- batch_run \
+                                                         returns 4 (unsupported); walk the schedule with batch_predict_update_k */ \
   /* T predict+update steps in ONE launch, x and P resident on chip between steps.  kinds (T) int32, dts (T),   \
    * R (T, zmax*zmax; the leading Z*Z entries of row t are that step's row-major R) and z (T, n, zmax; in: z,   \
    * out: y) are DEVICE arrays; the schedule is shared by all filters.  flags (T, n), trace_x (T, n, D) and      \

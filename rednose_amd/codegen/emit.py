@@ -363,6 +363,10 @@ int {name}_batch_predict_update_{k.kind}{sfx}(double *x, double *P, const double
   unroll = (emit_small.run_block(spec) or emit_small.run_unroll(spec)) if fam == "small" else 1
   abi.append(f"int {name}_run_unroll(void) {{ return {unroll}; }}")
   hdr.append(f"int {name}_run_unroll(void);")
+  # 0: this model's fused multi-step kernel did not fit the register file (fallback no_run) -- {name}_batch_run returns ERR_UNSUPPORTED
+  # and callers walk a schedule with the step-granular entry points (BatchedEKF.run does)
+  abi.append(f"int {name}_has_batch_run(void) {{ return {int(has_run)}; }}")
+  hdr.append(f"int {name}_has_batch_run(void);")
   abi.append(f"""int {name}_batch_run(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts, int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, double *trace_x, double *trace_P, const double *ea, const int32_t *augment, void *stream) {{
   RN_REQUIRE(n >= 0 && T >= 0 && x && P && Q && kinds && dts && z && R, rn::ERR_ARG);
   if (n == 0 || T == 0) return rn::OK;
@@ -382,10 +386,9 @@ int {name}_batch_predict_update_{k.kind}{sfx}(double *x, double *P, const double
   hipLaunchKernelGGL(rn::k_rts_group<RtsModel>, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
                      xf, Pf, ts, T, Q, n, norm_quats, xs, Ps, x_last, P_last);"""
     else:
-      launch = """  (void)x_last; (void)P_last;      // ordinary lane-per-filter models: the predicted pair of the last step is recomputed exactly
-  const int64_t tiles = (n + 1) / 2;
+      launch = """  const int64_t tiles = (n + 1) / 2;
   hipLaunchKernelGGL(rn::k_rts<RtsModel>, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
-                     xf, Pf, ts, T, Q, n, norm_quats, xs, Ps);"""
+                     xf, Pf, ts, T, Q, n, norm_quats, xs, Ps, x_last, P_last);"""
     abi.append(f"""int {name}_batch_rts(const double *xf, const double *Pf, const double *ts, int64_t T, const double *Q, int64_t n, int norm_quats, double *xs, double *Ps, const double *x_last, const double *P_last, void *stream) {{
   RN_REQUIRE(n >= 0 && T >= 0 && xf && Pf && ts && Q && xs && Ps, rn::ERR_ARG);
   if (n == 0 || T == 0) return rn::OK;

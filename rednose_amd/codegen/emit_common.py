@@ -113,3 +113,26 @@ def routine_device_function(routine):
   text += ["  " + s for s in stmts]
   text.append("}")
   return "\n".join(text), params, n_out
+
+
+def innovation_solver(Z, general, y_terms, thresh=None):
+  """Text pieces for the Z x Z innovation covariance S held in `S` (with `HPH`, `Rl` beside it): -> (factor, gate, solve) where
+  `factor` factors S into (L, iL), `gate` (when `thresh` is given) is the Mahalanobis test of ekf_c.c:88-94 on the residual `y_terms`
+  -- R *= 1e16 and a second factorisation when it trips --, and `solve(v)` is the call that overwrites the array v with S^-1 v.
+  general=True: S is taken as a general matrix (L D U, templates/ekf_hip_rt.h: ldu_*) -- the step-granular kernels, which follow the
+  reference on asymmetric covariances; False: L D L^T from the lower triangle (spd_*) -- the fused multi-step kernels, whose covariance
+  is symmetric by contract."""
+  pre = "rn::ldu" if general else "rn::spd"
+  factor = f"{pre}_factor<{Z}>(S, L, iL);"
+  gate = []
+  if thresh is not None:
+    ys = ", ".join(y_terms)
+    if general:
+      gate = ["{", f"  double v[{Z}] = {{{ys}}}, w[{Z}] = {{{ys}}};", f"  rn::ldu_forward<{Z}>(L, iL, v);", f"  rn::ldu_forward_t<{Z}>(L, iL, w);",
+              "  const double d2 = " + " + ".join(f"v[{i}]*w[{i}]*iL[{i}]" for i in range(Z)) + ";"]
+    else:
+      gate = ["{", f"  double v[{Z}] = {{{ys}}};", f"  rn::spd_forward<{Z}>(L, iL, v);",
+              "  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";"]
+    gate += [f"  if (d2 > {thresh!r}) {{", "    gated = 1;", "#pragma unroll",
+             f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}", f"    {factor}", "  }", "}"]
+  return factor, gate, (lambda v: f"{pre}_solve<{Z}>(L, iL, {v});")

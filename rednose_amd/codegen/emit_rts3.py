@@ -222,9 +222,21 @@ __global__ {bounds} void k_rts3(const double* __restrict__ xf, const double* __r
   A("      rn::wave_lds_sync();")
   A(f"      {rows_decl('a')}      // rows of Pk_k, then Pk1_k / its factor, then T")
   A(f"      {rows_decl('y')}      // right-hand sides (rows of A = Pk_k Fk^T), then rows of Ck")
+  # Contract of batch_rts (include/rednose_amd_filter.h): the LOWER triangle of every covariance it is given is read, mirrored.  The
+  # recursion below uses P = P^T throughout (one transposition in the predict, Cholesky factor and D as packed lower triangles), so
+  # the rows are taken from the lower triangle here: entry j of row r is P[r][j] for j <= r and P[j][r] above the diagonal.  A slot's
+  # columns left of its diagonal block are plain row reads, right of it column reads (the group's lanes read consecutive doubles),
+  # the diagonal block selects per lane.  Same number of LDS reads as taking the rows as they are.
   for s in S:
+    lo, hi = GL * s, min(E, GL * s + GL)
+    if lo:
+      A("#pragma unroll")
+      A(f"      for (int j = 0; j < {lo}; j++) a{s}[j] = sI[rc{s} * {E} + j];")
     A("#pragma unroll")
-    A(f"      for (int j = 0; j < {E}; j++) a{s}[j] = sI[rc{s} * {E} + j];")
+    A(f"      for (int j = {lo}; j < {hi}; j++) a{s}[j] = sI[(j <= rc{s}) ? rc{s} * {E} + j : j * {E} + rc{s}];")
+    if hi < E:
+      A("#pragma unroll")
+      A(f"      for (int j = {hi}; j < {E}; j++) a{s}[j] = sI[j * {E} + rc{s}];")
   A("      rn::wave_lds_sync();      // every lane has its rows: the image takes A")
   A("      RN_RTS_STAMP(2);")
   A("      // ---- C. rows of A = Pk_k Fk^T (row-local, F's structural zeros cost nothing): the right-hand sides, and through the")
@@ -543,13 +555,8 @@ __global__ {bounds} void k_rts3(const double* __restrict__ xf, const double* __r
   return "\n".join(b)
 
 
-def launch(spec=None):
-  from rednose_amd.codegen import tuning
-  if spec is not None and tuning.current().rts3_gl:
-    fpw = layout(spec)[2]
-    return f"""  const int64_t tiles = (n + {fpw - 1}) / {fpw};
-  hipLaunchKernelGGL(k_rts3, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
-                     xf, Pf, ts, T, Q, n, norm_quats, xs, Ps, x_last, P_last);"""
-  return """  const int64_t tiles = (n + FPWR - 1) / FPWR;
+def launch(spec):
+  fpw = layout(spec)[2]
+  return f"""  const int64_t tiles = (n + {fpw - 1}) / {fpw};
   hipLaunchKernelGGL(k_rts3, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
                      xf, Pf, ts, T, Q, n, norm_quats, xs, Ps, x_last, P_last);"""

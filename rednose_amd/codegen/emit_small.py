@@ -25,7 +25,7 @@ import sympy as sp
 
 from rednose_amd.codegen import tuning
 from rednose_amd.codegen.lower import Block, vector_names
-from rednose_amd.codegen.emit_common import SMat, term, sum_terms
+from rednose_amd.codegen.emit_common import SMat, term, sum_terms, innovation_solver
 
 
 def _ind(lines, n=2):
@@ -33,8 +33,15 @@ def _ind(lines, n=2):
   return [pad + s for s in lines]
 
 
-def predict_regs(spec):
-  """-> text of `predict_regs(x, P, Q, dt)` operating on registers."""
+def predict_regs(spec, sym=False):
+  """-> text of `predict_regs(x, P, Q, dt)` operating on registers.
+
+  sym=True emits `predict_regs_sym` for the fused multi-step kernels (k_run*), whose contract is a SYMMETRIC covariance: they read
+  (P + P^T) / 2 of the caller's matrix once, when the state enters the registers (include/rednose_amd_filter.h), and from then on only
+  the upper triangle is read and formed, mirrored at the end of every function -- register renames the compiler drops wherever the
+  lower triangle is not consumed.  kinematic6: 548 -> 446 fp64 instructions per step, 42 -> 56 G steps/s in the blocked run (MI355X,
+  same call).  The step-granular kernels keep the full product: they use both halves of P exactly as the reference does
+  (ekf_c.c:24)."""
   D, E, M = spec.dim_x, spec.dim_err, spec.dim_main_err
   names = {**vector_names(spec.x_sym, 'x'), spec.dt_sym: 'dt'}
   blk = Block(names, tmp_prefix="pt")
@@ -47,11 +54,6 @@ def predict_regs(spec):
   stmts, st = blk.lower()
   F = SMat.identity_padded(SMat.from_structure(M, M, st, fmtF), E)
 
-  # Experiment knob small_sym: P = P^T is taken for granted.  Only the upper triangle of P is read (U below), only the upper triangle of
-  # the result is formed, and the function ends by mirroring it -- register renames the compiler drops wherever the lower triangle is
-  # not consumed (the next function of the same kernel reads the upper triangle again).  -15 % fp64 instructions and 15 fewer live
-  # doubles for the 6-state model; results differ from the full product by the asymmetry of the input, i.e. by rounding.
-  sym = bool(tuning.current().small_sym)
   U = (lambda i, j: f"P[{min(i, j) * E + max(i, j)}]") if sym else (lambda i, j: f"P[{i * E + j}]")      # noqa: E731
   body = list(stmts)
   # T = F P   (rows of F that are a bare unit diagonal alias the row of P)
@@ -80,13 +82,13 @@ def predict_regs(spec):
   for i in range(D):
     kind, val = st[f"xn_{i}"]
     body.append(f"x[{i}] = xn_{i};" if kind == 'expr' else f"x[{i}] = {float(val)!r};")
-  head = (f"__device__ __forceinline__ void predict_regs(double (&x)[{D}], double (&P)[{E * E}], "
+  head = (f"__device__ __forceinline__ void predict_regs{'_sym' if sym else ''}(double (&x)[{D}], double (&P)[{E * E}], "
           "const double* Q, const double dt) {")
   return "\n".join([head] + _ind(body) + ["}"]), F
 
 
-def update_regs(spec, k):
-  """-> text of `update_<kind>_regs(x, P, z, R)`; returns the gate flag."""
+def update_regs(spec, k, sym=False):
+  """-> text of `update_<kind>_regs(x, P, z, R)`; returns the gate flag.  sym=True: `update_<kind>_regs_sym`, see predict_regs."""
   D, E, Z = spec.dim_x, spec.dim_err, k.zdim
   names = dict(vector_names(spec.x_sym, 'x'))
   if k.ea_sym is not None:
@@ -107,8 +109,7 @@ def update_regs(spec, k):
     kind, val = st[f"hx_{i}"]
     hx = f"hx_{i}" if kind == 'expr' else repr(float(val))
     b.append(f"const double y_{i} = z[{i}] - {hx};")
-  # G = He P ; Gt = He P^T   (knob small_sym: P = P^T, upper triangle only -- see predict_regs -- and Gt IS G)
-  sym = bool(tuning.current().small_sym)
+  # G = He P ; Gt = He P^T   (sym: P = P^T, upper triangle only -- see predict_regs -- and Gt IS G)
   U = (lambda i, j: f"P[{min(i, j) * E + max(i, j)}]") if sym else (lambda i, j: f"P[{i * E + j}]")      # noqa: E731
   for zi in range(Z):
     nz = He.row_nz(zi)
@@ -122,24 +123,14 @@ def update_regs(spec, k):
       b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(c, f'G_{zi}_{j}') for j, c in He.row_nz(w))};")
   b.append("#pragma unroll")
   b.append(f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}")
-  b.append(f"rn::spd_factor<{Z}>(S, L, iL);")
+  factor, gate, solve = innovation_solver(Z, not sym, [f"y_{i}" for i in range(Z)], k.maha_thresh if k.maha_test else None)
+  b.append(factor)
   b.append("int gated = 0;")
-  if k.maha_test:
-    b.append("{")
-    b.append(f"  double v[{Z}] = {{{', '.join(f'y_{i}' for i in range(Z))}}};")
-    b.append(f"  rn::spd_forward<{Z}>(L, iL, v);")
-    b.append("  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";")
-    b.append(f"  if (d2 > {k.maha_thresh!r}) {{")
-    b.append("    gated = 1;")
-    b.append("#pragma unroll")
-    b.append(f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}")
-    b.append(f"    rn::spd_factor<{Z}>(S, L, iL);")
-    b.append("  }")
-    b.append("}")
+  b += gate
   # K (E x Z): column j of Gt solved against S
   for j in range(E):
     b.append(f"double k_{j}[{Z}] = {{{', '.join(f'Gt_{zi}_{j}' for zi in range(Z))}}};")
-    b.append(f"rn::spd_solve<{Z}>(L, iL, k_{j});")
+    b.append(solve(f"k_{j}"))
   K = lambda i, zi: f"k_{i}[{zi}]"  # noqa: E731
   for j in range(E):
     b.append(f"const double dx_{j} = " + " + ".join(f"{K(j, zi)}*y_{zi}" for zi in range(Z)) + ";")
@@ -152,7 +143,7 @@ def update_regs(spec, k):
     eblk.add(f"xi_{i}", sp.Matrix(spec.err_eqs[0])[i])
   estmts, est = eblk.lower()
   b += estmts
-  # B = P - K G (in place).  small_sym: B = (I - K He) P is NOT symmetric -- its upper triangle is needed for the result and the
+  # B = P - K G (in place).  sym: B = (I - K He) P is NOT symmetric -- its upper triangle is needed for the result and the
   # columns He touches for C below, all rows of those; an entry below the diagonal starts from its mirror image and lives in the
   # (otherwise unused) lower half of the array until the final mirroring overwrites it.
   hcols = sorted({j for zi in range(Z) for j, _ in He.row_nz(zi)})
@@ -181,7 +172,7 @@ def update_regs(spec, k):
     b.append(f"z[{i}] = y_{i};")
   b.append("return gated;")
   ea_arg = ", const double* __restrict__ ea" if k.ea_sym is not None else ""
-  head = (f"__device__ __forceinline__ int update_{k.kind}_regs(double (&x)[{D}], double (&P)[{E * E}], "
+  head = (f"__device__ __forceinline__ int update_{k.kind}_regs{'_sym' if sym else ''}(double (&x)[{D}], double (&P)[{E * E}], "
           f"double (&z)[{Z}], const double (&R)[{Z * Z}]{ea_arg}) {{")
   return "\n".join([head] + _ind(b) + ["}"]), He
 
@@ -213,9 +204,12 @@ def maha_regs(spec, k):
   for zi in range(Z):
     for w in range(Z):
       b.append(f"S[{zi * Z + w}] = {sum_terms(term(c, f'G_{zi}_{j}') for j, c in He.row_nz(w))} + R[{zi * Z + w}];")
-  b.append(f"rn::spd_factor<{Z}>(S, L, iL);")
-  b.append(f"rn::spd_forward<{Z}>(L, iL, v);")
-  b.append("return " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";")
+  b.append(f"double w[{Z}];")
+  b += ["#pragma unroll", f"for (int i = 0; i < {Z}; i++) w[i] = v[i];"]
+  b.append(f"rn::ldu_factor<{Z}>(S, L, iL);")
+  b.append(f"rn::ldu_forward<{Z}>(L, iL, v);")
+  b.append(f"rn::ldu_forward_t<{Z}>(L, iL, w);")
+  b.append("return " + " + ".join(f"v[{i}]*w[{i}]*iL[{i}]" for i in range(Z)) + ";")
   head = (f"__device__ __forceinline__ double maha_{k.kind}_regs(const double (&x)[{D}], const double (&P)[{E * E}], "
           f"const double (&z)[{Z}], const double (&R)[{Z * Z}]) {{")
   return "\n".join([head] + _ind(b) + ["}"])
@@ -273,6 +267,12 @@ def launch_maha(kind):
                      x, P, z, R, r_per_filter, n, d2);"""
 
 
+def norm_text(spec):
+  """Quaternion renormalisation after predict / update (EKFSym::normalize_quaternions, ekf_sym.cc:69-77,207,213)."""
+  quat = "".join(f" rn::normalize_quat<{spec.dim_x}>(x, {q});" for q in spec.quaternion_idxs)
+  return f"if (norm_quats) {{{quat} }}" if spec.quaternion_idxs else "(void)norm_quats;"
+
+
 def kernels(spec):
   """Device functions + __global__ kernels of family S for every kind."""
   waves = tuning.current().small_waves
@@ -280,13 +280,23 @@ def kernels(spec):
   D, E = spec.dim_x, spec.dim_err
   EE = E * E
   out = []
-  ptxt, _ = predict_regs(spec)
-  out.append(ptxt)
-  for k in spec.kinds:
-    utxt, _ = update_regs(spec, k)
-    out.append(utxt)
-  quat = "".join(f" rn::normalize_quat<{D}>(x, {q});" for q in spec.quaternion_idxs)
-  norm = f"if (norm_quats) {{{quat} }}" if spec.quaternion_idxs else "(void)norm_quats;"
+  for sym in (False, True):          # full products for the step-granular kernels, symmetric arithmetic for the fused runs
+    ptxt, _ = predict_regs(spec, sym)
+    out.append(ptxt)
+    for k in spec.kinds:
+      utxt, _ = update_regs(spec, k, sym)
+      out.append(utxt)
+  out.append(f"""
+// the fused multi-step kernels read (P + P^T) / 2 of the caller's covariance, once, as the state enters the registers
+__device__ __forceinline__ void symmetrize_regs(double (&P)[{EE}]) {{
+#pragma unroll
+  for (int i = 0; i < {E}; i++) {{
+#pragma unroll
+    for (int j = i + 1; j < {E}; j++) {{ P[i * {E} + j] = 0.5 * (P[i * {E} + j] + P[j * {E} + i]); P[j * {E} + i] = P[i * {E} + j]; }}
+  }}
+}}
+""")
+  norm = norm_text(spec)
 
   out.append(f"""
 // ---- predict only: one launch propagates n filters by dt -------------------------------------------
@@ -398,11 +408,11 @@ __global__ __launch_bounds__(64){kattr} void k_step_{k.kind}(double* __restrict_
   }}
 }}
 """)
-  out.append(run_kernel(spec, norm))
-  if run_block(spec) > 0:
+  if run_block(spec) > 0:          # blocked fused runs: k_run_blk (no trace) and k_run_blk_tr (filtered trace)
     out.append(run_kernel_blk(spec, norm))
-    if tuning.current().run_block_trace:
-      out.append(run_kernel_blk(spec, norm, trace=True))
+    out.append(run_kernel_blk(spec, norm, trace=True))
+  else:                            # fallback "no_run_blk" (the blocked kernels spilled): the step-at-a-time k_run serves both
+    out.append(run_kernel(spec, norm))
   return "\n".join(out)
 
 
@@ -449,7 +459,7 @@ def run_kernel(spec, norm):
           for (int i = 0; i < {Z}; i++) zk[i] = z[i];
 #pragma unroll
           for (int i = 0; i < {Z * Z}; i++) Rk[i] = gR[t * {zmax * zmax} + i];
-          fl = update_{k.kind}_regs(x, P, zk, Rk{ea});
+          fl = update_{k.kind}_regs_sym(x, P, zk, Rk{ea});
 #pragma unroll
           for (int i = 0; i < {Z}; i++) z[i] = zk[i];
           break;
@@ -478,6 +488,7 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
     double x[{D}], P[{EE}], z[{zmax}];
     rn::lds_to_regs<{D}>(s_x, lane, x);
     rn::lds_to_regs<{EE}>(s_P, lane, P);
+    symmetrize_regs(P);
     // Observation prefetch, {KP} steps deep: a step of a small model takes a fraction of a microsecond, less than one HBM round
     // trip, so with the next step's row alone in flight every step waited for its observation (r3a counters of the 2-state
     // model: 59 % of the wave cycles in s_waitcnt, 13 % issuing).  ring[j] carries the row of the step t = j (mod {KP}); the
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       ring[u].issue(gz + ((t + {KP} < T ? t + {KP} : T - 1) * n + base) * {zmax}, cnt, lane);
       const int kind = kinds[t];
       const double dt = dts[t];
-      predict_regs(x, P, s_Q, dt);
+      predict_regs_sym(x, P, s_Q, dt);
       {norm}
       int fl = 0;
       switch (kind) {{
@@ -543,9 +554,9 @@ def run_kernel_blk(spec, norm, trace=False):
       load the wavefront is waiting for ever queues behind a store it has just issued.
   Same arithmetic as k_run (predict_regs / update_*_regs); results agree to the last bits (FMA contraction may differ per kernel).
 
-  trace=True (experiment knob run_block_trace, off): the same structure writing the filtered trace -- every step's x / P leave through
-  the LDS image as coalesced stores that nothing waits for until the next block starts (k_run_blk_tr; the traced k_run pays the
-  per-step store wait this kernel was written to remove)."""
+  trace=True: the same structure writing the filtered trace -- every step's x / P leave through the LDS image as coalesced stores that
+  nothing waits for until the next block starts (k_run_blk_tr; the step-at-a-time k_run paid a store wait per step: MI355X, same call,
+  8 192 x 200 kinematic6 3.04 -> 3.38 G steps/s, 65 536 x 200 kinematic 59 -> 75 G steps/s, results bit-identical)."""
   D, E = spec.dim_x, spec.dim_err
   EE = E * E
   zmax = max(k.zdim for k in spec.kinds)
@@ -566,7 +577,7 @@ def run_kernel_blk(spec, norm, trace=False):
             for (int i = 0; i < {Z}; i++) zk[i] = cur[u][i];
 #pragma unroll
             for (int i = 0; i < {Z * Z}; i++) Rk[i] = lane_bcast(Rv[(u * {ZZ} + i) >> 6], (u * {ZZ} + i) & 63);
-            fl = update_{k.kind}_regs(x, P, zk, Rk{ea});
+            fl = update_{k.kind}_regs_sym(x, P, zk, Rk{ea});
 #pragma unroll
             for (int i = 0; i < {Z}; i++) cur[u][i] = zk[i];
             break;
@@ -640,6 +651,7 @@ __global__ __launch_bounds__(64) void {kname}(double* __restrict__ gx, double* _
     double x[{D}], P[{EE}];
     rn::lds_to_regs<{D}>(s_x, lane, x);
     rn::lds_to_regs<{EE}>(s_P, lane, P);
+    symmetrize_regs(P);
     // lanes past the end of a ragged tile compute on a copy of the last filter's rows and store nothing
     const int lc = lane < cnt ? lane : cnt - 1;
     const bool live = lane < cnt;
@@ -683,7 +695,7 @@ __global__ __launch_bounds__(64) void {kname}(double* __restrict__ gx, double* _
         if (t < T) {{
           const double dt = lane_bcast(dtv, u);
           const int kind = __builtin_amdgcn_readlane(kv, u);
-          predict_regs(x, P, s_Q, dt);
+          predict_regs_sym(x, P, s_Q, dt);
           {norm}
           int fl = 0;
           switch (kind) {{
@@ -723,18 +735,14 @@ def launch_run(spec=None):
     return """  const int64_t tiles = (n + 63) >> 6;
   hipLaunchKernelGGL(k_run, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
                      x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P, ea, augment);"""
-  traced = """    hipLaunchKernelGGL(k_run, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
-                       x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P, ea, augment);"""
-  if tuning.current().run_block_trace:
-    traced = """    (void)augment;
-    hipLaunchKernelGGL(k_run_blk_tr, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
-                       x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, ea, trace_x, trace_P);"""
-  return """  const int64_t tiles = (n + 63) >> 6;
+  return """  (void)augment;
+  const int64_t tiles = (n + 63) >> 6;
   if (trace_x == nullptr && trace_P == nullptr) {
     hipLaunchKernelGGL(k_run_blk, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
                        x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, ea);
   } else {
-""" + traced + """
+    hipLaunchKernelGGL(k_run_blk_tr, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                       x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, ea, trace_x, trace_P);
   }"""
 
 

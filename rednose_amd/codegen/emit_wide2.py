@@ -26,7 +26,7 @@ import sympy as sp
 
 from rednose_amd.codegen import tuning
 from rednose_amd.codegen.lower import Block, vector_names
-from rednose_amd.codegen.emit_common import SMat, term, sum_terms
+from rednose_amd.codegen.emit_common import SMat, term, sum_terms, innovation_solver
 
 
 def group_lanes(spec):
@@ -169,9 +169,16 @@ def _slotted(smat, var_list, off):
   return m
 
 
+COEF_BATCH_MAX = 40      # coefficients held in registers at once by _in_registers (live: 33 of F, 27 of He; a denser model -- the 24-state
+                         # random test model has 86 -- would spill under the 256-register budget of two wavefronts per SIMD: it keeps
+                         # the slot reads where they are used)
+
+
 def _in_registers(smat, name):
-  """-> (copy of `smat` whose named entries are `name[i]`, C statements loading them from where the original read them).  Used by
-  the experiment knob wide_lean_coef: every coefficient is read from the slot ONCE, all reads issued before the first use."""
+  """-> (copy of `smat` whose named entries are `name[i]`, C statements loading them from where the original read them): every
+  coefficient of the register-lean matrix phase is read from the slot ONCE, all reads issued before the first use and held there by a
+  scheduling barrier -- left alone hipcc sinks each LDS broadcast read next to its use, and every output of the phase becomes a
+  read -> wait -> FMA -> write chain of its own.  live, dt > 0 launch at 16 384 filters, same call: 40.5 -> 37.8 us, results bit-identical."""
   m = SMat(smat.rows, smat.cols)
   src = []
   for i in range(smat.rows):
@@ -183,8 +190,8 @@ def _in_registers(smat, name):
         m.e[i][j] = ('var', f"{name}[{src.index(e[1])}]")
       else:
         m.e[i][j] = e
-  if not src:
-    return m, []
+  if not src or len(src) > COEF_BATCH_MAX:
+    return (m if not src else smat), []
   loads = [f"double {name}[{len(src)}];"] + [f"{name}[{i}] = {v};" for i, v in enumerate(src)] + ["__builtin_amdgcn_sched_barrier(0);"]
   return m, loads
 
@@ -203,14 +210,12 @@ def _lean_update(k, Hs, lay, E, rows_in_regs=False):
   Z = Zf - EADIM if feat else Zf
   used = sorted({kk for zi in range(Zf) for kk, _ in Hs.row_nz(zi)})
   b = [f"double R[{Z * Z}];", f"double* pr = sP + cc * {E};"]
-  if tuning.current().wide_lean_coef and not feat:
+  if not feat:      # the non-zeros of He (27 for live) are read from the slot once, up front, behind a scheduling barrier (_in_registers)
     Hs, coef_loads = _in_registers(Hs, "hc")
     b += coef_loads
   if rows_in_regs:
     b += [f"double row[{E}];", "#pragma unroll", f"for (int j = 0; j < {E}; j++) row[j] = pr[j];"]
     b += [f"const double col_{kk} = sP[{kk} * {E} + cc], row_{kk} = row[{kk}];" for kk in used]
-  elif tuning.current().wide_lean_sym and not feat:
-    b += [f"const double row_{kk} = pr[{kk}], col_{kk} = row_{kk};      // P = P^T: column cc of P is the lane's own row" for kk in used]
   else:
     b += [f"const double col_{kk} = sP[{kk} * {E} + cc], row_{kk} = pr[{kk}];" for kk in used]
   if feat:
@@ -241,15 +246,12 @@ def _lean_update(k, Hs, lay, E, rows_in_regs=False):
     for zi in range(Z):
       for w in range(Z):
         b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))};")
-  b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}", f"rn::spd_factor<{Z}>(S, L, iL);",
-        "int gated = 0;"]
-  if k.maha_test:
-    b += ["{", f"  double v[{Z}] = {{{', '.join(f'sl[{lay.OFF_Y + i}]' for i in range(Z))}}};", f"  rn::spd_forward<{Z}>(L, iL, v);",
-          "  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";", f"  if (d2 > {k.maha_thresh!r}) {{", "    gated = 1;",
-          "#pragma unroll", f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}",
-          f"    rn::spd_factor<{Z}>(S, L, iL);", "  }", "}"]
+  # S is solved as a GENERAL matrix (L D U): the step-granular kernels follow the reference on asymmetric covariances (ekf_c.c:100-101)
+  factor, gate, solve = innovation_solver(Z, True, [f"sl[{lay.OFF_Y + i}]" for i in range(Z)], k.maha_thresh if k.maha_test else None)
+  b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}", factor, "int gated = 0;"]
+  b += gate
   b.append(f"double kk[{Z}] = {{{', '.join(f'Gt_{zi}' for zi in range(Z))}}};")
-  b.append(f"rn::spd_solve<{Z}>(L, iL, kk);")
+  b.append(solve("kk"))
   if feat:     # the reference's numpy path ignores a measurement whose null-space projection failed (ekf_sym.py:589-591)
     b += ["if (rank_deficient != 0.0) {", "#pragma unroll", f"  for (int i = 0; i < {Z}; i++) kk[i] = 0.0;", "}"]
   b.append("const double dxc = " + " + ".join(f"kk[{zi}]*sl[{lay.OFF_Y + zi}]" for zi in range(Z)) + ";")
@@ -379,10 +381,8 @@ def device_functions(spec, lay_cls=None, sfx=""):
     # rows, then columns, pass through ONE register array; every result goes straight back to LDS (in place: the lane's
     # own row / column is in registers, other lanes' are untouched), so nothing but the array stays live
     b = [f"const double dt = sl[{lay.OFF_DT}];", f"double v[{E}];"]
-    Fp = Fs
-    if tuning.current().wide_lean_coef:
-      Fp, coef_loads = _in_registers(Fs, "fc")
-      b += coef_loads
+    Fp, coef_loads = _in_registers(Fs, "fc")      # the non-zeros of F (33 for live): one batch of slot reads, not one read-wait-FMA chain per output
+    b += coef_loads
     b += ["if (act) {", "#pragma unroll", f"  for (int j = 0; j < {E}; j++) v[j] = sP[cc * {E} + j];"]
     for i in range(E):
       b.append(f"  sP[cc * {E} + {i}] = {sum_terms(term(cf, f'v[{kk}]') for kk, cf in Fp.row_nz(i))};")
@@ -445,15 +445,11 @@ def device_functions(spec, lay_cls=None, sfx=""):
       for zi in range(Z):
         for w in range(Z):
           b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))};")
-      b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}", f"rn::spd_factor<{Z}>(S, L, iL);",
-            "int gated = 0;"]
-      if k.maha_test:
-        b += ["{", f"  double v[{Z}] = {{{', '.join(f'sl[{lay.OFF_Y + i}]' for i in range(Z))}}};", f"  rn::spd_forward<{Z}>(L, iL, v);",
-              "  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";", f"  if (d2 > {k.maha_thresh!r}) {{", "    gated = 1;",
-              "#pragma unroll", f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}",
-              f"    rn::spd_factor<{Z}>(S, L, iL);", "  }", "}"]
+      factor, gate, solve = innovation_solver(Z, True, [f"sl[{lay.OFF_Y + i}]" for i in range(Z)], k.maha_thresh if k.maha_test else None)
+      b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}", factor, "int gated = 0;"]
+      b += gate
       b.append(f"double kk[{Z}] = {{{', '.join(f'Gt_{zi}' for zi in range(Z))}}};")
-      b.append(f"rn::spd_solve<{Z}>(L, iL, kk);")
+      b.append(solve("kk"))
       b.append("const double dxc = " + " + ".join(f"kk[{zi}]*sl[{lay.OFF_Y + zi}]" for zi in range(Z)) + ";")
       for j in range(E):
         b.append(f"row[{j}] -= " + " + ".join(f"kk[{zi}]*sG[{zi * E + j}]" for zi in range(Z)) + ";")
@@ -669,14 +665,14 @@ def maha_kernels(spec):
       b.append(f"const double G_{zi} = {sum_terms(term(cf, f'col[{kk}]') for kk, cf in Hs.row_nz(zi))};")
     b.append("if (act) { " + " ".join(f"sG[{zi} * {E} + cc] = G_{zi};" for zi in range(Z)) + " }")
     b.append("rn::wave_lds_sync();")
-    b.append(f"double S[{ZZ}], L[{ZZ}], iL[{Z}], v[{Z}];")
+    b.append(f"double S[{ZZ}], L[{ZZ}], iL[{Z}], v[{Z}], w[{Z}];")
     for zi in range(Z):
       for w in range(Z):
         b.append(f"S[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))} + R[{zi * Z + w}];")
     for i in range(Z):
-      b.append(f"v[{i}] = sl[{lay.OFF_Y + i}];")
-    b += [f"rn::spd_factor<{Z}>(S, L, iL);", f"rn::spd_forward<{Z}>(L, iL, v);", "rn::wave_lds_sync();",
-          "return " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";"]
+      b.append(f"v[{i}] = w[{i}] = sl[{lay.OFF_Y + i}];")
+    b += [f"rn::ldu_factor<{Z}>(S, L, iL);", f"rn::ldu_forward<{Z}>(L, iL, v);", f"rn::ldu_forward_t<{Z}>(L, iL, w);", "rn::wave_lds_sync();",
+          "return " + " + ".join(f"v[{i}]*w[{i}]*iL[{i}]" for i in range(Z)) + ";"]
     out.append("\n".join([f"__device__ __forceinline__ double mat_maha_{k.kind}(const double* sP, const double* __restrict__ gR, const double* sl, "
                           "double* sG, const int cc, const bool act) {"] + _ind(b) + ["}"]))
     out.append(f"""

@@ -71,13 +71,15 @@ def gen_code(folder, name, f_sym, dt_sym, x_sym, obs_eqs, dim_x, dim_err, eskf_p
 
     usage, bad = build()
     if not os.environ.get("RN_ALLOW_SPILLS"):
-      if "k_run_blk" in bad:
-        usage, bad = fall_back("no_run_blk", "the blocked fused run spills registers: the traced kernel serves untraced runs too")
+      if "k_run_blk" in bad or "k_run_blk_tr" in bad:
+        usage, bad = fall_back("no_run_blk", "a blocked fused run spills registers: the step-at-a-time k_run serves fused runs instead")
       if bad and rn_emit.family(spec, ()) == "small":
         usage, bad = fall_back("force_wide", f"lane-per-filter kernels {bad} spill registers: regenerating in the lane-group family")
       if "k_rts3" in bad:
         usage, bad = fall_back("no_rts3", "the smoother in the fused run's layout spills registers: lane-group smoother instead")
-      if "k_run" in bad and usage["k_run"]["scratch"] > 0 and spec.dim_err > 32:
+      if "k_run" in bad and usage["k_run"]["scratch"] > 0 and rn_emit.family(spec, tuple(fallbacks)) == "wide":
+        # whatever the state count: a lone wavefront pays about a microsecond per scratch access, and the rows of P live in registers
+        # for the whole schedule.  BatchedEKF.run() then walks the schedule with the step-granular entry points.
         usage, bad = fall_back("no_run", "the fused run touches scratch memory: library without batch_run (step-granular entry points only)")
       heavy = [k for k in bad if usage[k]["vgpr_spill"] > 8 and not k.startswith(("k_rts", "k_run"))]
       if heavy and rn_tuning.model_defaults(spec):
@@ -719,12 +721,18 @@ class BatchedEKF:
     self.filter_time = torch.where(act, tt, ft)
     if self.rewind_to_keep > 0:
       self._ring_push(act, self.filter_time, kind, z_obs, Rd, per, ea)
+    # The Estimate is the state right after THIS observation -- the reference captures `ret` before it fast-forwards over the
+    # observations the rewind overtook (ekf_sym.py:473-479) -- and the flags the caller reads are this observation's too: the
+    # replay launches write the replayed (older) observations' flags into the same buffer.
+    xk_k, Pk_k = (self.x.clone(), self.P.clone()) if keep_estimate else (None, None)
     if replay is not None:
+      fl_new = self.flags.clone()
       self._ring_replay(replay)
+      self.flags = fl_new
     if bool(dropped.any()):
       self.flags |= dropped.to(torch.uint8) * 32
     if keep_estimate:
-      return est[0], self.x.clone(), est[1], self.P.clone(), tt, kind, zin, z_obs, extra_args
+      return est[0], xk_k, est[1], Pk_k, tt, kind, zin, z_obs, extra_args
     return zin
 
   def _ring_alloc(self):
@@ -1001,8 +1009,11 @@ class BatchedEKF:
     if augment is not None:
       assert self.msckf, "augment: MSCKF models only"
       ag = torch.as_tensor(np.asarray(augment, dtype=np.int32).reshape(T), device=self.device)
-    self._call("batch_run", self._p(xv), self._p(Pv), self._p(self.Q), self._p(kd), self._p(dd), T, self._p(zs),
-               self._p(Rd), nb, self.norm_quats, self._p(fl), self._p(tx), self._p(tP), self._p(ea), self._p(ag), self._stream())
+    if self._has_batch_run():
+      self._call("batch_run", self._p(xv), self._p(Pv), self._p(self.Q), self._p(kd), self._p(dd), T, self._p(zs),
+                 self._p(Rd), nb, self.norm_quats, self._p(fl), self._p(tx), self._p(tP), self._p(ea), self._p(ag), self._stream())
+    else:
+      self._run_stepwise(xv, Pv, kinds, dts, zs, Rd, nb, fl, tx, tP, ea, None if augment is None else np.asarray(augment).reshape(T))
     if nb == self.batch:          # a strict subset leaves the orchestrator's clock alone: the other filters have not moved
       if ag is not None and self.msckf:
         for t_, a_ in zip(ts, np.asarray(augment).reshape(T)):
@@ -1011,6 +1022,37 @@ class BatchedEKF:
       self.filter_time = float(ts[-1])
     self._keepalive = (kd, dd, Rd, ea, ag)      # the launch is asynchronous: keep its inputs alive
     return zs, tx, tP, fl
+
+  def _has_batch_run(self):
+    """False for a library whose fused multi-step kernel did not fit the register file (gen_code fallback `no_run`: its
+    {name}_batch_run returns ERR_UNSUPPORTED)."""
+    fn = getattr(self._lib, f"{self.name}_has_batch_run", None)
+    if fn is None:            # a library generated before the query existed: it has the kernel unless the call says otherwise
+      return True
+    fn.restype = ctypes.c_int
+    return bool(fn())
+
+  def _run_stepwise(self, xv, Pv, kinds, dts, zs, Rd, nb, fl, tx, tP, ea, augment):
+    """run() for a library without the fused multi-step kernel: the same schedule, one fused predict + update launch per step
+    through the step-granular entry points (same results as the reference's per-call path; the state crosses HBM every step)."""
+    zmax = zs.shape[2]
+    for t in range(len(kinds)):
+      k = int(kinds[t])
+      Z = self.zdims[k]
+      zt = zs[t, :, :Z].clone()              # own allocation: the C ABI wants 16-byte aligned observations
+      Rt = Rd[t, :Z * Z]
+      flp = None if fl is None else self._p(fl[t])
+      eat = None if (ea is None or self.eadims.get(k, 0) == 0) else ea[t, :, :self.eadims[k]].contiguous()
+      self._call(f"batch_predict_update_{k}", self._p(xv), self._p(Pv), self._p(self.Q), None, float(dts[t]), self._p(zt), self._p(Rt), 0,
+                 self._p(eat), nb, self.norm_quats, flp, self._stream())
+      zs[t, :, :Z] = zt
+      if tx is not None:
+        tx[t].copy_(xv)
+      if tP is not None:
+        tP[t].copy_(Pv)
+      if augment is not None and augment[t]:
+        self._call("batch_augment", self._p(xv), self._p(Pv), nb, self._stream())
+      self._keepalive_step = (zt, Rt, eat)
 
   # -- offline smoothing ----------------------------------------------------------------------------
   def smooth(self, ts, kinds, zs, Rs, passes=1, chunk=None, norm_quats=None, on_chunk=None, flags=False, extra_args=None, augment=None):
@@ -1042,6 +1084,7 @@ class BatchedEKF:
     if on_chunk is None and step < self.batch:
       raise KalmanError("smooth(chunk=...) hands the smoothed trajectory out chunk by chunk: pass on_chunk")
     t_init = self.filter_time
+    aug0 = list(self.augment_times) if self.msckf else None      # run() shifts them when it covers the whole batch: once per pass
     tx = torch.empty((T, step, self.dim_x), dtype=torch.float64, device=self.device)
     tP = torch.empty((T, step, self.dim_err, self.dim_err), dtype=torch.float64, device=self.device)
     for lo in range(0, self.batch, step):
@@ -1061,6 +1104,8 @@ class BatchedEKF:
       if on_chunk is not None:
         on_chunk(lo, hi, xs, Ps, ys, fl)
     self.filter_time = float(ts[-1])
+    if self.msckf:
+      self.augment_times = aug0            # the window shifts of the schedule happened ONCE, whatever the passes / chunks
     if augment is not None and self.msckf:
       for t_, a_ in zip(ts, np.asarray(augment).reshape(T)):
         if a_:

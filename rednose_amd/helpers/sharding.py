@@ -19,7 +19,7 @@ def aggregate_throughput(steps_local, seconds_local, dist=None, device=None):
   import torch
   t = torch.tensor([float(steps_local)], dtype=torch.float64, device=device)
   s = torch.tensor([float(seconds_local)], dtype=torch.float64, device=device)
-  if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+  if dist is not None and dist.is_initialized():      # a one-rank group reduces too (bench.py RN_BENCH_FORCE_DIST: the RCCL branch on one GPU)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     dist.all_reduce(s, op=dist.ReduceOp.MAX)
   return float(t[0]) / float(s[0]), float(t[0]), float(s[0])

@@ -506,6 +506,75 @@ __device__ __forceinline__ void spd_solve(const double (&L)[Z * Z], const double
   }
 }
 
+// General (non-symmetric) variant for the step-granular kernels: S = L D U with unit lower-triangular L (stored below the diagonal
+// of LU) and unit upper-triangular U (above it), no pivoting; iD[j] = 1 / D[j].  The reference never symmetrises P
+// (ekf_c.c:24,115), so its S = H P H^T + R (ekf_c.c:100) is as asymmetric as the caller's P and is solved as a general matrix
+// (fullPivLu, ekf_c.c:101): reading one triangle of S, as spd_factor does, would change the result by the asymmetry of P.  For a
+// symmetric S this IS the L D L^T above (U = L^T) at the same dependent-chain depth: the entries of U are formed next to those of L.
+// No pivoting: S is a covariance plus R up to that asymmetry -- its symmetric part is positive definite.
+template <int Z>
+__device__ __forceinline__ void ldu_factor(const double (&S)[Z * Z], double (&LU)[Z * Z], double (&iD)[Z]) {
+  double D[Z];
+#pragma unroll
+  for (int j = 0; j < Z; j++) {
+    double d = S[j * Z + j];
+#pragma unroll
+    for (int k = 0; k < j; k++) d -= LU[j * Z + k] * D[k] * LU[k * Z + j];
+    D[j] = d;
+    iD[j] = fast_recip(d);
+#pragma unroll
+    for (int i = j + 1; i < Z; i++) {
+      double s = S[i * Z + j], u = S[j * Z + i];
+#pragma unroll
+      for (int k = 0; k < j; k++) {
+        s -= LU[i * Z + k] * D[k] * LU[k * Z + j];
+        u -= LU[j * Z + k] * D[k] * LU[k * Z + i];
+      }
+      LU[i * Z + j] = s * iD[j];
+      LU[j * Z + i] = u * iD[j];
+    }
+  }
+}
+
+// b <- L^{-1} b
+template <int Z>
+__device__ __forceinline__ void ldu_forward(const double (&LU)[Z * Z], const double (&iD)[Z], double (&b)[Z]) {
+  (void)iD;
+#pragma unroll
+  for (int i = 0; i < Z; i++) {
+    double s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= LU[i * Z + k] * b[k];
+    b[i] = s;
+  }
+}
+
+// b <- U^{-T} b.  The quadratic form b^T S^{-1} b = (U^{-T} b)^T D^{-1} (L^{-1} b) = sum_i u[i] v[i] iD[i].
+template <int Z>
+__device__ __forceinline__ void ldu_forward_t(const double (&LU)[Z * Z], const double (&iD)[Z], double (&b)[Z]) {
+  (void)iD;
+#pragma unroll
+  for (int i = 0; i < Z; i++) {
+    double s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= LU[k * Z + i] * b[k];
+    b[i] = s;
+  }
+}
+
+// b <- (L D U)^{-1} b
+template <int Z>
+__device__ __forceinline__ void ldu_solve(const double (&LU)[Z * Z], const double (&iD)[Z], double (&b)[Z]) {
+  ldu_forward<Z>(LU, iD, b);
+#pragma unroll
+  for (int i = Z - 1; i >= 0; i--) {
+    double s = b[i] * iD[i];
+#pragma unroll
+    for (int k = i + 1; k < Z; k++) s -= LU[i * Z + k] * b[k];
+    b[i] = s;
+  }
+}
+
 // EKFSym::normalize_slice (/root/reference/rednose/helpers/ekf_sym.cc:75-77): x[idx:idx+4] /= ||.||
 template <int DIM>
 __device__ __forceinline__ void normalize_quat(double (&x)[DIM], int idx) {

@@ -32,7 +32,9 @@ template <class Model>
 __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const double* __restrict__ Pf,
                                             const double* __restrict__ ts, const int64_t T,
                                             const double* __restrict__ gQ, const int64_t n, const int norm_quats,
-                                            double* __restrict__ xs, double* __restrict__ Ps) {
+                                            double* __restrict__ xs, double* __restrict__ Ps,
+                                            const double* __restrict__ xl, const double* __restrict__ Pl) {
+  // xl / Pl (optional): the predicted pair of the last step, returned verbatim as the newest smoothed estimate (ekf_sym.py:658-659)
   constexpr int D = Model::D, E = Model::E, EE = E * E, GL = 32, FPW = 2;
   constexpr int DP = D + (D & 1);
   __shared__ __attribute__((aligned(16))) double s_A[FPW * EE];   // Pk_k in, Pk_n out (HBM staging)
@@ -99,9 +101,13 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
       double xk[D], x1k[D];
 #pragma unroll
       for (int i = 0; i < D; i++) xk[i] = s_x[gg * D + i];
+      // Contract of batch_rts (include/rednose_amd_filter.h): the LOWER triangle of every covariance handed in is read, mirrored --
+      // the recursion factors Pk1_k by Cholesky and the lane-group kernels keep D = Pk1_n - Pk1_k as a packed triangle, so all
+      // three smoother kernels take P[r][j] for j <= r and P[j][r] above the diagonal.  (The reference solves with general
+      // matrices, ekf_sym.py:677,686; on the symmetric traces a forward pass produces the two agree to rounding.)
       double prow[E];       // row c of Pk_k
 #pragma unroll
-      for (int j = 0; j < E; j++) prow[j] = A[cc * E + j];
+      for (int j = 0; j < E; j++) prow[j] = (j <= cc) ? A[cc * E + j] : A[j * E + cc];
 
       // ---- recompute the predicted pair of step k+1 exactly as the forward pass did ----------------------
       const bool first = (k == T - 2);     // recursion start: smoothed(T-1) := predicted(T-1)  (estimates[-1][0], [2])
@@ -131,15 +137,22 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
           const double v = s + dt * s_Q[i * E + cc];
           if (on) {
             L[i * E + c] = v;
-            if (first) Nn[i * E + c] = v;
+            if (first) Nn[i * E + c] = (Pl != nullptr) ? Pl[(base + gg) * EE + i * E + c] : v;
             Dm[i * E + c] = Nn[i * E + c] - v;
           }
         }
       }
       wave_lds_sync();
+      if (on) {             // D from its lower triangle (Pk1_n = Pk_k + correction carries whatever asymmetry the caller's Pk_k had)
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+          if (i < c) Dm[i * E + c] = Dm[c * E + i];
+        }
+      }
+      wave_lds_sync();
       if (k == T - 2) {
 #pragma unroll
-        for (int i = 0; i < D; i++) xn1[i] = x1k[i];
+        for (int i = 0; i < D; i++) xn1[i] = (xl != nullptr) ? xl[(base + gg) * D + i] : x1k[i];
       }
       if (norm_quats & 2) Model::normalize(xn1);
       // smoothed step k+1 is final now: write it out (state after the in-place renormalisation)
@@ -295,6 +308,20 @@ __device__ __forceinline__ void rts_load_row(const double* __restrict__ p, doubl
   } else {
 #pragma unroll
     for (int j = 0; j < EM; j++) r[j] = p[j];
+  }
+}
+
+// Row c of the covariance READ FROM ITS LOWER TRIANGLE (the contract of batch_rts, see k_rts): entries j <= c from the row itself,
+// entries above the diagonal from column c -- for a fixed j the lanes of a group read consecutive doubles of row j.
+template <int E, int EM>
+__device__ __forceinline__ void rts_load_row_lower(const double* __restrict__ prow_ptr, const double* __restrict__ pcol_ptr, const int c,
+                                                   double (&r)[EM]) {
+  // one 8-byte load per entry from the selected side (a value select between a row load and a column load trips an hipcc 7.2
+  // backend assertion in some instantiations: "V_CMP_NE_U32 $src_shared_base: incorrect register class")
+#pragma unroll
+  for (int j = 0; j < EM; j++) {
+    const int64_t off = (j <= c) ? (int64_t)j : (int64_t)j * E + (pcol_ptr - prow_ptr);
+    r[j] = prow_ptr[off];
   }
 }
 
@@ -528,7 +555,7 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
         // row c of Pk_k is requested first: its HBM / L2 latency passes under the scalar phase, which
         // keeps one lane per filter busy for about a microsecond (up to 32 error states; beyond, the registers are not there)
         double prow[EM];
-        if constexpr (EM <= 32) rts_load_row<E, EM>(Pk, prow);
+        if constexpr (EM <= 32) rts_load_row_lower<E, EM>(Pk, Pf + ((k * n + fil) * EE + cc), cc, prow);
         for (int i = c; i < D; i += GL) sxk[i] = xf[(k * n + fil) * D + i];
         const double dt = ts[k + 1] - ts[k];
         wave_lds_sync();
@@ -538,7 +565,7 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
         wave_lds_sync();
         RN_RTS_STAMP(2);
         // ---- C. predicted pair of step k+1 (main block): B <- Pk1_k, y <- column c of M = Fk Pk_k^T -----------------------
-        if constexpr (EM > 32) rts_load_row<E, EM>(Pk, prow);
+        if constexpr (EM > 32) rts_load_row_lower<E, EM>(Pk, Pf + ((k * n + fil) * EE + cc), cc, prow);
         // column cc of Q behind an opaque zero: without it hipcc hoists one 64-bit address per entry out of the step loop
         // (2 EM registers for the whole kernel; beyond the immediate-offset range they cannot share a base) and spills them
         int qz = 0;
@@ -576,6 +603,13 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
 #pragma unroll
         for (int j = 0; j < EM; j++) C[c * EM + j] = nrow[j] - lrow[j];
         rts_store_row<E, EM>(Ps + (((k + 1) * n + fil) * EE + (int64_t)c * E), nrow);
+      }
+      wave_lds_sync();
+      if (on) {             // D from its lower triangle (see k_rts): Pk1_n carries whatever asymmetry the caller's covariances had
+#pragma unroll
+        for (int j = 1; j < EM; j++) {
+          if (j > c) C[c * EM + j] = C[j * EM + c];
+        }
       }
       wave_lds_sync();
       if (g < cnt) {

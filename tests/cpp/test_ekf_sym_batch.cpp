@@ -58,6 +58,60 @@ static int run_timelines(const char* dir, const char* stream, int64_t n) {
   return 0;
 }
 
+// Robustness mode (round-3 review of the per-filter path): (a) a time-varying R -- a new matrix on every call -- must not grow the
+// host-side noise table without bound; (b) an observation that is too old for one filter's ring sets bits 4 and 5 of that filter's
+// flag byte; (c) a call that is refused (a late observation without a ring) throws BEFORE anything is touched: filter times and
+// states are what they were, and the next valid call works.
+static int run_robustness(const char* dir) {
+  const int64_t n = 5;
+  const std::vector<double> Q = {0.1 * 0.1, 0.0, 0.0, 2.0 * 2.0}, x0 = {0.5, 0.0}, P0 = {1.0, 0.0, 0.0, 1.0};
+  rednose_amd::EKFSymBatch kf(dir, "kinematic", Q, x0, P0, n, false, nullptr, 8, 1.0);
+  double* z_dev = nullptr;
+  uint8_t* fl_dev = nullptr;
+  if (hipMalloc((void**)&z_dev, sizeof(double) * n) != hipSuccess || hipMalloc((void**)&fl_dev, n) != hipSuccess) return 3;
+  std::vector<double> ts(n), zs(n, 0.1);
+  size_t table_max = 0;
+  for (int it = 0; it < 400; it++) {
+    for (int64_t i = 0; i < n; i++) ts[i] = 0.01 * (it + 1) + 1e-4 * i;
+    const double R[1] = {0.01 * (1.0 + 1e-3 * it)};                       // never the same matrix twice
+    if (hipMemcpy(z_dev, zs.data(), sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) return 3;
+    kf.predict_and_update_batch_per_filter(ts.data(), nullptr, 1, z_dev, R, fl_dev);
+    table_max = std::max(table_max, kf.noise_table_size());
+  }
+  // (b) filter 2 gets an observation 3 s in its past (ring: 8 entries, max_rewind_age 1 s): ignored for it alone
+  for (int64_t i = 0; i < n; i++) ts[i] = 0.01 * 401 + 1e-4 * i;
+  ts[2] -= 3.0;
+  const double R1[1] = {0.01};
+  if (hipMemcpy(z_dev, zs.data(), sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) return 3;
+  const int64_t ign = kf.predict_and_update_batch_per_filter(ts.data(), nullptr, 1, z_dev, R1, fl_dev);
+  kf.synchronize();
+  std::vector<uint8_t> fl(n);
+  if (hipMemcpy(fl.data(), fl_dev, n, hipMemcpyDeviceToHost) != hipSuccess) return 3;
+  std::printf("table_max %zu ignored %lld flags", table_max, (long long)ign);
+  for (int64_t i = 0; i < n; i++) std::printf(" %d", (int)fl[i]);
+  std::printf("\n");
+  // (c) no ring: a late observation for one filter is refused up front
+  rednose_amd::EKFSymBatch nr(dir, "kinematic", Q, x0, P0, n, false, nullptr, 0, 1.0);
+  for (int64_t i = 0; i < n; i++) ts[i] = 1.0 + 0.1 * i;
+  if (hipMemcpy(z_dev, zs.data(), sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) return 3;
+  nr.predict_and_update_batch_per_filter(ts.data(), nullptr, 1, z_dev, R1);
+  nr.synchronize();
+  const std::vector<double> ft0 = nr.filter_times(), xs0 = nr.state();
+  std::vector<double> t2(ts);
+  t2[0] += 0.5; t2[1] += 0.5; t2[3] -= 0.2;                                 // filters 0 and 1 would advance, filter 3 is late
+  bool threw = false;
+  try { nr.predict_and_update_batch_per_filter(t2.data(), nullptr, 1, z_dev, R1); } catch (const std::runtime_error&) { threw = true; }
+  nr.synchronize();
+  const bool untouched = nr.filter_times() == ft0 && nr.state() == xs0;
+  for (int64_t i = 0; i < n; i++) t2[i] = ts[i] + 0.5;
+  if (hipMemcpy(z_dev, zs.data(), sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) return 3;
+  nr.predict_and_update_batch_per_filter(t2.data(), nullptr, 1, z_dev, R1);
+  nr.synchronize();
+  std::printf("refused %d untouched %d next_call_time %.17g\n", threw ? 1 : 0, untouched ? 1 : 0, nr.filter_times()[3]);
+  (void)hipFree(z_dev); (void)hipFree(fl_dev);
+  return 0;
+}
+
 // Globals mode: set_global / get_extra_routine on a model generated with global_vars (tests/test_global_vars.py's gv_runtime)
 static int run_globals(const char* dir) {
   rednose_amd::EKFSymBatch kf(dir, "gv_runtime", {0.01, 0.0, 0.0, 4.0}, {0.5, 0.3}, {1.0, 0.0, 0.0, 1.0}, 3);
@@ -82,6 +136,7 @@ int main(int argc, char** argv) {
   try {
     if (argc >= 5 && std::string(argv[4]) == "rewind") return run_rewind(argv[1], argv[2], n);
     if (argc >= 5 && std::string(argv[4]) == "globals") return run_globals(argv[1]);
+    if (argc >= 5 && std::string(argv[4]) == "robustness") return run_robustness(argv[1]);
     if (argc >= 5 && std::string(argv[4]) == "timelines") return run_timelines(argv[1], argv[2], n);
     rednose_amd::EKFSymBatch kf(argv[1], "kinematic", {0.1 * 0.1, 0.0, 0.0, 2.0 * 2.0}, {0.5, 0.0}, {1.0, 0.0, 0.0, 1.0}, n);
     std::ifstream in(argv[2]);

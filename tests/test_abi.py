@@ -17,7 +17,7 @@ MODELS = ["kinematic", "kinematic6", "kinematic9", "live", "feature"]
 @pytest.fixture(scope="module")
 def gen_dir():
   from examples import ensure_generated
-  return ensure_generated(MODELS)            # hipcc cross-compiles gfx950 without a GPU
+  return ensure_generated(MODELS + ["live_maha"])            # hipcc cross-compiles gfx950 without a GPU
 
 
 @pytest.mark.parametrize("name", MODELS)
@@ -78,7 +78,7 @@ def test_compute_without_device_fails_loudly(gen_dir):
     BatchedEKF(gen_dir, "kinematic", np.eye(2), np.zeros(2), np.eye(2), 2, 2, batch=8)
 
 
-@pytest.mark.parametrize("name", ["kinematic", "kinematic6", "kinematic9", "live", "feature"])
+@pytest.mark.parametrize("name", ["kinematic", "kinematic6", "kinematic9", "live", "live_maha", "feature"])
 def test_step_kernels_do_not_spill(gen_dir, name):
   """Every library is built with hipcc's per-kernel resource report next to it ({name}.kernels.txt).  The step kernels of the
   shipped models must not touch scratch memory: a spill costs a lone wavefront microseconds per access, and the one
@@ -95,11 +95,15 @@ def test_step_kernels_do_not_spill(gen_dir, name):
   steps = {k: v for k, v in rows.items() if k.startswith("k_step_") or k == "k_predict"}
   assert steps, rows.keys()
   for k, v in steps.items():
-    # zero, except for a handful of tile-invariant addresses (<= 8 registers) that the two-wavefronts-per-SIMD build of the live
-    # accelerometer kind parks in scratch at kernel entry and reloads once per tile, outside every loop over filters
-    # (gen_code regenerates a model in the general structure beyond that: rednose_amd/helpers/ekf_sym.py)
-    assert v["scratch"] <= 32 and v["spills"] <= 8, f"{name}: {k} spills ({v})"
+    # zero: round 3 allowed the live accelerometer kernel 4 registers in scratch; with the slot coefficients of the matrix phase
+    # read in one batch (emit_wide2._in_registers) it needs 246-256 registers and none in scratch
+    assert v["scratch"] == 0 and v["spills"] == 0, f"{name}: {k} spills ({v})"
     assert v["lds"] <= 65536
+  # fused multi-step kernels and smoothers: whatever ships must not touch scratch memory either (gen_code drops batch_run / falls
+  # back to another smoother otherwise: rednose_amd/helpers/ekf_sym.py)
+  for k, v in rows.items():
+    if k.startswith(("k_run", "k_rts")):
+      assert v["scratch"] == 0, f"{name}: {k} uses scratch memory ({v})"
 
 
 def test_loader_backends(gen_dir):

@@ -54,20 +54,39 @@ def _build_plugin_host():
   return exe
 
 
+def _plugin_host(which):
+  """`lookalike`: the host with its own registry; `reference_loader`: the same driver linked against the reference's own
+  rednose/helpers/ekf_load.cc object (oracle/_ref/ref_ekf_load.o, built by __graft_entry__.build() where /root/reference exists and
+  shipped to the GPU box) -- ekf_load_and_register / ekf_lookup are then the reference's code, not a restatement."""
+  if which == "lookalike":
+    return _build_plugin_host()
+  import __graft_entry__ as ge
+  exe = ge.build_reference_loader()
+  if exe is None:
+    pytest.skip("oracle/_ref/ref_ekf_load.o is not there: run __graft_entry__.build() where /root/reference is present")
+  return exe
+
+
+@pytest.mark.parametrize("host", ["lookalike", "reference_loader"])
 @pytest.mark.parametrize("name,kinds,nfeat", [("kinematic", "1", 0), ("live", "3 4 9 10 12 13 14 19", 0), ("feature", "1 2", 1)])
-def test_plugin_descriptor_loads_like_the_reference_host(name, kinds, nfeat):
-  """ekf_get() / struct EKF / self-registration (rednose/helpers/ekf.h:14-42, ekf_load.cc:22-39) of a generated library,
-  through a host program written like the reference's loader.  No device needed: only the descriptor is read."""
+def test_plugin_descriptor_loads_like_the_reference_host(name, kinds, nfeat, host):
+  """ekf_get() / struct EKF / self-registration (rednose/helpers/ekf.h:14-42, ekf_load.cc:22-39) of a generated library, through
+  a host program written like the reference's loader and through the reference's loader itself.  No device needed: only the
+  descriptor is read.  (The reference's registry ends up holding the descriptor twice -- once from the library's constructor, once
+  from ekf_load_and_register, ekf_load.cc:38 -- as it does for the reference's own libraries.)"""
   from examples import ensure_generated
   gen = ensure_generated([name])
-  out = subprocess.run([_build_plugin_host(), gen, name], check=True, capture_output=True, text=True).stdout.strip().split("\n")
-  assert out[0] == f"name {name} kinds {kinds} feature_kinds {nfeat} registered 1 same 1", out
+  out = subprocess.run([_plugin_host(host), gen, name], check=True, capture_output=True, text=True).stdout.strip().split("\n")
+  reg = 1 if host == "lookalike" else 2
+  assert out[0] == f"name {name} kinds {kinds} feature_kinds {nfeat} registered {reg} same 1", out
   assert out[1].startswith("complete 1"), out
 
 
 @pytest.mark.gpu
-def test_plugin_known_answers_through_descriptor(tmp_path):
-  """The calls EKFSym makes (ekf->predict, ekf->updates.at(kind)) over /root/reference/examples/test_kinematic_kf.py's stream."""
+@pytest.mark.parametrize("host", ["lookalike", "reference_loader"])
+def test_plugin_known_answers_through_descriptor(tmp_path, host):
+  """The calls EKFSym makes (ekf->predict, ekf->updates.at(kind)) over /root/reference/examples/test_kinematic_kf.py's stream, the
+  library found and registered by the reference's own ekf_load_and_register / ekf_lookup in the `reference_loader` build."""
   from examples import ensure_generated
   gen = ensure_generated(["kinematic"])
   g = golden("kinematic_stream.npz")
@@ -75,7 +94,7 @@ def test_plugin_known_answers_through_descriptor(tmp_path):
   with open(stream, "w", encoding="utf-8") as f:
     for t, z in zip(g["ts"], g["zs"]):
       f.write(f"{float(t)!r} {float(z)!r}\n")
-  out = subprocess.run([_build_plugin_host(), gen, "kinematic", str(stream)], check=True, capture_output=True, text=True).stdout.strip().split("\n")
+  out = subprocess.run([_plugin_host(host), gen, "kinematic", str(stream)], check=True, capture_output=True, text=True).stdout.strip().split("\n")
   v = out[-1].split()
   assert v[0] == "steps" and v[1] == "500"
   got = (float(v[3]), float(v[6]), float(v[4]), float(v[7]))
@@ -139,3 +158,19 @@ def test_cpp_orchestrator_per_filter_timelines(tmp_path):
   keep = g["A_keep"]
   assert np.abs(rows[keep][:, :, 2:4].transpose(1, 0, 2) - g["A_x"]).max() < 1e-9
   assert np.abs(rows[-1, :, 2:4] - g["A_x_final"]).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_cpp_per_filter_path_is_robust():
+  """EKFSymBatch per-filter timelines: the host-side table of noise matrices stays bounded under a time-varying R (400 calls, a
+  new R each: entries no live ring slot references are dropped), an observation too old for one filter's ring sets flag bits 4 | 5
+  for that filter only, and a refused call (late observation, no ring) throws before any state -- rings, filter times, x, P -- is
+  touched."""
+  from examples import ensure_generated
+  gen = ensure_generated(["kinematic"])
+  out = subprocess.run([_build(), gen, "-", "5", "robustness"], check=True, capture_output=True, text=True).stdout.strip().split("\n")
+  a = out[0].split()
+  assert a[0] == "table_max" and int(a[1]) <= 130, out[0]                      # 400 distinct matrices went through a ring of 8 x 5 slots
+  assert a[3] == "1" and [int(v) for v in a[5:]] == [0, 0, 48, 0, 0], out[0]
+  b = out[1].split()
+  assert b[1] == "1" and b[3] == "1" and abs(float(b[5]) - 1.8) < 1e-12, out[1]

@@ -242,3 +242,25 @@ def test_kalmanfilter_stream_with_landmarks_and_window_shifts(env):
   for j in (0, n - 1):
     assert_close(kf.x[j], g["x_after"][-1], rtol=1e-8, floor=1e-10, what="stream API, state after the last window shift")
     assert_close(kf.P[j].reshape(1, -1), g["P_after"][-1].reshape(1, -1), rtol=1e-7, floor=1e-9)
+
+
+@pytest.mark.parametrize("passes", [1, 2])
+def test_smooth_shifts_the_augment_times_once(env, passes):
+  """smooth(augment=...) over the whole batch: the window shifts of the schedule are recorded in get_augment_times() ONCE, whatever
+  the number of passes (round-3 advice: run() shifted them once per pass and smooth() once more)."""
+  torch, gen, FK = env
+  g = _gold(env)
+  n = 4
+  kinds, ts = g["kinds"].astype(np.int32), g["ts"]
+  zs = np.tile(g["zs"][:, None, :], (1, n, 1))
+  eas = np.tile(g["eas"][:, None, :], (1, n, 1))
+  Rs = {1: FK.obs_noise[1], 2: FK.obs_noise[2]}
+  r = _filter(env, n)
+  before = list(r.get_augment_times())
+  r.run(ts, kinds, zs.copy(), Rs, extra_args=eas, augment=g["augment"])
+  want = list(r.get_augment_times())
+  f = _filter(env, n)
+  assert list(f.get_augment_times()) == before
+  f.smooth(ts, kinds, zs.copy(), Rs, passes=passes, extra_args=eas, augment=g["augment"], norm_quats=False)
+  torch.cuda.synchronize()
+  assert list(f.get_augment_times()) == want and want != before

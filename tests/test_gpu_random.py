@@ -67,12 +67,22 @@ def test_fused_run_and_step_path_vs_oracle(env):
   torch, gen, M = env
   from oracle_lib import OracleLib
   o = OracleLib(M.name)
-  if M.dim > 40:
-    from rednose_amd.helpers import KalmanError
-    g = _filter(env, 3)
-    with pytest.raises(KalmanError):         # 56 states: the fused run does not fit the register file and is left out: status 4, not a wrong answer
-      g.run(np.array([0.1]), np.array([1], dtype=np.int32), np.zeros((1, 3, 3)), {1: M.obs_noise[1]})
-    return
+  g = _filter(env, 3)
+  has_fused = bool(getattr(g._lib, f"{M.name}_has_batch_run")())        # pylint: disable=protected-access
+  if M.dim in (24, 32, 56):
+    # these models' fused kernels touch scratch memory as hipcc builds them and are left out (gen_code fallback no_run): the C entry
+    # point says so with status 4 -- never a wrong answer -- and BatchedEKF.run walks the schedule with the step-granular entry
+    # points instead (the rest of this test runs through that path)
+    assert not has_fused
+    import ctypes
+    fn = getattr(g._lib, f"{M.name}_batch_run")                          # pylint: disable=protected-access
+    z1 = torch.zeros((1, 3, 3), dtype=torch.float64, device=g.device); k1 = torch.ones(1, dtype=torch.int32, device=g.device)
+    rc = fn(g._p(g.x), g._p(g.P), g._p(g.Q), g._p(k1), g._p(z1), ctypes.c_int64(1), g._p(z1), g._p(z1), ctypes.c_int64(3), 0,      # pylint: disable=protected-access
+            None, None, None, None, None, None)
+    assert rc == 4
+    getattr(g._lib, f"{M.name}_clear_error")()                           # pylint: disable=protected-access
+  elif M.dim <= 17:
+    assert has_fused
   n, T = 41, 18
   rng = np.random.default_rng(M.dim)
   x0, P0 = _states(M, rng, n)

@@ -126,3 +126,43 @@ def test_late_observation_without_a_ring_is_an_error(gen):
   f.predict_and_update_batch(np.array([1.0, 2.0, 3.0, 4.0, 5.0]), 1, np.zeros((5, 1)), np.array([[0.01]]))
   with pytest.raises(AssertionError):
     f.predict_and_update_batch(np.array([1.5, 2.5, 2.9, 4.5, 5.5]), 1, np.zeros((5, 1)), np.array([[0.01]]))
+
+
+def test_estimate_and_flags_of_a_late_observation_are_its_own():
+  """Round-3 advice on the per-filter path: after a per-filter rewind the returned Estimate must be the state right after the
+  LATE observation (the reference captures `ret` before it fast-forwards, ekf_sym.py:473-479), not the fast-forwarded one, and the
+  flags the caller reads must be the late observation's (here: its Mahalanobis gate fired), not those of the replayed ones."""
+  import torch
+  from examples import ensure_generated
+  from examples.kinematic6_kf import Kinematic6Kalman as K6
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  gen6 = ensure_generated(["kinematic6_maha"])
+  n = 3
+  mk = lambda **kw: BatchedEKF(gen6, "kinematic6_maha", K6.Q, K6.initial_x, np.diag(K6.initial_P_diag), 6, 6, batch=n, maha_test_kinds=[1], **kw)   # noqa: E731
+  rng = np.random.default_rng(3)
+  R = K6.obs_noise[1]
+  ts = 0.01 * np.arange(1, 11)
+  zs = rng.normal(size=(10, n, 3)) * 0.1
+  z_late = zs[4].copy()
+  z_late[1] += 50.0                                   # a gross outlier for filter 1: its gate fires
+  f = mk(rewind_to_keep=32, per_filter=True)
+  for t, z in zip(ts, zs):
+    f.predict_and_update_batch(np.full(n, t), 1, z.copy(), R)
+  act = np.array([False, True, False])
+  est = f.predict_and_update_batch(np.full(n, 0.055), 1, z_late.copy(), R, active=act, keep_estimate=True)
+  torch.cuda.synchronize()
+  assert (f.flags.cpu().numpy()[1] & 1) == 1, "the late observation's gate flag must survive the replay"
+  # what the reference instance of filter 1 returns: observations up to 0.05, then the late one
+  a = mk()
+  for t, z in zip(ts[:5], zs[:5]):
+    a.predict_and_update_batch(float(t), 1, z.copy(), R)
+  a.predict_and_update_batch(0.055, 1, z_late.copy(), R)
+  torch.cuda.synchronize()
+  assert_close(est[1][1].cpu().numpy()[None], a.state()[1][None], rtol=1e-10, floor=1e-12, what="xk_k of the late observation")
+  assert_close(est[3][1].cpu().numpy().reshape(1, -1), a.covs()[1].reshape(1, -1), rtol=1e-10, floor=1e-12, what="Pk_k of the late observation")
+  # ... and the filter itself went on through the five observations it had overtaken
+  for t, z in zip(ts[5:], zs[5:]):
+    a.predict_and_update_batch(float(t), 1, z.copy(), R)
+  torch.cuda.synchronize()
+  assert_close(f.state()[1][None], a.state()[1][None], rtol=1e-9, floor=1e-11, what="state after the fast-forward")
+  assert np.abs(f.state()[1] - est[1][1].cpu().numpy()).max() > 1e-6, "the two must differ for this test to mean anything"

@@ -171,9 +171,10 @@ def test_fused_run_generates_for_wide_observations():
 
 
 def test_blocked_fused_run_is_emitted_and_falls_back(tmp_path, monkeypatch):
-  """Lane-per-filter models get a second fused-run kernel for untraced runs (k_run_blk, emit_small.run_kernel_blk): batch_run picks it
-  when no trace is asked for, {name}_run_unroll reports its block size, multi-kind models get a shorter block, and a build in which
-  ONLY that kernel spills is re-emitted without it (fallback no_run_blk) instead of moving the whole model to the lane-group family."""
+  """Lane-per-filter models run their fused schedules in blocks of steps (k_run_blk without the trace, k_run_blk_tr with it,
+  emit_small.run_kernel_blk): {name}_run_unroll reports the block size, multi-kind models get a shorter block, and a build in which
+  ONLY those kernels spill is re-emitted with the step-at-a-time k_run instead (fallback no_run_blk), not moved to the lane-group
+  family."""
   import examples.random_kf as R
   from examples.kinematic_kf import KinematicKalman
   from rednose_amd import build as rb
@@ -184,12 +185,13 @@ def test_blocked_fused_run_is_emitted_and_falls_back(tmp_path, monkeypatch):
   assert family(spec) == "small" and emit_small.run_block(spec) == 16
   _, src = emit(spec)
   launch = src.split("kinematic_batch_run(")[1]
-  assert "void k_run_blk(" in src and "if (trace_x == nullptr && trace_P == nullptr) {" in launch and "k_run_blk" in launch and "k_run," in launch
+  assert "void k_run_blk(" in src and "void k_run_blk_tr(" in src and "void k_run(" not in src
+  assert "if (trace_x == nullptr && trace_P == nullptr) {" in launch and "k_run_blk," in launch and "k_run_blk_tr," in launch
   assert "kinematic_run_unroll(void) { return 16; }" in src
   spec3 = build_spec(**R.Random3Kalman.model())           # three kinds: 16 / 3 -> blocks of 4 steps (code size)
   assert emit_small.run_block(spec3) == 4
   _, src = emit(spec, fallbacks=("no_run_blk",))
-  assert "k_run_blk" not in src and "kinematic_run_unroll(void) { return 8; }" in src      # the traced kernel's prefetch depth
+  assert "k_run_blk" not in src and "void k_run(" in src and "kinematic_run_unroll(void) { return 8; }" in src      # the step-at-a-time kernel's prefetch depth
   monkeypatch.setenv("RN_TUNE", "run_block=-1")
   assert emit_small.run_block(spec) == 0
   monkeypatch.delenv("RN_TUNE")
@@ -201,8 +203,9 @@ def test_blocked_fused_run_is_emitted_and_falls_back(tmp_path, monkeypatch):
     blk = "void k_run_blk(" in src_
     seen.append((blk, "family=small" in src_))
     usage = {"k_run": dict(vgprs=200, agprs=0, scratch=0, lds=0, vgpr_spill=0, occupancy=2)}
-    if blk:
-      usage["k_run_blk"] = dict(vgprs=256, agprs=256, scratch=32, lds=0, vgpr_spill=4, occupancy=1)
+    if blk:           # the traced twin is the one that does not fit
+      usage["k_run_blk"] = dict(vgprs=256, agprs=100, scratch=0, lds=0, vgpr_spill=0, occupancy=1)
+      usage["k_run_blk_tr"] = dict(vgprs=256, agprs=256, scratch=32, lds=0, vgpr_spill=4, occupancy=1)
     rb.compile_filter.last_usage = usage
     return f"{folder}/lib{name}.so"
   monkeypatch.setattr(rb, "compile_filter", fake_compile)

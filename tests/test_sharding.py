@@ -150,3 +150,29 @@ def test_bench_sweep_on_the_leased_gpu():
     assert p1["status"] == "ok" and p1["n_gpus"] == 1 and p1["global_batch"] == total and p1["value"] > 0
     assert p2["status"] == ("ok" if have >= 2 else "not run")
   assert out["n_gpus"] == (2 if have >= 2 else 1)
+
+
+@pytest.mark.gpu
+def test_bench_rccl_branch_on_one_gpu():
+  """RN_BENCH_FORCE_DIST=1: the N = 1 line goes through the process-group branch of the N > 1 run -- a one-rank RCCL communicator
+  on the leased GPU, barrier, device-tensor all-reduce of sharding.aggregate_throughput.  Not a scaling measurement (one GPU): it
+  shows that the branch the 8-GPU run takes loads librccl, creates a communicator and reduces, and that the line keeps its shape."""
+  import json
+  import subprocess
+  import sys
+  env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RN_BENCH_BACKEND")}
+  common = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "5", "--batch", "8192", "--no-extras",
+            "--no-cpu-baseline"]
+  lines = {}
+  for label, extra_env in (("plain", {}), ("forced", {"RN_BENCH_FORCE_DIST": "1", "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})):
+    res = subprocess.run(common, capture_output=True, text=True, env=dict(env, **extra_env), cwd=REPO, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    js = [ln for ln in res.stdout.split("\n") if ln.startswith("{")]
+    assert len(js) == 1, res.stdout[-2000:]
+    lines[label] = json.loads(js[0])
+  plain, forced = lines["plain"], lines["forced"]
+  assert forced["forced_process_group"] == {"backend": "nccl", "world_size": 1}
+  assert forced["n_gpus"] == 1 and forced["steps"] == 40 and forced["config"]["global_batch"] == 8192
+  assert set(forced) - {"forced_process_group"} == set(plain)
+  assert set(forced["roofline"]) == set(plain["roofline"]) and 0 < forced["roofline"]["frac"] < 1.2
+  assert abs(forced["value"] - 8192 * 40 / (forced["ms_per_step"] * 1e-3 * 40)) < 1e-6 * forced["value"]
