@@ -133,7 +133,12 @@ extern "C" {
 
 /* feature-track kinds of an MSCKF model additionally export the reference's extra-argument Jacobian:
  *   void {name}_He_{k}(double *state, double *ea, double *out)   -- Z x 3, ekf_sym.py:110-113; their updates project the
- *   residual, H and R on the left null space of it (ekf_c.c:66-76) and write Z - 3 residual rows back into z */
+ *   residual, H and R on the left null space of it (ekf_c.c:66-76) and write Z - 3 residual rows back into z (the last 3 entries of
+ *   z pass through).  BASIS of that residual: the reference writes A^T (z - h) with A = Hea^T.fullPivLu().kernel() (ekf_c.c:71-73,120),
+ *   a basis that is not orthonormal; these kernels use an ORTHONORMAL basis Q of the same space (Householder QR of Hea).  x and P do
+ *   not depend on the choice (tested to 1e-10); the residuals are related by y_ref = (A^T Q) y, and the quantity that does not
+ *   depend on the basis agrees: |y|^2 = y_ref^T (A^T A)^-1 y_ref = |projection of z - h on the null space|^2
+ *   (tests/test_gpu_msckf.py::test_both_kinds_vs_oracle_strict checks it against the reference's A for every filter). */
 #define RN_DECLARE_BATCH_KIND(name, k)                                                                           \
   /* update only.  ea: (n, kind_eadim) extra arguments, one row per filter (NULL when the kind takes none).    \
    * flags (n bytes, may be NULL): bit0 = Mahalanobis gate fired (R inflated, ekf_c.c:88-94),                  \

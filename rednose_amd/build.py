@@ -12,8 +12,11 @@ import subprocess
 
 from rednose_amd.helpers import TEMPLATE_DIR
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wno-unused-value"]
+# -amdgpu-kernarg-preload-count: the first kernel arguments arrive in SGPRs with the dispatch instead of through an s_load the
+# wavefront waits for before it can issue its first tile load (gfx950 supports the preload; the code keeps the s_load prologue for
+# firmware that does not).  Same call, results bit-identical: headline launch 8.62 -> 8.46 us, live gyro launch 37.43 -> 37.13 us.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-Wno-unused-value",
+               "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def find_hipcc():

@@ -154,6 +154,7 @@ def kernel(spec):
   A(f"constexpr int RTS3_SLOT = {lay.SLOT};")
   A(f"constexpr int RTS3_IMG = {IMG};      // doubles of LDS image per filter: a full E x E matrix, or two packed triangles")
   A(scal)
+  qd_decl = "\n".join(f"  const double qd{s} = gQ[((c + {GL * s}) < {E} ? (c + {GL * s}) : 0) * {E + 1}];" for s in S)
   A(f"""
 __global__ {bounds} void k_rts3(const double* __restrict__ xf, const double* __restrict__ Pf, const double* __restrict__ ts,
     const int64_t T, const double* __restrict__ gQ, const int64_t n, const int norm_quats, double* __restrict__ xs,
@@ -166,6 +167,12 @@ __global__ {bounds} void k_rts3(const double* __restrict__ xf, const double* __r
   const int lane = threadIdx.x;
   const int g = lane / {GL};
   const int c = lane % {GL};
+  // a diagonal process noise (the usual case) lives in registers, as in the fused run (emit_wide3.predict_fn): the rows of Q were 3 E
+  // eight-byte loads per lane and step, each instruction a gather of eight rows
+  int qoff = 0;
+  for (int i = lane; i < {EE}; i += 64) qoff |= (i / {E} != i % {E}) && (gQ[i] != 0.0);
+  const bool qdiag = !__any(qoff);
+{qd_decl}
   const int64_t tiles = (n + {FPW} - 1) / {FPW};
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
     const int64_t base = tile * {FPW};
@@ -246,7 +253,18 @@ __global__ {bounds} void k_rts3(const double* __restrict__ xf, const double* __r
       A(f"      y{s}[{i}] = {sum_terms(term(cf, f'a{s}[{kk}]') for kk, cf in Fs.row_nz(i))};")
   rows_to_image("y")
   A("      rn::wave_lds_sync();")
-  A("      {")
+  A("      if (qdiag) {")
+  for s in S:
+    A("        {")
+    A(f"          double col[{E}];")
+    A(f"          const double dq = dt * qd{s};")
+    A("#pragma unroll")
+    A(f"          for (int m = 0; m < {E}; m++) col[m] = sI[m * {E} + rc{s}];      // column of A = row of Fk Pk_k")
+    for j in range(E):
+      diag = f" + (rc{s} == {j} ? dq : 0.0)" if GL * s <= j < GL * (s + 1) else ""      # the lane's own row index is c + GL s
+      A(f"          a{s}[{j}] = {sum_terms(term(cf, f'col[{m}]') for m, cf in Fs.row_nz(j))}{diag};")
+    A("        }")
+  A("      } else {")
   A("        int qz = 0;")
   A('        asm volatile("" : "+v"(qz));       // Q behind an opaque zero: its addresses are not worth registers across the step loop')
   A("        const double* __restrict__ gq = gQ + qz;")
@@ -293,23 +311,40 @@ __global__ {bounds} void k_rts3(const double* __restrict__ xf, const double* __r
   A("      }")
   A("      rn::wave_lds_sync();")
   A('      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the previous step\'s output stores have reached the L2')
-  A(f"      {rows_decl('pn')}      // rows of Pk1_n, read back from Ps[k + 1] (L2-served: nontemporal, not this CU's L1 -- another lane stored them)")
-  for s in S:
-    if E % 2 == 0:
-      A("      {")
-      A("        typedef double rts3_v2d __attribute__((ext_vector_type(2)));")
-      A(f"        const rts3_v2d* pn_ = reinterpret_cast<const rts3_v2d*>(Ps + (((k + 1) * n + base + gg) * {EE} + rc{s} * {E}));")
-      A("#pragma unroll")
-      A(f"        for (int j = 0; j < {E // 2}; j++) {{ const rts3_v2d v_ = __builtin_nontemporal_load(pn_ + j); pn{s}[2 * j] = v_.x; pn{s}[2 * j + 1] = v_.y; }}")
-      A("      }")
+  if aligned:
+    # Round 4: the smoothed covariance of step k + 1 comes back THROUGH THE IMAGE -- one coalesced asynchronous burst (1 KiB per
+    # wave-instruction, as for Pk_k in phase A), then conflict-free LDS row reads.  Until then every lane fetched its rows with 16-byte
+    # loads at a 176-byte stride: 33 instructions per lane and step, each a gather of 64 pieces that the texture-address path takes
+    # one cache line at a time (64 cycles an instruction, four wavefronts of a CU behind one such path): the 4 us "read back + D" of
+    # the phase timeline.  The image is free here (rows of Pk1_k are in a*), and the L1 is invalidated first: in place (Ps == Pf) this
+    # CU read the same addresses as Pf[k + 1] one step ago.
+    A('      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");')
+    if IMG == EE:
+      A(f"      rn::async_copy_g2l<{FPW} * {EE}>(Ps + ((k + 1) * n + base) * {EE}, cnt * {EE}, s_I, lb);")
     else:
+      A(f"      for (int f_ = 0; f_ < cnt; f_++) rn::async_copy_g2l<{EE}>(Ps + ((k + 1) * n + base + f_) * {EE}, {EE}, s_I + f_ * RTS3_IMG, lb);")
+    A("      {")
+    A("        int lo = lane;")
+    A('        asm volatile("" : "+v"(lo));')
+    A(f"        for (int i = lo; i < cnt * {D}; i += 64) xs[((k + 1) * n + base) * {D} + i] = s_xn[i];      // smoothed state of step k + 1 (after its renormalisation)")
+    A("      }")
+    A("      rn::async_wait();")
+    A("      rn::wave_lds_sync();")
+    A(f"      {rows_decl('pn')}      // rows of Pk1_n up to each slot's last row (its lower block triangle is all D needs)")
+    for s in S:
+      A("#pragma unroll")
+      A(f"      for (int j = 0; j < {min(E, GL * s + GL)}; j++) pn{s}[j] = sI[rc{s} * {E} + j];")
+    A("      rn::wave_lds_sync();      // every lane has its rows: the image takes the two packed triangles")
+  else:
+    A(f"      {rows_decl('pn')}      // rows of Pk1_n, read back from Ps[k + 1] (L2-served: nontemporal, not this CU's L1 -- another lane stored them)")
+    for s in S:
       A("#pragma unroll")
       A(f"      for (int j = 0; j < {E}; j++) pn{s}[j] = __builtin_nontemporal_load(Ps + (((k + 1) * n + base + gg) * {EE} + rc{s} * {E}) + j);")
-  A("      {      // issued AFTER those loads: the wait for them then leaves these stores in flight (vmcnt retires in order)")
-  A("        int lo = lane;")
-  A('        asm volatile("" : "+v"(lo));')
-  A(f"        for (int i = lo; i < cnt * {D}; i += 64) xs[((k + 1) * n + base) * {D} + i] = s_xn[i];      // smoothed state of step k + 1 (after its renormalisation)")
-  A("      }")
+    A("      {      // issued AFTER those loads: the wait for them then leaves these stores in flight (vmcnt retires in order)")
+    A("        int lo = lane;")
+    A('        asm volatile("" : "+v"(lo));')
+    A(f"        for (int i = lo; i < cnt * {D}; i += 64) xs[((k + 1) * n + base) * {D} + i] = s_xn[i];      // smoothed state of step k + 1 (after its renormalisation)")
+    A("      }")
   for s in S:
     A("#pragma unroll")
     A(f"      for (int j = 0; j < {min(E, GL * s + GL)}; j++) {{      // (columns beyond the slot's last row are above the diagonal for every lane)")
@@ -462,6 +497,25 @@ __global__ {bounds} void k_rts3(const double* __restrict__ xf, const double* __r
   product("a", "y", lambda j, kk: f"sI[{j * E + kk}]", "e", "c", slots=below)
   A("      RN_RTS_STAMP(9);")
   A("      // ---- J. Pk_n = Pk_k + U leaves: U's rows through the image, then one coalesced read-add-write over the tile's records ----")
+  early = EE % 2 == 0          # (config 4 backward, same call: 66.35 ms per chunk with the early request, 66.90 ms without)
+  if early:
+    # The tile's filtered records are requested HERE, before U goes through the image: the coefficient row set of the last product
+    # (a*) is dead, its registers take the loads, and the HBM / Infinity Cache round trip passes under the image writes, the
+    # mirroring and the lead lanes' state update instead of being waited for after them.
+    IT = -(-(FPW * EE // 2) // 64)
+    A("      typedef double rts3_d2 __attribute__((ext_vector_type(2)));")
+    A("      int le = lane;")
+    A('      asm volatile("" : "+v"(le));')
+    A(f"      const rts3_d2* __restrict__ in2 = reinterpret_cast<const rts3_d2*>(Pf + (k * n + base) * {EE});")
+    A(f"      const int nv = cnt * {EE // 2};")
+    A(f"      rts3_d2 v[{IT}];")
+    A("#pragma unroll")
+    A(f"      for (int it = 0; it < {IT}; it++) {{ const int idx = le + 64 * it; v[it] = in2[idx < nv ? idx : nv - 1]; }}")
+    A("      if (k > 0) {")
+    A("#pragma unroll")
+    A(f"        for (int it = 0; it < {XT}; it++) {{ const int i = lane + 64 * it; xnext[it] = xf[((k - 1) * n + base) * {D} + (i < cnt * {D} ? i : 0)]; }}")
+    A("      }")
+    A("      __builtin_amdgcn_sched_barrier(0);")
   for s in S:
     ncol = min(E, GL * s + GL)        # columns this slot formed
     A(f"      if (ok{s}) {{")
@@ -483,24 +537,27 @@ __global__ {bounds} void k_rts3(const double* __restrict__ xf, const double* __r
         A("        }")
     A("      }")
     A("      rn::wave_lds_sync();")
-  A("      if (k > 0) {")
-  A("#pragma unroll")
-  A(f"        for (int it = 0; it < {XT}; it++) {{ const int i = lane + 64 * it; xnext[it] = xf[((k - 1) * n + base) * {D} + (i < cnt * {D} ? i : 0)]; }}")
-  A("      }")
+  if not early:
+    A("      if (k > 0) {")
+    A("#pragma unroll")
+    A(f"        for (int it = 0; it < {XT}; it++) {{ const int i = lane + 64 * it; xnext[it] = xf[((k - 1) * n + base) * {D} + (i < cnt * {D} ? i : 0)]; }}")
+    A("      }")
   A("      {")
-  A("        int le = lane;")
-  A('        asm volatile("" : "+v"(le));')
+  if not early:
+    A("        int le = lane;")
+    A('        asm volatile("" : "+v"(le));')
   # every load of the tile's records is issued before the first is used (a rolled loop of load -> add -> store pays one
   # memory round trip per iteration: 61 of them per step in the first build, half of the kernel's time in s_waitcnt)
   if EE % 2 == 0:
     IT = -(-(FPW * EE // 2) // 64)
-    A("        typedef double rts3_d2 __attribute__((ext_vector_type(2)));")
-    A(f"        const rts3_d2* __restrict__ in2 = reinterpret_cast<const rts3_d2*>(Pf + (k * n + base) * {EE});")
+    if not early:
+      A("        typedef double rts3_d2 __attribute__((ext_vector_type(2)));")
+      A(f"        const rts3_d2* __restrict__ in2 = reinterpret_cast<const rts3_d2*>(Pf + (k * n + base) * {EE});")
+      A(f"        const int nv = cnt * {EE // 2};")
+      A(f"        rts3_d2 v[{IT}];")
+      A("#pragma unroll")
+      A(f"        for (int it = 0; it < {IT}; it++) {{ const int idx = le + 64 * it; v[it] = in2[idx < nv ? idx : nv - 1]; }}")
     A(f"        rts3_d2* __restrict__ out2 = reinterpret_cast<rts3_d2*>(Ps + (k * n + base) * {EE});")
-    A(f"        const int nv = cnt * {EE // 2};")
-    A(f"        rts3_d2 v[{IT}];")
-    A("#pragma unroll")
-    A(f"        for (int it = 0; it < {IT}; it++) {{ const int idx = le + 64 * it; v[it] = in2[idx < nv ? idx : nv - 1]; }}")
     A("        if (lead) {      // state update, second half (see phase G): one lane per filter, while the loads above are in flight")
     A(f"          double xa[{D}], xnew[{D}], delta[{E}];")
     A("#pragma unroll")

@@ -361,10 +361,12 @@ __global__ __launch_bounds__(64){kattr} void k_step_{k.kind}(double* __restrict_
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
     const int64_t base = tile << 6;
     const int cnt = (n - base) < 64 ? (int)(n - base) : 64;
-    rn::tile_g2l_async<{D}>(gx + base * {D}, cnt, s_x, lane);
-    rn::tile_g2l_async<{EE}>(gP + base * {EE}, cnt, s_P, lane);
+    // the observations first: in a stream every launch reads a z buffer nothing has touched since it was written (HBM), while x and P
+    // were written by the previous launch and sit in the L2 / Infinity Cache -- the tile waits for its slowest load
     rn::tile_g2l_async<{Z}>(gz + base * {Z}, cnt, s_z, lane);
     if (r_per_filter) rn::tile_g2l_async<{ZZ}>(gR + base * {ZZ}, cnt, s_R, lane);
+    rn::tile_g2l_async<{D}>(gx + base * {D}, cnt, s_x, lane);
+    rn::tile_g2l_async<{EE}>(gP + base * {EE}, cnt, s_P, lane);
     double dt = dt_scalar;
     if (DO_PREDICT && gdt != nullptr && lane < cnt) dt = gdt[base + lane];
     rn::async_wait();

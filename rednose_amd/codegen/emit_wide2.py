@@ -263,7 +263,7 @@ def _lean_update(k, Hs, lay, E, rows_in_regs=False):
   b.append("if (act) { " + " ".join(f"sK[{zi} * {E} + cc] = kk[{zi}];" for zi in range(Z)) + f" sw[{lay.OFF_DX} + cc] = dxc; if (cc == 0) sw[{lay.OFF_FL}] = {fl}; }}")
   b.append("rn::wave_lds_sync();")
   src = "row[j]" if rows_in_regs else "pr[j]"
-  b += ["if (act) {", "#pragma unroll" if rows_in_regs else f"#pragma unroll {tuning.current().wide_lean_unroll}", f"  for (int j = 0; j < {E}; j++) {{",
+  b += ["if (act) {", "#pragma unroll" if rows_in_regs else "#pragma unroll 2", f"  for (int j = 0; j < {E}; j++) {{",
         f"    const double bj = {src} - (" + " + ".join(f"kk[{zi}]*sG[{zi * E} + j]" for zi in range(Z)) + ");",
         "    pr[j] = bj + (" + " + ".join(f"Dm_{zi}*sK[{zi * E} + j]" for zi in range(Z)) + ");", "  }", "}", "rn::wave_lds_sync();"]
   return b

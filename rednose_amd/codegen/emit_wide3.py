@@ -390,16 +390,6 @@ def run_kernel(spec):
   # the fused run's covariance is symmetric by contract (include/rednose_amd_filter.h): (P + P^T) / 2 of the caller's matrix, once, as
   # the rows enter the registers -- predict_fn / update_fn below use P = P^T, the reference's dense products use both halves
   load_rows = "\n".join(f"#pragma unroll\n    for (int j = 0; j < {E}; j++) row{s}[j] = 0.5 * (sP[rc{s} * {E} + j] + sP[j * {E} + rc{s}]);" for s in range(R))
-  # Covariance trace straight from the register rows, TRANSPOSED (knob run_trace_t): lane c of a group holds P[c + GL s][j]; written
-  # to element [j][c + GL s] of the record, the GL lanes of a group cover GL consecutive doubles (64 bytes for GL = 8) with one
-  # 8-byte store each -- no LDS image, no read-back, one instruction with an immediate offset per entry.  The record then holds the
-  # transpose of the register state, which equals it up to the rounding asymmetry of the Joseph form (the covariance is symmetric
-  # by contract).  Row-wise 16-byte stores of the same registers touch 64 different cache lines per instruction and were slower
-  # than the LDS image (profiles/tuning_notes.md); these touch 8.
-  trace_t = bool(tuning.current().run_trace_t)
-  tr_rows = "\n".join(
-    f"        if (ok{s}) {{\n" + "\n".join(f"          __builtin_nontemporal_store(row{s}[{j}], tpt + {j * E + GL * s});" for j in range(E)) + "\n        }"
-    for s in range(R))
   nlc = chr(10)
 
   def TL(ph):      # debug stamps (tuning knob wide_timeline; tools/timeline.py run): the last three steps, twenty stamps each
@@ -407,11 +397,11 @@ def run_kernel(spec):
       return ""
     return (f"if (lane == 0 && blockIdx.x < 256) {{ const int ti_ = (int)(t % 3) * 20 + {ph}; "
             "g_tl[(blockIdx.x * 64 + ti_) * 2] = __builtin_readcyclecounter(); g_tl[(blockIdx.x * 64 + ti_) * 2 + 1] = wall_clock64(); }")
-  if trace_t:
-    trace_store = f"""        double* tpt = tP + ((t * n + base + gg) * {EE} + c);
-{tr_rows}"""
-  else:
-    trace_store = f"""{img}
+  # (Measured and not kept, round 4: the trace straight from the register rows as 8-byte stores to the TRANSPOSED positions -- lane c of
+  # a group holds P[c + GL s][j]; written to [j][c + GL s] the lanes of a group cover 64 contiguous bytes per instruction, no LDS image,
+  # no read-back -- config 4 forward 70.6 ms per chunk against 22.6 ms through the image: 66 store instructions per lane and step, each
+  # a scatter of eight 64-byte pieces.  Round 3 measured the row-wise 16-byte variant at 25.3 ms.  profiles/tuning_notes.md.)
+  trace_store = f"""{img}
         rn::wave_lds_sync();
         rn::copy_l2g<FPWR * {EE}, {nt_trace}>(tP + (t * n + base) * {EE}, cnt * {EE}, s_P, lz);"""
   return f"""

@@ -10,11 +10,9 @@ variants do not overwrite generated/).  What each alternative measured: profiles
   wide_inline  0 = phase functions __noinline__
   wide_fpw     filters per wavefront in the matrix phase (0 = 64 // dim_err)
   wide_lean    1 = covariance rows stay in LDS (register-lean structure, two wavefronts per SIMD)
-  wide_lean_unroll  unroll factor of the lean update's in-place row pass (2: a few dozen live registers; more: its LDS reads overlap)
   wide_lean_q  1 = the lean predict takes its column of Q from registers instead of an LDS copy
   small_waves  amdgpu_waves_per_eu on the lane-per-filter step kernels
   small_max_e  largest error-state count served lane-per-filter
-  run_trace_t  1 = the lane-group fused run writes its covariance trace straight from the register rows, transposed (emit_wide3.run_kernel)
   nt_trace     1 = nontemporal stores for the fused run's covariance trace (lane-group models)
   run_block    steps per block of the lane-per-filter fused run without trace (0 = auto by model size, -1 = that kernel is not emitted)
   rts3_gl      lanes per filter of the emit_rts3 smoother (0 = the fused run's layout); rts3_lb: second argument of its __launch_bounds__
@@ -33,11 +31,9 @@ class Tuning:
   wide_fpw: int = 0
   wide_lean: int = 0
   wide_lean_q: int = 0
-  wide_lean_unroll: int = 2
   small_waves: int = 0
   small_max_e: int = 7
   run_block: int = 0
-  run_trace_t: int = 0
   rts3: int = 1
   rts3_gl: int = 0
   rts3_lb: int = 0

@@ -1035,7 +1035,8 @@ class BatchedEKF:
   def _run_stepwise(self, xv, Pv, kinds, dts, zs, Rd, nb, fl, tx, tP, ea, augment):
     """run() for a library without the fused multi-step kernel: the same schedule, one fused predict + update launch per step
     through the step-granular entry points (same results as the reference's per-call path; the state crosses HBM every step)."""
-    zmax = zs.shape[2]
+    # one contract for run(), whichever path serves it: the fused kernels read (P + P^T) / 2 (include/rednose_amd_filter.h)
+    Pv.copy_(0.5 * (Pv + Pv.transpose(1, 2)))
     for t in range(len(kinds)):
       k = int(kinds[t])
       Z = self.zdims[k]

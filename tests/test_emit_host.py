@@ -292,22 +292,6 @@ def test_generated_lane_group_step_on_the_host(tmp_path, name):
   assert (gated > 0) == (name == "live_maha")
 
 
-def test_lean_row_pass_unroll_knob_on_the_host(tmp_path, monkeypatch):
-  """The register-lean matrix phase with its row pass fully unrolled (knob wide_lean_unroll) against the oracle, function level (all
-  kinds of live) and kernel level (live_maha); the slot coefficients are read once, up front, in every build."""
-  monkeypatch.setenv("RN_TUNE", "wide_lean_unroll=22")
-  from rednose_amd.codegen import emit_wide2, tuning
-  from rednose_amd.codegen.spec import build_spec
-  M, mdl, kw, _ = _wide_model("live")
-  mdl = dict(mdl)
-  mdl["name"] = "live"
-  with tuning.using_model(build_spec(**mdl, **kw)):
-    text, _ = emit_wide2.device_functions(build_spec(**mdl, **kw))
-  assert "double fc[" in text and "double hc[" in text and "#pragma unroll 22" in text
-  test_generated_lane_group_step_on_the_host(tmp_path, "live")
-  test_lane_group_step_kernels_on_the_host(tmp_path, "live_maha")
-
-
 # ---- lane-group fused run (emit_wide3): GL lanes x R rows per filter, rows of P in registers for T steps ----------------------------
 # Same emulation (a thread per lane of one filter's group, wave_lds_sync() = barrier); the rows stay in each lane's "registers"
 # (thread-local arrays) from step to step like in k_run, only x / P / z move through the shared images.  Both predict variants
@@ -852,18 +836,14 @@ extern "C" __attribute__((visibility("default"))) void host_wide_run(int grid, d
   return ctypes.CDLL(str(lib)), FPW
 
 
-@pytest.mark.parametrize("trace_t", [0, 1], ids=["trace_image", "trace_transposed"])
 @pytest.mark.parametrize("name", ["kinematic9", "live_maha"])
-def test_lane_group_fused_run_kernel_on_the_host(tmp_path, name, trace_t, monkeypatch):
+def test_lane_group_fused_run_kernel_on_the_host(tmp_path, name):
   """k_run of the lane-group family, filtered trace and flags included, against the oracle's batch_run: a ragged last tile, fewer
   workgroups than tiles, a schedule mixing every non-feature kind with dt = 0 steps, gated observations, an unknown kind (flag 8,
   observation passes through).  The input covariances are ASYMMETRIC: the fused run is specified on (P + P^T) / 2
-  (include/rednose_amd_filter.h), which is what the oracle is given.  Both trace paths: through the LDS image, and straight from the
-  register rows, transposed (knob run_trace_t)."""
+  (include/rednose_amd_filter.h), which is what the oracle is given."""
   from oracle_lib import OracleLib
   from rednose_amd.codegen.spec import build_spec
-  if trace_t:
-    monkeypatch.setenv("RN_TUNE", "run_trace_t=1")
   M, mdl, kw, quat_idx = _wide_model(name)
   mdl = dict(mdl)
   mdl["name"] = name

@@ -79,6 +79,59 @@ def test_both_kinds_vs_oracle_strict(env, n):
       assert_close(f.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-10, floor=1e-12, what=what + " P")
       if kind == 1:
         assert_close(y.cpu().numpy(), zr, atol=1e-14 * np.abs(z).max(), what=what + " y")
+      else:
+        # Feature-track kinds: the residual written back into z is A^T (z - h) (ekf_c.c:73,120) and depends on the BASIS A of the
+        # left null space of Hea.  The reference takes Eigen's FullPivLU::kernel() (ekf_c.c:71: not orthonormal), these kernels an
+        # orthonormal one (Householder QR; include/rednose_amd_filter.h states it).  Both span the same space, so the residuals are
+        # related by y_ref = (A_ref^T Q) y_ours, and the form that does not depend on the basis must agree entry for entry of the
+        # batch: y_ref^T (A_ref^T A_ref)^-1 y_ref = |P_null (z - h)|^2 = |y_ours|^2 -- with A_ref rebuilt here by the same full-pivot
+        # elimination (the oracle's restatement of Eigen's algorithm) from the oracle's own Hea.  x and P above do not depend on it.
+        yh, Zp = y.cpu().numpy(), Z - 3
+        xpred = x0.copy()
+        for i in range(n):
+          Pd = P0[i].copy()
+          o.predict(xpred[i], Pd, FK.Q, 0.05)
+        for i in range(n):
+          Hea = np.zeros(Z * 3)
+          o.call(f"He_{kind}", xpred[i].copy(), landmarks[i].copy(), Hea)
+          Aref = _fullpiv_kernel(Hea.reshape(Z, 3).T)
+          assert Aref.shape == (Z, Zp)
+          w = zr[i, :Zp] @ np.linalg.solve(Aref.T @ Aref, zr[i, :Zp])
+          assert abs(w - yh[i, :Zp] @ yh[i, :Zp]) <= 1e-9 * max(w, 1e-30), f"{what} filter {i}: basis-independent form of the projected residual"
+          assert np.array_equal(yh[i, Zp:], z[i, Zp:]), what + ": the last 3 entries of z pass through (y has Z - 3 rows, ekf_c.c:120)"
+
+
+def _fullpiv_kernel(M):
+  """Basis of the right null space of M (rows x cols) the way Eigen's FullPivLU::kernel() builds it (ekf_c.c:71 calls it on Hea^T):
+  Gaussian elimination with full pivoting, P M Q = L U, U = [U1 U2], kernel vectors Q [-U1^-1 U2 ; I] (oracle/ekf_oracle.c
+  fullpiv_kernel is the same restatement in C)."""
+  U = np.array(M, dtype=np.float64)
+  rows, cols = U.shape
+  perm = list(range(cols))
+  rank, maxpiv = 0, 0.0
+  for k in range(min(rows, cols)):
+    sub = np.abs(U[k:, k:])
+    pr, pc = np.unravel_index(np.argmax(sub), sub.shape)
+    best = sub[pr, pc]
+    pr, pc = pr + k, pc + k
+    if k == 0:
+      maxpiv = best
+    if best <= 2.220446049250313e-16 * max(rows, cols) * maxpiv:
+      break
+    U[[k, pr]] = U[[pr, k]]
+    U[:, [k, pc]] = U[:, [pc, k]]
+    perm[k], perm[pc] = perm[pc], perm[k]
+    for i in range(k + 1, rows):
+      U[i, k:] -= U[i, k] / U[k, k] * U[k, k:]
+    rank += 1
+  nk = cols - rank
+  ker = np.zeros((cols, nk))
+  for c in range(nk):
+    v = np.linalg.solve(np.triu(U[:rank, :rank]), -U[:rank, rank + c])
+    for i in range(rank):
+      ker[perm[i], c] = v[i]
+    ker[perm[rank + c], c] = 1.0
+  return ker
 
 
 def test_stream_with_window_shifts_vs_reference_numpy(env):

@@ -60,6 +60,17 @@ def timed(fn, reps):
   return out
 
 
+if os.environ.get("RN_PROBE_BEKF") and MODE == "tensors":
+  # does merely CONSTRUCTING the orchestrator (library loaded through load_code, a handful of small torch tensors, init_state's copies)
+  # change the timing of the raw launches below?  (tools/gap_probe3.py: every variant of a process that had one was slow)
+  sys.path.insert(0, os.path.join(HERE, ".."))
+  from examples.kinematic_kf import KinematicKalman as _M
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  _f = BatchedEKF(os.path.join(HERE, "..", os.environ.get("RN_GEN", "generated")), "kinematic", _M.Q, _M.initial_x, np.diag(_M.initial_P_diag), 2, 2,
+                  batch=65536, device="cuda:0")
+  if os.environ.get("RN_PROBE_BEKF") == "2":
+    del _f
+  torch.cuda.synchronize()
 rt = ctypes.c_int(0)
 hip.hipRuntimeGetVersion(ctypes.byref(rt))
 gen = os.path.join(HERE, "..", os.environ.get("RN_GEN", "generated"))
