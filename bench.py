@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 STEADY_GROUP = 50              # launches per group of the steady-state warm-up (run_model)
 STEADY_MIN_S = 0.1             # ... its minimum duration (clocks keep rising for milliseconds after the first launches)
 STEADY_CAP_S = 0.5             # ... and its time limit
-MEDIAN_GROUP = 10              # launches per event interval of the launch-duration distribution pass
+MEDIAN_GROUP = 10              # fewest launches between two markers of the timed region (launch-duration distribution)
 FP64_VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9     # 256 CUs x 4 SIMDs x 16 fp64 lanes per clock x 2.4 GHz = 39.3 T lane-instructions/s
 #                                               (78.6 TFLOP/s vector fp64 counts an FMA as two)
 
@@ -339,30 +339,31 @@ def run_model(torch, dist, model, n, K, W, dev, rank, world, only_kind=None):
   if dist is not None and dist.is_initialized():
     dist.barrier()
   torch.cuda.synchronize()
+  # The timed region: exactly K steps between ev0 and ev1 (mean launch duration = their interval / K).  A marker every G launches
+  # inside it (at most 50 of them: a marker is one queue packet, no kernel) gives the distribution: launch_us_median is the median
+  # of the per-group means -- the same launches, the same observation buffers, nothing replayed.
+  G = max(MEDIAN_GROUP, -(-K // 50))
   ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  spare = [torch.cuda.Event(enable_timing=True) for _ in range(K // G + 1)]      # created outside the timed region
+  marks = [(W, ev0)]
   t0 = time.perf_counter()
   ev0.record()
   for i in range(W, W + K):
     step(i)
+    if (i + 1 - W) % G == 0 and i + 1 < W + K:
+      m_ = spare.pop()
+      m_.record()
+      marks.append((i + 1, m_))
   ev1.record()
+  marks.append((W + K, ev1))
   torch.cuda.synchronize()
   if dist is not None and dist.is_initialized():
     dist.barrier()
   torch.cuda.synchronize()
   wall = time.perf_counter() - t0
   dev_ms = ev0.elapsed_time(ev1)
-  # Distribution of the launch duration (NOT part of the timed region above, which carries no event between its K launches): the
-  # same entry points again in groups of MEDIAN_GROUP launches with an event pair around each group; median over the groups.
+  groups = [a[1].elapsed_time(b[1]) * 1e3 / (b[0] - a[0]) for a, b in zip(marks[:-1], marks[1:])]
   assert torch.isfinite(f.x).all() and torch.isfinite(f.P).all(), "filter diverged: refusing to report a timing"
-  groups = []
-  if os.environ.get("RN_BENCH_NO_STEADY") != "1":
-    x_keep, P_keep = f.x.clone(), f.P.clone()
-    ng = max(3, min(50, K // MEDIAN_GROUP))
-    evs = [untimed_group(g_ * MEDIAN_GROUP, MEDIAN_GROUP) for g_ in range(ng)]
-    torch.cuda.synchronize()
-    groups = [a.elapsed_time(b) * 1e3 / MEDIAN_GROUP for a, b in evs]
-    f.x.copy_(x_keep)
-    f.P.copy_(P_keep)
   zdims = [f.zdims[sched[i][0]] for i in range(W, W + K)]
   bytes_per_step = 8.0 * (2 * (D + E * E) + 2 * float(np.mean(zdims)))
   return dict(M=M, D=D, E=E, Z=float(np.mean(zdims)), wall=wall, dev_ms=dev_ms, bytes_per_step=bytes_per_step, gen=gen,

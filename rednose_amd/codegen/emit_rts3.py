@@ -111,14 +111,11 @@ def sym(i, j):
 
 
 def layout(spec):
-  """The fused run's layout (emit_wide3.layout) unless the experiment knob rts3_gl asks for wider lane groups -- fewer filters and
-  rows per wavefront, so that two wavefronts fit a SIMD's registers and a CU's LDS (rts3_lb = 2)."""
+  """The fused run's layout (emit_wide3.layout).  Wider lane groups at two wavefronts per SIMD (16 lanes x 2 rows: 114 spilled registers
+  under the 256 budget; 32 lanes x 1 row: 7.58 ms against 4.48 ms on 16 384 x 60 steps) were measured in round 3 and removed in round 4:
+  profiles/tuning_notes.md."""
   from rednose_amd.codegen import emit_wide3 as w3
-  from rednose_amd.codegen import tuning
-  gl = tuning.current().rts3_gl
-  if not gl:
-    return w3.layout(spec)
-  return gl, -(-spec.dim_err // gl), 64 // gl
+  return w3.layout(spec)
 
 
 def kernel(spec):
@@ -130,8 +127,7 @@ def kernel(spec):
   IMG = max(EE, 2 * TRI)
   IMG += IMG & 1
   GL, R, FPW = layout(spec)
-  lb = tuning.current().rts3_lb
-  bounds = f"__launch_bounds__(64, {lb})" if lb else "__launch_bounds__(64)"
+  bounds = "__launch_bounds__(64)"
   scal, lay = _scal_text(spec)
   _, Fs = _tables(spec)
   quat = "".join(f" rn::normalize_quat<{D}>(xv, {q});" for q in spec.quaternion_idxs)
@@ -215,7 +211,9 @@ __global__ {bounds} void k_rts3(const double* __restrict__ xf, const double* __r
   else:
     A(f"      for (int i = lb; i < cnt * {EE}; i += 64) s_I[(i / {EE}) * RTS3_IMG + i % {EE}] = Pf[(k * n + base) * {EE} + i];      // (odd record size)")
     pre_wait = None
-  A("      {      // xk_k was requested at the end of the previous (newer) step (before the loop for the first): its round trip is off the path")
+  A("      {      // xk_k was requested at the end of the previous (newer) step (before the loop for the first).  (Committing it BEFORE the copy is")
+  A("             // issued -- its wait is a vmcnt(0), the value crosses the loop's back edge, and behind the copy it waits for the burst to land --")
+  A("             // measured slower, 67.3 against 66.0 ms per config-4 chunk: the wait then delays the ISSUE of the copy by the store drain.)")
   A("#pragma unroll")
   A(f"        for (int it = 0; it < {XT}; it++) {{ const int i = lb + 64 * it; if (i < cnt * {D}) s_xk[i] = xnext[it]; }}")
   A("      }")

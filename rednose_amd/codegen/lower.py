@@ -6,9 +6,9 @@ becomes `pow(x, 2)`; live.cpp contains 1 638 pow(), 252 sin(), 234 cos() calls -
 On a GPU that turns a memory-bound filter step into a transcendental-bound one, so here
 
   * all outputs of a fused block (e.g. f and F, or h and H.H_mod) go through ONE `sympy.cse` pass;
-  * small integer powers are printed as multiplications, half-integer powers through sqrt
-    (`pow(r2, -1.5)` -> `1.0/(r2*sqrt(r2))`), everything else uses the C99 names which hipcc maps
-    to the ocml double-precision device functions;
+  * small integer powers are printed as multiplications, reciprocals as `rn::fast_recip`, negative half-integer powers as odd
+    powers of the reciprocal square root (`pow(r2, -1.5)` -> `rn::rsqrt_pow<3>(r2)`), positive ones through sqrt, everything else
+    uses the C99 names which hipcc maps to the ocml double-precision device functions;
   * entries that are structurally 0 / 1 / numeric constants are reported as such so the kernel
     emitters can skip or fold them (sparsity is resolved at generation time, never at run time).
 
@@ -48,14 +48,15 @@ class HipPrinter(C99CodePrinter):
       if 1 <= n <= 4:
         return self._mul_chain(base, n)
       if -4 <= n <= -1:
-        return f"(1.0/{self._mul_chain(base, -n)})"
+        return f"rn::fast_recip({self._mul_chain(base, -n)})"      # v_rcp_f64 + two Newton steps (templates/ekf_hip_rt.h): 5 dependent instructions, an IEEE division ~12
     if exp.is_Rational or exp.is_Float:
       two = sp.nsimplify(2 * exp)
       if two.is_Integer and abs(int(two)) <= 9 and int(two) % 2:
         k = (abs(int(two)) - 1) // 2          # |exp| = k + 1/2
+        if two < 0:      # a^-(k + 1/2): odd power of the reciprocal square root (rn::rsqrt_pow), no IEEE sqrt / division chain
+          return f"rn::rsqrt_pow<{2 * k + 1}>({self._print(base)})"
         root = f"sqrt({self._print(base)})"
-        body = root if k == 0 else f"({self._mul_chain(base, k)}*{root})"
-        return body if two > 0 else f"(1.0/{body})"
+        return root if k == 0 else f"({self._mul_chain(base, k)}*{root})"
     return super()._print_Pow(expr)
 
   def _print_Rational(self, expr):

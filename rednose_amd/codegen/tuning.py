@@ -15,7 +15,6 @@ variants do not overwrite generated/).  What each alternative measured: profiles
   small_max_e  largest error-state count served lane-per-filter
   nt_trace     1 = nontemporal stores for the fused run's covariance trace (lane-group models)
   run_block    steps per block of the lane-per-filter fused run without trace (0 = auto by model size, -1 = that kernel is not emitted)
-  rts3_gl      lanes per filter of the emit_rts3 smoother (0 = the fused run's layout); rts3_lb: second argument of its __launch_bounds__
   rts3         1 = smoother of lane-group models in the fused run's layout (emit_rts3: 8 filters per wavefront), 0 = rn::k_rts_group
 """
 import os
@@ -35,8 +34,6 @@ class Tuning:
   small_max_e: int = 7
   run_block: int = 0
   rts3: int = 1
-  rts3_gl: int = 0
-  rts3_lb: int = 0
   nt_trace: int = 1          # the fused run's covariance trace leaves with nontemporal stores (config 4 forward: 23.5 vs 24.5 ms per chunk, same call)
   wide_timeline: int = 0     # debug: lane 0 of the first 256 workgroups stamps s_memtime / the 100 MHz wall clock at every phase boundary of
                              # the three-phase step kernels into a device buffer read back by {name}_debug_timeline (tools/timeline.py)

@@ -376,6 +376,21 @@ __device__ __forceinline__ double fast_rsqrt(const double a) {
   return y;
 }
 
+// a^(-N/2) for odd N (sympy's pow(r2, -1.5), pow(r2, -2.5) of gravity-like terms): powers of the reciprocal square root instead of an
+// IEEE sqrt followed by an IEEE division -- two chains of ~20 and ~12 DEPENDENT fp64 instructions on the one lane per filter that
+// evaluates the model's scalars (40 cycles each for a lone wavefront), against 7 + (N + 1) / 2 here.  Within an ulp or two of the
+// correctly rounded composition (tests/test_gpu_parity.py::test_scalar_sympy_routines_on_gpu bounds it against the oracle's libm).
+template <int N>
+__device__ __forceinline__ double rsqrt_pow(const double a) {
+  static_assert(N >= 1 && N <= 9 && (N & 1), "odd powers of 1 / sqrt(a)");
+  const double r = fast_rsqrt(a);
+  const double r2 = r * r;
+  double p = r;
+#pragma unroll
+  for (int i = 0; i < (N - 1) / 2; i++) p *= r2;
+  return p;
+}
+
 // ---- left null space of the extra-argument Jacobian (MSCKF, /root/reference/rednose/templates/ekf_c.c:66-76) --------
 // The reference projects the residual, H and R of a feature-track observation on A = kernel(Hea^T) (Eigen fullPivLu;
 // numpy twin: SVD null space, ekf_sym.py:20-26,583).  Any basis of that null space gives the same x and P; we use the
@@ -578,11 +593,14 @@ __device__ __forceinline__ void ldu_solve(const double (&LU)[Z * Z], const doubl
 // EKFSym::normalize_slice (/root/reference/rednose/helpers/ekf_sym.cc:75-77): x[idx:idx+4] /= ||.||
 template <int DIM>
 __device__ __forceinline__ void normalize_quat(double (&x)[DIM], int idx) {
-  const double n = sqrt(x[idx] * x[idx] + x[idx + 1] * x[idx + 1] + x[idx + 2] * x[idx + 2] + x[idx + 3] * x[idx + 3]);
-  x[idx] /= n;
-  x[idx + 1] /= n;
-  x[idx + 2] /= n;
-  x[idx + 3] /= n;
+  // one reciprocal square root (v_rsq_f64 + two Newton steps, fast_rsqrt) and four multiplications: the IEEE sqrt + four IEEE
+  // divisions this replaces were ~30 dependent fp64 instructions on the one lane per filter that runs it, twice per step (after
+  // predict and after the update) -- about a microsecond of every step of the fused run.  Differs from Eigen's normalize() in the last bit.
+  const double r = fast_rsqrt(x[idx] * x[idx] + x[idx + 1] * x[idx + 1] + x[idx + 2] * x[idx + 2] + x[idx + 3] * x[idx + 3]);
+  x[idx] *= r;
+  x[idx + 1] *= r;
+  x[idx + 2] *= r;
+  x[idx + 3] *= r;
 }
 
 // ------------------------------------------------------------------------------------------------

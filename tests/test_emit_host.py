@@ -38,7 +38,7 @@ def _host_library(tmp_path, spec, sym=False):
   registers (emit_small.predict_regs)."""
   from rednose_amd.codegen import emit_small
   hdr = open(HDR, encoding="utf-8").read()
-  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "normalize_quat"))
+  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "normalize_quat"))
   D, E = spec.dim_x, spec.dim_err
   body = [emit_small.predict_regs(spec, sym)[0]] + [emit_small.update_regs(spec, k, sym)[0] for k in spec.kinds]
   sfx = "_sym" if sym else ""
@@ -66,6 +66,7 @@ extern "C" int host_step_{k.kind}(double* gx, double* gP, const double* Q, doubl
 }}""")
   src = "\n".join(["#include <cmath>", "#include <cstdint>", "#define __device__", "#define __forceinline__ inline",
                    "namespace rn {", "inline double fast_recip(const double d) { return 1.0 / d; }      // device: v_rcp_f64 + two Newton steps",
+                   "inline double fast_rsqrt(const double a) { return 1.0 / std::sqrt(a); }      // device: v_rsq_f64 + two Newton steps",
                    helpers, "}  // namespace rn"] + body + entry)
   cpp, lib = tmp_path / f"{spec.name}{sfx}_host.cpp", tmp_path / f"lib{spec.name}{sfx}_host.so"
   cpp.write_text(src, encoding="utf-8")
@@ -154,7 +155,7 @@ def test_generated_lane_per_filter_arithmetic_on_the_host(tmp_path, name, sym):
 def _wide_host_library(tmp_path, spec):
   from rednose_amd.codegen import emit_wide2, tuning
   hdr = open(HDR, encoding="utf-8").read()
-  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "normalize_quat"))
+  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "normalize_quat"))
   with tuning.using_model(spec):
     text, lay = emit_wide2.device_functions(spec)
     GL = emit_wide2.group_lanes(spec)
@@ -208,7 +209,7 @@ extern "C" int host_wide_step_{k.kind}(double* x, double* P, const double* Q, do
   src = "\n".join(["#include <cmath>", "#include <cstdint>", "#include <pthread.h>", "#define __device__", "#define __forceinline__ inline",
                    "#define __noinline__", "#define __builtin_amdgcn_sched_barrier(x)", "static pthread_barrier_t g_bar;", "static bool g_sync_on = false;", "namespace rn {",
                    "inline void wave_lds_sync() { if (g_sync_on) pthread_barrier_wait(&g_bar); }      // device: a compiler fence inside one wavefront",
-                   "inline double fast_recip(const double d) { return 1.0 / d; }", helpers, "}  // namespace rn"] + fns + entry)
+                   "inline double fast_recip(const double d) { return 1.0 / d; }", "inline double fast_rsqrt(const double a) { return 1.0 / std::sqrt(a); }", helpers, "}  // namespace rn"] + fns + entry)
   cpp, lib = tmp_path / f"{spec.name}_wide_host.cpp", tmp_path / f"lib{spec.name}_wide_host.so"
   cpp.write_text(src, encoding="utf-8")
   res = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", str(cpp), "-o", str(lib)], capture_output=True, text=True)
@@ -301,7 +302,7 @@ def test_generated_lane_group_step_on_the_host(tmp_path, name):
 def _run_host_library(tmp_path, spec):
   from rednose_amd.codegen import emit_wide2 as w2, emit_wide3 as w3, tuning
   hdr = open(HDR, encoding="utf-8").read()
-  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "normalize_quat"))
+  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "normalize_quat"))
   D, E = spec.dim_x, spec.dim_err
   kinds = [k for k in spec.kinds if k.He_sym is None and k.ea_sym is None]
   with tuning.using_model(spec):
@@ -321,7 +322,7 @@ def _run_host_library(tmp_path, spec):
                    "#define __noinline__", "static pthread_barrier_t g_bar;",
                    "static thread_local bool t_scalar = false;      // inside a scalar-phase function (one lane): its fences are not barriers",
                    "namespace rn {", "inline void wave_lds_sync() { if (!t_scalar) pthread_barrier_wait(&g_bar); }", "inline void pin(double&) {}",
-                   "inline double fast_recip(const double d) { return 1.0 / d; }", helpers, "}  // namespace rn"] + fns + [f"""
+                   "inline double fast_recip(const double d) { return 1.0 / d; }", "inline double fast_rsqrt(const double a) { return 1.0 / std::sqrt(a); }", helpers, "}  // namespace rn"] + fns + [f"""
 struct Job {{ double* x; double* sP; const double* Q; const double* R; const int* kinds; const double* dts; double* z; int T; double* sl; double* sG;
              unsigned char* flags; int c; int norm_quats; int qdiag; int skip_dt0; }};
 static void* lane(void* p) {{
@@ -496,13 +497,14 @@ inline void wave_lds_sync() { pthread_barrier_wait(&g_bar); }
 inline void async_wait() {}
 inline void pin(double&) {}
 inline double fast_recip(const double d) { return 1.0 / d; }
+inline double fast_rsqrt(const double a) { return 1.0 / std::sqrt(a); }
 """
 
 
 def _kernel_host_library(tmp_path, spec):
   from rednose_amd.codegen import emit_small
   hdr = open(HDR, encoding="utf-8").read()
-  names = ("lds_stride", "tile_g2l", "tile_l2g", "lds_to_regs", "regs_to_lds", "spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "normalize_quat")
+  names = ("lds_stride", "tile_g2l", "tile_l2g", "lds_to_regs", "regs_to_lds", "spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "normalize_quat")
   helpers = "\n".join(_function_text(hdr, f) for f in names)
   at = hdr.index("struct TilePrefetch")
   prefetch = hdr[hdr.rfind("template <", 0, at):hdr.index("};", at) + 2]
@@ -698,7 +700,7 @@ inline void sched_barrier_(int) {}
 def _wide_kernel_host_library(tmp_path, spec):
   from rednose_amd.codegen import emit_wide2, tuning
   hdr = open(HDR, encoding="utf-8").read()
-  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "normalize_quat"))
+  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "normalize_quat"))
   with tuning.using_model(spec):
     text = emit_wide2.kernels(spec)
     FT = emit_wide2.tile_filters(spec)
@@ -814,7 +816,7 @@ inline int host_readfirstlane(int v) {  // every lane is active wherever the ker
 def _wide_run_kernel_host_library(tmp_path, spec):
   from rednose_amd.codegen import emit_wide3, tuning
   hdr = open(HDR, encoding="utf-8").read()
-  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "normalize_quat"))
+  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "normalize_quat"))
   with tuning.using_model(spec):
     text = emit_wide3.kernels(spec)
     _, _, FPW = emit_wide3.layout(spec)

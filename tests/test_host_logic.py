@@ -211,3 +211,33 @@ def test_blocked_fused_run_is_emitted_and_falls_back(tmp_path, monkeypatch):
   monkeypatch.setattr(rb, "compile_filter", fake_compile)
   KinematicKalman.generate_code(str(tmp_path))
   assert seen == [(True, True), (False, True)], seen       # second build: same family, without the blocked kernel
+
+
+def test_cffi_branch_of_load_code_runs_the_known_answers(monkeypatch):
+  """`load_code` prefers cffi where it is importable -- which is every real rednose environment (rednose/helpers/__init__.py:3,18-31)
+  -- and this image has none, so that branch (header lines -> ffi.cdef -> ffi.dlopen, ffi.cast marshalling in EKF_sym) never ran.
+  Here it runs against the ctypes-backed stand-in the oracle tooling uses to import the reference (oracle/cffi_shim: cdef / dlopen /
+  cast, the three cffi features the reference's orchestrator uses): the known-answer stream of test_kinematic_kf.py through
+  EKF_sym over the cffi-loaded library, and the loader's refusal logic.  It is a stand-in, not cffi: what this pins is OUR side of
+  the branch."""
+  import sys
+  from conftest import REPO
+  import rednose_amd.helpers as H
+  monkeypatch.syspath_prepend(os.path.join(REPO, "oracle", "cffi_shim"))
+  monkeypatch.delenv("RN_LOADER", raising=False)
+  sys.modules.pop("cffi", None)
+  try:
+    ffi, lib = H.load_code(oracle_folder("kinematic"), "kinematic", backend="cffi")
+    assert type(ffi).__module__ == "cffi" and not isinstance(ffi, H.CtypesFFI)
+    assert "kinematic_predict" in dir(lib) and "kinematic_h_1" in dir(lib)
+    g = golden("kinematic_stream.npz")
+    f = EKF_sym(oracle_folder("kinematic"), "kinematic", np.diag([0.1**2, 2.0**2]), np.array([0.5, 0.0]), np.diag([1.0, 1.0]), 2, 2)
+    assert type(f._ffi).__module__ == "cffi"           # pylint: disable=protected-access
+    R = np.array([[[0.1**2]]])
+    for t, meas in zip(g["ts"], g["zs"]):
+      f.predict_and_update_batch(t, 1, np.array([[meas]]), R)
+    x, std = f.state(), np.sqrt(np.diag(f.covs()))
+    for got, want in zip((x[0], std[0], x[1], std[1]), g["literals"]):
+      assert round(abs(got - want), 7) == 0
+  finally:
+    sys.modules.pop("cffi", None)
