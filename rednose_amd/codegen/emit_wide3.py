@@ -401,6 +401,17 @@ def run_kernel(spec):
   # a group holds P[c + GL s][j]; written to [j][c + GL s] the lanes of a group cover 64 contiguous bytes per instruction, no LDS image,
   # no read-back -- config 4 forward 70.6 ms per chunk against 22.6 ms through the image: 66 store instructions per lane and step, each
   # a scatter of eight 64-byte pieces.  Round 3 measured the row-wise 16-byte variant at 25.3 ms.  profiles/tuning_notes.md.)
+  # (Measured and not kept, round 4, profiles/tuning_notes.md: the copy of a step's covariance trace DEFERRED into the next step and woven
+  # between the statements of its scalar phase when that step has no predict -- LDS / store throughput under a chain of dependent fp64
+  # instructions, the arithmetic run redundantly on all lanes so that no divergent region separates the two streams.  Host-verified,
+  # parity-green on the device, and 8 % SLOWER: config 4 forward 23.6 ms per chunk against 21.8.)
+  scal_phase = f"""      if (c == 0 && live) {{
+        switch (kind) {{
+{nlc.join(scal_cases)}
+          default: bad = 8; break;      // unknown kind
+        }}
+      }}"""
+  pend_decl = flush_before_predict = flush_after_loop = ""
   trace_store = f"""{img}
         rn::wave_lds_sync();
         rn::copy_l2g<FPWR * {EE}, {nt_trace}>(tP + (t * n + base) * {EE}, cnt * {EE}, s_P, lz);"""
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
     rn::wave_lds_sync();
 {decl_rows}
 {load_rows}
-    for (int64_t t = 0; t < T; t++) {{
+{pend_decl}    for (int64_t t = 0; t < T; t++) {{
 {z_next}
       const int kind = kinds[t];
       const double dt = dts[t];
@@ -458,7 +469,7 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       rn::wave_lds_sync();
       {TL(1)}
       if (do_pred) {{
-        if (qdiag) {{
+{flush_before_predict}        if (qdiag) {{
           predict_rows_qd({rows}, sP, {qd_args}, sl, {idx}{_tl_arg(True)});
         }} else {{
           int qz = 0;
@@ -469,12 +480,7 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       {TL(2)}
       // ---- phase 1b / 2b: update ----
       int bad = 0;
-      if (c == 0 && live) {{
-        switch (kind) {{
-{nlc.join(scal_cases)}
-          default: bad = 8; break;      // unknown kind
-        }}
-      }}
+{scal_phase}
       bad = __builtin_amdgcn_readfirstlane(__any(bad) ? 8 : 0);
       rn::wave_lds_sync();
       {TL(3)}
@@ -508,7 +514,7 @@ __global__ __launch_bounds__(64) void k_run(double* __restrict__ gx, double* __r
       rn::wave_lds_sync();
       {TL(7)}{aug}
     }}
-{img}
+{flush_after_loop}{img}
     rn::wave_lds_sync();
     int le = lane;
     asm volatile("" : "+v"(le));         // (same: nothing of the first copy's index arithmetic is kept alive across the step loop)

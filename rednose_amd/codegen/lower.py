@@ -6,7 +6,7 @@ becomes `pow(x, 2)`; live.cpp contains 1 638 pow(), 252 sin(), 234 cos() calls -
 On a GPU that turns a memory-bound filter step into a transcendental-bound one, so here
 
   * all outputs of a fused block (e.g. f and F, or h and H.H_mod) go through ONE `sympy.cse` pass;
-  * small integer powers are printed as multiplications, reciprocals as `rn::fast_recip`, negative half-integer powers as odd
+  * small integer powers are printed as multiplications, reciprocals as `rn::safe_recip`, negative half-integer powers as odd
     powers of the reciprocal square root (`pow(r2, -1.5)` -> `rn::rsqrt_pow<3>(r2)`), positive ones through sqrt, everything else
     uses the C99 names which hipcc maps to the ocml double-precision device functions;
   * entries that are structurally 0 / 1 / numeric constants are reported as such so the kernel
@@ -48,7 +48,7 @@ class HipPrinter(C99CodePrinter):
       if 1 <= n <= 4:
         return self._mul_chain(base, n)
       if -4 <= n <= -1:
-        return f"rn::fast_recip({self._mul_chain(base, -n)})"      # v_rcp_f64 + two Newton steps (templates/ekf_hip_rt.h): 5 dependent instructions, an IEEE division ~12
+        return f"rn::safe_recip({self._mul_chain(base, -n)})"      # v_rcp_f64 + two Newton steps, IEEE's answer kept for 0 / inf (templates/ekf_hip_rt.h): 6 dependent instructions, an IEEE division ~12
     if exp.is_Rational or exp.is_Float:
       two = sp.nsimplify(2 * exp)
       if two.is_Integer and abs(int(two)) <= 9 and int(two) % 2:

@@ -376,6 +376,25 @@ __device__ __forceinline__ double fast_rsqrt(const double a) {
   return y;
 }
 
+// fast_recip / fast_rsqrt for the MODEL'S OWN expressions (rednose_amd/codegen/lower.py prints reciprocals and negative half-integer
+// powers through these): a user's h(x) may legitimately divide by something that is 0 or overflows to infinity in a degenerate
+// configuration (the MSCKF test model does: a landmark scaled out to 1e200), where IEEE gives inf / 0 and the Newton steps turn the
+// hardware seed's exact inf / 0 into NaN (inf * 0).  The seed IS the IEEE answer there, so it is returned whenever the refined value
+// is not finite: one compare + select at the end of the chain.  The factorisations keep the unguarded forms (their pivots are variances).
+__device__ __forceinline__ double safe_recip(const double d) {
+  const double r0 = __builtin_amdgcn_rcp(d);
+  double r = fma(fma(-d, r0, 1.0), r0, r0);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return (r - r == 0.0) ? r : r0;
+}
+__device__ __forceinline__ double safe_rsqrt(const double a) {
+  const double y0 = __builtin_amdgcn_rsq(a);
+  const double h = 0.5 * a;
+  double y = fma(y0, fma(-h * y0, y0, 0.5), y0);
+  y = fma(y, fma(-h * y, y, 0.5), y);
+  return (y - y == 0.0) ? y : y0;
+}
+
 // a^(-N/2) for odd N (sympy's pow(r2, -1.5), pow(r2, -2.5) of gravity-like terms): powers of the reciprocal square root instead of an
 // IEEE sqrt followed by an IEEE division -- two chains of ~20 and ~12 DEPENDENT fp64 instructions on the one lane per filter that
 // evaluates the model's scalars (40 cycles each for a lone wavefront), against 7 + (N + 1) / 2 here.  Within an ulp or two of the
@@ -383,7 +402,7 @@ __device__ __forceinline__ double fast_rsqrt(const double a) {
 template <int N>
 __device__ __forceinline__ double rsqrt_pow(const double a) {
   static_assert(N >= 1 && N <= 9 && (N & 1), "odd powers of 1 / sqrt(a)");
-  const double r = fast_rsqrt(a);
+  const double r = safe_rsqrt(a);
   const double r2 = r * r;
   double p = r;
 #pragma unroll

@@ -67,6 +67,7 @@ extern "C" int host_step_{k.kind}(double* gx, double* gP, const double* Q, doubl
   src = "\n".join(["#include <cmath>", "#include <cstdint>", "#define __device__", "#define __forceinline__ inline",
                    "namespace rn {", "inline double fast_recip(const double d) { return 1.0 / d; }      // device: v_rcp_f64 + two Newton steps",
                    "inline double fast_rsqrt(const double a) { return 1.0 / std::sqrt(a); }      // device: v_rsq_f64 + two Newton steps",
+                   "inline double safe_recip(const double d) { return 1.0 / d; }", "inline double safe_rsqrt(const double a) { return 1.0 / std::sqrt(a); }",
                    helpers, "}  // namespace rn"] + body + entry)
   cpp, lib = tmp_path / f"{spec.name}{sfx}_host.cpp", tmp_path / f"lib{spec.name}{sfx}_host.so"
   cpp.write_text(src, encoding="utf-8")
@@ -209,7 +210,7 @@ extern "C" int host_wide_step_{k.kind}(double* x, double* P, const double* Q, do
   src = "\n".join(["#include <cmath>", "#include <cstdint>", "#include <pthread.h>", "#define __device__", "#define __forceinline__ inline",
                    "#define __noinline__", "#define __builtin_amdgcn_sched_barrier(x)", "static pthread_barrier_t g_bar;", "static bool g_sync_on = false;", "namespace rn {",
                    "inline void wave_lds_sync() { if (g_sync_on) pthread_barrier_wait(&g_bar); }      // device: a compiler fence inside one wavefront",
-                   "inline double fast_recip(const double d) { return 1.0 / d; }", "inline double fast_rsqrt(const double a) { return 1.0 / std::sqrt(a); }", helpers, "}  // namespace rn"] + fns + entry)
+                   "inline double fast_recip(const double d) { return 1.0 / d; }", "inline double fast_rsqrt(const double a) { return 1.0 / std::sqrt(a); }", "inline double safe_recip(const double d) { return 1.0 / d; }", "inline double safe_rsqrt(const double a) { return 1.0 / std::sqrt(a); }", helpers, "}  // namespace rn"] + fns + entry)
   cpp, lib = tmp_path / f"{spec.name}_wide_host.cpp", tmp_path / f"lib{spec.name}_wide_host.so"
   cpp.write_text(src, encoding="utf-8")
   res = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", str(cpp), "-o", str(lib)], capture_output=True, text=True)
@@ -322,7 +323,7 @@ def _run_host_library(tmp_path, spec):
                    "#define __noinline__", "static pthread_barrier_t g_bar;",
                    "static thread_local bool t_scalar = false;      // inside a scalar-phase function (one lane): its fences are not barriers",
                    "namespace rn {", "inline void wave_lds_sync() { if (!t_scalar) pthread_barrier_wait(&g_bar); }", "inline void pin(double&) {}",
-                   "inline double fast_recip(const double d) { return 1.0 / d; }", "inline double fast_rsqrt(const double a) { return 1.0 / std::sqrt(a); }", helpers, "}  // namespace rn"] + fns + [f"""
+                   "inline double fast_recip(const double d) { return 1.0 / d; }", "inline double fast_rsqrt(const double a) { return 1.0 / std::sqrt(a); }", "inline double safe_recip(const double d) { return 1.0 / d; }", "inline double safe_rsqrt(const double a) { return 1.0 / std::sqrt(a); }", helpers, "}  // namespace rn"] + fns + [f"""
 struct Job {{ double* x; double* sP; const double* Q; const double* R; const int* kinds; const double* dts; double* z; int T; double* sl; double* sG;
              unsigned char* flags; int c; int norm_quats; int qdiag; int skip_dt0; }};
 static void* lane(void* p) {{
@@ -498,6 +499,8 @@ inline void async_wait() {}
 inline void pin(double&) {}
 inline double fast_recip(const double d) { return 1.0 / d; }
 inline double fast_rsqrt(const double a) { return 1.0 / std::sqrt(a); }
+inline double safe_recip(const double d) { return 1.0 / d; }
+inline double safe_rsqrt(const double a) { return 1.0 / std::sqrt(a); }
 """
 
 
@@ -914,8 +917,12 @@ def test_lane_group_fused_run_kernel_on_the_host(tmp_path, name):
   sched2 = sched.copy(); sched2[1] = 77
   xh2, Ph2, zh2 = x0.copy(), P0.copy(), zs.copy()
   fl2 = np.zeros((T, n), dtype=np.uint8)
-  lib.host_wide_run(grid, ptr(xh2), ptr(Ph2), ptr(Q), ptr(sched2, ip), ptr(dts), T, ptr(zh2), ptr(Rt), n, int(quat_idx >= 0), ptr(fl2, bp), None, None)
+  tx2, tP2 = np.zeros((T, n, D)), np.zeros((T, n, E, E))
+  lib.host_wide_run(grid, ptr(xh2), ptr(Ph2), ptr(Q), ptr(sched2, ip), ptr(dts), T, ptr(zh2), ptr(Rt), n, int(quat_idx >= 0), ptr(fl2, bp), ptr(tx2), ptr(tP2))
   assert (fl2[1] == 8).all() and np.array_equal(zh2[1], zs[1]) and np.isfinite(xh2).all()
+  # the trace of the step before the unknown kind is complete, and the unknown kind's own row is the state it passed through
+  assert np.array_equal(tP2[0], tP[0]) and np.array_equal(tx2[0], tx[0]) and np.isfinite(tP2).all()
+  assert np.array_equal(tP2[1], tP2[0]) == (dts[1] == 0.0)
 
 
 # Not emulated here: the smoother kernel (emit_rts3).  A wavefront executes in lockstep, so a lane may overwrite LDS that another
