@@ -333,18 +333,18 @@ def run_model(torch, dist, model, n, K, W, dev, rank, world, only_kind=None):
         break
       prev = cur
     steady["seconds"] = time.perf_counter() - t_warm
-    f.x.copy_(x_keep)                                 # the timed schedule continues where the warm-up steps left the filter
-    f.P.copy_(P_keep)
+    # (no restore here: the last group started from the saved state and advanced it by STEADY_GROUP more observations -- the timed
+    # schedule continues from there; two copy kernels between the warm-up and the timed region would undo part of what it is for)
     t_prev[0] = sched[W - 1][1] if W else None
+  G = int(os.environ.get("RN_BENCH_MARK_EVERY", 0)) or max(MEDIAN_GROUP, -(-K // 50))
+  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  spare = [torch.cuda.Event(enable_timing=True) for _ in range(K // G + 1)]      # created outside the timed region
   if dist is not None and dist.is_initialized():
     dist.barrier()
   torch.cuda.synchronize()
   # The timed region: exactly K steps between ev0 and ev1 (mean launch duration = their interval / K).  A marker every G launches
   # inside it (at most 50 of them: a marker is one queue packet, no kernel) gives the distribution: launch_us_median is the median
   # of the per-group means -- the same launches, the same observation buffers, nothing replayed.
-  G = max(MEDIAN_GROUP, -(-K // 50))
-  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  spare = [torch.cuda.Event(enable_timing=True) for _ in range(K // G + 1)]      # created outside the timed region
   marks = [(W, ev0)]
   t0 = time.perf_counter()
   ev0.record()
@@ -368,7 +368,8 @@ def run_model(torch, dist, model, n, K, W, dev, rank, world, only_kind=None):
   bytes_per_step = 8.0 * (2 * (D + E * E) + 2 * float(np.mean(zdims)))
   return dict(M=M, D=D, E=E, Z=float(np.mean(zdims)), wall=wall, dev_ms=dev_ms, bytes_per_step=bytes_per_step, gen=gen,
               kinds=sorted(set(s[0] for s in sched[W:W + K])), steady=steady,
-              launch_us_median=float(np.median(groups)) if groups else None, launch_us_groups=len(groups))
+              launch_us_median=float(np.median(groups)) if groups else None, launch_us_groups=len(groups),
+              group_us=[round(g_, 3) for g_ in groups] if os.environ.get("RN_BENCH_MARK_EVERY") else None)
 
 
 def fused_run_extra(torch, model, n, T, dev):
@@ -708,6 +709,8 @@ def main():
                                launch_us_median=r["launch_us_median"], launch_us_median_groups=r["launch_us_groups"]),
       "steady_state_warmup": r["steady"],
     }
+    if r.get("group_us"):
+      out["roofline"]["group_us"] = r["group_us"]
     if force_dist:
       out["forced_process_group"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
     if not args.no_cpu_baseline and world == 1:
