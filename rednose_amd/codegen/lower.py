@@ -6,6 +6,8 @@ becomes `pow(x, 2)`; live.cpp contains 1 638 pow(), 252 sin(), 234 cos() calls -
 On a GPU that turns a memory-bound filter step into a transcendental-bound one, so here
 
   * all outputs of a fused block (e.g. f and F, or h and H.H_mod) go through ONE `sympy.cse` pass;
+  * sin(a) and cos(a) of one argument come from ONE straight-line rn::sincos_fast(a, s, c) per distinct argument (hipcc does not merge the
+    two ocml calls, ~170 instructions each behind a branch; live's IMU kinds made six of them per step);
   * small integer powers are printed as multiplications, reciprocals as `rn::safe_recip`, negative half-integer powers as odd
     powers of the reciprocal square root (`pow(r2, -1.5)` -> `rn::rsqrt_pow<3>(r2)`), positive ones through sqrt, everything else
     uses the C99 names which hipcc maps to the ocml double-precision device functions;
@@ -21,9 +23,16 @@ from sympy.printing.c import C99CodePrinter
 class HipPrinter(C99CodePrinter):
   """C99 printer with power strength-reduction suitable for fp64 device code."""
 
-  def __init__(self, symbol_names=None):
+  def __init__(self, symbol_names=None, trig=None):
     super().__init__(dict(precision=17, contract=False))
     self._names = symbol_names or {}
+    self._trig = trig or {}      # argument -> name of the (name_s, name_c) pair Block.lower() computes once through rn::sincos_fast
+
+  def _print_sin(self, expr):
+    return self._trig[expr.args[0]] + "_s"
+
+  def _print_cos(self, expr):
+    return self._trig[expr.args[0]] + "_c"
 
   def _print_Symbol(self, expr):
     return self._names.get(expr, super()._print_Symbol(expr))
@@ -110,9 +119,24 @@ class Block:
     stmts = []
     if exprs:
       repl, reduced = sp.cse(exprs, symbols=sp.numbered_symbols(self.tmp_prefix), optimizations='basic', order='none')
-      pr = HipPrinter(self.names)
-      for sym, sub in repl:
+      # sin / cos: ONE rn::sincos_fast per distinct argument (templates/ekf_hip_rt.h says why), placed where its argument becomes
+      # available (the calls that land at the same place are emitted next to each other: straight-line code, their chains interleave)
+      trig, where = {}, {}
+      defined = {sym: i for i, (sym, _) in enumerate(repl)}
+      for e in [sub for _, sub in repl] + list(reduced):
+        for node in sp.preorder_traversal(e):          # (encounter order: the names must not depend on a set's iteration order)
+          if isinstance(node, (sp.sin, sp.cos)) and node.args[0] not in trig:
+            arg = node.args[0]
+            trig[arg] = f"{self.tmp_prefix}sc{len(trig)}"
+            where[arg] = max([defined[q] + 1 for q in arg.free_symbols if q in defined] + [0])
+      pr = HipPrinter(self.names, trig)
+
+      def trig_group(i):
+        return [f"double {trig[a]}_s, {trig[a]}_c; rn::sincos_fast({pr.doprint(a)}, {trig[a]}_s, {trig[a]}_c);" for a in trig if where[a] == i]
+      for i, (sym, sub) in enumerate(repl):
+        stmts += trig_group(i)
         stmts.append(f"const double {sym} = {pr.doprint(sub)};")
+      stmts += trig_group(len(repl))
       for (lv, _), red in zip(live, reduced):
         stmts.append(f"{decl}{lv} = {pr.doprint(red)};")
     self.statements = stmts

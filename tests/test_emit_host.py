@@ -22,9 +22,12 @@ pytestmark = pytest.mark.timeout(180, method="thread")      # the lane emulation
 
 
 def _function_text(text, name):
-  """Text of the (template) function `name` of the runtime header, from its `template <...>` line to its closing brace."""
+  """Text of the function `name` of the runtime header, from its `template <...>` line (when it has one) to its closing brace."""
   at = text.index(f" {name}(")
-  start = text.rfind("template <", 0, at)
+  start = text.rfind("\n", 0, at) + 1
+  prev = text.rfind("\n", 0, start - 1) + 1
+  if text[prev:start].startswith("template <"):
+    start = prev
   depth, i = 0, text.index("{", at)
   while True:
     depth += {"{": 1, "}": -1}.get(text[i], 0)
@@ -38,7 +41,7 @@ def _host_library(tmp_path, spec, sym=False):
   registers (emit_small.predict_regs)."""
   from rednose_amd.codegen import emit_small
   hdr = open(HDR, encoding="utf-8").read()
-  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "normalize_quat"))
+  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "sincos_fast", "normalize_quat"))
   D, E = spec.dim_x, spec.dim_err
   body = [emit_small.predict_regs(spec, sym)[0]] + [emit_small.update_regs(spec, k, sym)[0] for k in spec.kinds]
   sfx = "_sym" if sym else ""
@@ -156,7 +159,7 @@ def test_generated_lane_per_filter_arithmetic_on_the_host(tmp_path, name, sym):
 def _wide_host_library(tmp_path, spec):
   from rednose_amd.codegen import emit_wide2, tuning
   hdr = open(HDR, encoding="utf-8").read()
-  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "normalize_quat"))
+  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "sincos_fast", "normalize_quat"))
   with tuning.using_model(spec):
     text, lay = emit_wide2.device_functions(spec)
     GL = emit_wide2.group_lanes(spec)
@@ -303,7 +306,7 @@ def test_generated_lane_group_step_on_the_host(tmp_path, name):
 def _run_host_library(tmp_path, spec):
   from rednose_amd.codegen import emit_wide2 as w2, emit_wide3 as w3, tuning
   hdr = open(HDR, encoding="utf-8").read()
-  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "normalize_quat"))
+  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "sincos_fast", "normalize_quat"))
   D, E = spec.dim_x, spec.dim_err
   kinds = [k for k in spec.kinds if k.He_sym is None and k.ea_sym is None]
   with tuning.using_model(spec):
@@ -507,7 +510,7 @@ inline double safe_rsqrt(const double a) { return 1.0 / std::sqrt(a); }
 def _kernel_host_library(tmp_path, spec):
   from rednose_amd.codegen import emit_small
   hdr = open(HDR, encoding="utf-8").read()
-  names = ("lds_stride", "tile_g2l", "tile_l2g", "lds_to_regs", "regs_to_lds", "spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "normalize_quat")
+  names = ("lds_stride", "tile_g2l", "tile_l2g", "lds_to_regs", "regs_to_lds", "spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "sincos_fast", "normalize_quat")
   helpers = "\n".join(_function_text(hdr, f) for f in names)
   at = hdr.index("struct TilePrefetch")
   prefetch = hdr[hdr.rfind("template <", 0, at):hdr.index("};", at) + 2]
@@ -703,7 +706,7 @@ inline void sched_barrier_(int) {}
 def _wide_kernel_host_library(tmp_path, spec):
   from rednose_amd.codegen import emit_wide2, tuning
   hdr = open(HDR, encoding="utf-8").read()
-  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "normalize_quat"))
+  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "sincos_fast", "normalize_quat"))
   with tuning.using_model(spec):
     text = emit_wide2.kernels(spec)
     FT = emit_wide2.tile_filters(spec)
@@ -819,7 +822,7 @@ inline int host_readfirstlane(int v) {  // every lane is active wherever the ker
 def _wide_run_kernel_host_library(tmp_path, spec):
   from rednose_amd.codegen import emit_wide3, tuning
   hdr = open(HDR, encoding="utf-8").read()
-  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "normalize_quat"))
+  helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "sincos_fast", "normalize_quat"))
   with tuning.using_model(spec):
     text = emit_wide3.kernels(spec)
     _, _, FPW = emit_wide3.layout(spec)

@@ -241,3 +241,51 @@ def test_cffi_branch_of_load_code_runs_the_known_answers(monkeypatch):
       assert round(abs(got - want), 7) == 0
   finally:
     sys.modules.pop("cffi", None)
+
+
+def test_lowered_sin_cos_pairs_and_their_accuracy(tmp_path):
+  """rednose_amd/codegen/lower.py prints sin(a) / cos(a) through ONE rn::sincos_fast per distinct argument; the function itself (pure
+  IEEE arithmetic: the host build computes what the device computes) against libm's long double routines over 2e6 arguments up to
+  2^45, the quadrant boundaries, and NaN beyond 2^45 and for NaN / inf."""
+  import ctypes
+  import subprocess
+  import sympy as sp
+  from rednose_amd.codegen.lower import Block
+  from test_emit_host import HDR, _function_text
+  a, b = sp.symbols("a b")
+  blk = Block()
+  blk.add("o0", sp.sin(a) * sp.cos(a) + sp.sin(2 * a * b))
+  blk.add("o1", sp.cos(a) * b + sp.cos(2 * a * b) * sp.sin(b))
+  stmts, _ = blk.lower()
+  text = "\n".join(stmts)
+  assert text.count("rn::sincos_fast(") == 3      # arguments a, 2 a b, b: one pair each
+  assert " sin(" not in text and " cos(" not in text and "(sin(" not in text and "(cos(" not in text
+  # the compound argument 2 a b became a temporary: its pair is computed after that temporary, the two plain arguments' pairs first, together
+  tmp = [i for i, ln in enumerate(stmts) if ln.startswith("const double t1 = 2.0*a*b")][0]
+  assert [i for i, ln in enumerate(stmts) if "rn::sincos_fast(t1," in ln][0] == tmp + 1
+  assert "rn::sincos_fast(a," in stmts[0] and "rn::sincos_fast(b," in stmts[1]
+  hdr = open(HDR, encoding="utf-8").read()
+  src = "\n".join(["#include <cmath>", "#define __device__", "#define __forceinline__ inline", "namespace rn {",
+                   _function_text(hdr, "sincos_fast"), "}",
+                   'extern "C" void sc(const double* a, double* s, double* c, double* rs, double* rc, long n) {',
+                   "  for (long i = 0; i < n; i++) { rn::sincos_fast(a[i], s[i], c[i]); rs[i] = (double)sinl((long double)a[i]); rc[i] = (double)cosl((long double)a[i]); } }"])
+  cpp, lib = tmp_path / "sc.cpp", tmp_path / "libsc.so"
+  cpp.write_text(src, encoding="utf-8")
+  res = subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", str(cpp), "-o", str(lib)], capture_output=True, text=True)
+  assert res.returncode == 0, res.stderr[-2000:]
+  fn = ctypes.CDLL(str(lib)).sc
+  rng = np.random.default_rng(5)
+  k = np.arange(-40000, 40001) * (np.pi / 2)
+  big = np.ldexp(rng.uniform(1.0, 2.0, 400000), rng.integers(16, 45, 400000)) * rng.choice([-1.0, 1.0], 400000)
+  args = np.concatenate([rng.uniform(-4, 4, 500000), rng.uniform(-100, 100, 500000), rng.uniform(-65536, 65536, 500000), rng.uniform(-1e-3, 1e-3, 250000),
+                         big, k, np.nextafter(k, 1e9), np.nextafter(k, -1e9), k + np.pi / 4,
+                         [0.0, -0.0, 65536.0, -65536.0, 1e6, -3e9, 2.0**31, 2.0**31 + 1, -2.0**40, 2.0**45, -2.0**45]])
+  out = [np.empty_like(args) for _ in range(4)]
+  dp = ctypes.POINTER(ctypes.c_double)
+  fn(args.ctypes.data_as(dp), *[o.ctypes.data_as(dp) for o in out], ctypes.c_long(args.size))
+  s, c, rs, rc = out
+  assert float(np.abs(s - rs).max()) < 2.5e-16 and float(np.abs(c - rc).max()) < 2.5e-16
+  bad = np.array([np.nan, np.inf, -np.inf, 2.0**45 + 1, -1e300])
+  ob = [np.zeros(5) for _ in range(4)]
+  fn(bad.ctypes.data_as(dp), *[o.ctypes.data_as(dp) for o in ob], ctypes.c_long(5))
+  assert np.isnan(ob[0]).all() and np.isnan(ob[1]).all()
