@@ -281,24 +281,22 @@ def run_model(torch, dist, model, n, K, W, dev, rank, world, only_kind=None):
     t_prev[0] = t
     bound[kind](z, dt)
 
-  for i in range(W):
-    step(i)
-  torch.cuda.synchronize()
   # Steady state before the timed region, whatever --warmup says: a short run (--steps 20 --warmup 5 is 0.25 ms of GPU work) is
   # otherwise timed on a device that is still raising its clocks (round 3: 10.7 us per launch in such a run against 9.05 us in a
   # long one, same kernel).  Extra launches of the same entry point on this filter, in groups of STEADY_GROUP with HIP events
-  # around each group, for at least STEADY_MIN_S seconds and until two consecutive groups agree within 2 % -- at most STEADY_CAP_S.  The observations are the
-  # warm-up rows again (scratch copies: z is overwritten by y); the filter simply sees more measurements.  Not part of `steps`.
+  # around each group, for at least STEADY_MIN_S seconds and until two consecutive groups agree within 2 % -- at most STEADY_CAP_S.
+  # They come FIRST and start from the initial state every time; then the initial state is put back and the --warmup steps of the
+  # schedule run, so what precedes the timed region is W step launches and the filter is exactly where the schedule expects it
+  # (the nonlinear live filter does not survive being moved half a second ahead of its observations).  Not part of `steps`.
   steady = dict(launches=0, seconds=0.0, group=STEADY_GROUP, converged=False, last_group_us=None)
-  # observations of the untimed launches (steady-state warm-up here, launch-duration distribution after the timed region): pristine
-  # copies of the warm-up rows, restored into scratch buffers BEFORE each group's first event -- a launch overwrites z with the
-  # residual y, and a filter fed its own residuals as observations drifts away
+  # observations of the untimed launches: pristine copies of the first rows of the schedule, restored into scratch buffers BEFORE each
+  # group's first event -- a launch overwrites z with the residual y, and a filter fed its own residuals as observations drifts away
   pool0 = [(k, z.clone()) for (k, _, z) in (sched[:W] if W else sched[:1])]
   scratch = {}       # observation shape -> scratch buffers
 
   def untimed_group(first, count):
-    # every group starts from the filter state saved before the first one: thousands of extra launches on repeated observations
-    # (each with dt = 0.01) are not a trajectory any filter was tuned for -- live drifts to non-finite states after a few thousand
+    # every group starts from the initial state: thousands of extra launches on repeated observations (each with dt = 0.01) are
+    # not a trajectory any filter was tuned for -- live drifts to non-finite states after a few thousand
     f.x.copy_(x_keep)
     f.P.copy_(P_keep)
     used, plan = {}, []
@@ -333,9 +331,10 @@ def run_model(torch, dist, model, n, K, W, dev, rank, world, only_kind=None):
         break
       prev = cur
     steady["seconds"] = time.perf_counter() - t_warm
-    # (no restore here: the last group started from the saved state and advanced it by STEADY_GROUP more observations -- the timed
-    # schedule continues from there; two copy kernels between the warm-up and the timed region would undo part of what it is for)
-    t_prev[0] = sched[W - 1][1] if W else None
+    f.x.copy_(x_keep)
+    f.P.copy_(P_keep)
+  for i in range(W):
+    step(i)
   G = int(os.environ.get("RN_BENCH_MARK_EVERY", 0)) or max(MEDIAN_GROUP, -(-K // 50))
   ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   spare = [torch.cuda.Event(enable_timing=True) for _ in range(K // G + 1)]      # created outside the timed region
