@@ -56,9 +56,13 @@ def hbm_roofline(bytes_per_launch, launch_s, kernel, traffic=None, **more):
               algorithmic_bytes_per_launch=bytes_per_launch, launch_us=launch_s * 1e6, **more)
 
 
+TRAFFIC_CARRIED = {}      # section label -> note, for counters taken on an earlier build of the library that is being timed
+
+
 def measured_traffic(label, lib_name, gen):
   """HBM bytes per launch of the section `label` of profiles/pmc_workload.py from the committed PMC passes -- only if they were
-  taken on the library that is being timed (digest of generated/{lib_name}.digest)."""
+  taken on the library that is being timed (digest of generated/{lib_name}.digest), or on an earlier build that the record lists
+  under `carried_to` together with what changed since (`carried_note`): the JSON line then says so under `traffic_carried`."""
   tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
   if not os.path.exists(tf):
     return None
@@ -68,8 +72,11 @@ def measured_traffic(label, lib_name, gen):
   if rec is None or not os.path.exists(dg):
     return None
   with open(dg, encoding="utf-8") as fh:
-    if rec.get("lib_digest") != fh.read().strip():
+    now = fh.read().strip()
+  if rec.get("lib_digest") != now:
+    if now not in rec.get("carried_to", []):
       return None
+    TRAFFIC_CARRIED[label] = f"counters taken on build {rec['lib_digest'][:12]} of lib{lib_name}.so; since then: {rec.get('carried_note', '?')}"
   return rec["hbm_bytes_per_launch"]
 
 
@@ -729,6 +736,8 @@ def main():
                                                 "sample": f"{nl} filters, fused predict + PHONE_ACCEL update, gcc -O2"}
     if extra:
       out["extra"] = extra
+    if TRAFFIC_CARRIED:
+      out["traffic_carried"] = dict(TRAFFIC_CARRIED)
     print(json.dumps(out))
   if use_dist:
     dist.destroy_process_group()

@@ -452,4 +452,8 @@ void {name}_predict(double *in_x, double *in_P, double *in_Q, double dt) {{
   abi.append(plugin_text(spec))
 
   hdr += ["#ifdef __cplusplus", "}", "#endif", ""]
-  return "\n".join(hdr), "\n".join(src) + "\n" + "\n".join(abi) + "\n"
+  text = "\n".join(src) + "\n" + "\n".join(abi) + "\n"
+  if "rn::sincos_fast(" in text:      # the model has trigonometric terms: codegen/lower.py printed them through this helper
+    from rednose_amd.codegen.lower import SINCOS_FAST
+    text = text.replace('#include "ekf_hip_rts.h"\n', '#include "ekf_hip_rts.h"\n' + SINCOS_FAST, 1)
+  return "\n".join(hdr), text

@@ -20,6 +20,49 @@ import sympy as sp
 from sympy.printing.c import C99CodePrinter
 
 
+# Emitted once into every generated file that evaluates a sin or cos (emit.emit; libraries without trigonometric terms are not touched).
+SINCOS_FAST = r"""namespace rn {
+// sin and cos of one argument for the MODEL'S OWN expressions (rednose_amd/codegen/lower.py prints every sin(a) / cos(a) of a fused block
+// through ONE call per distinct argument).  The ocml sin and cos are ~170 instructions each, mostly one dependent chain behind a branch
+// (the large-argument reduction), and hipcc does not merge sin(a) with cos(a): live's gyro / accelerometer kinds called them six times
+// for the three mounting angles -- ~500 of the ~630 instructions of the gyro kind's scalar phase, executed by the ONE lane per filter
+// that evaluates the scalars.  Here: k = rint(a 2/pi); r = a - k pi/2 with pi/2 in three doubles and three FMAs -- the first difference
+// is exact for every |a| >= 1 (both terms are multiples of 2^-52, the result is below 1), the second rounds at 5.5e-17 ABSOLUTE, the
+// constants leave 6e-50 k --; minimax polynomials of degree 13 / 12 on [-pi/4, pi/4] (the classic fdlibm kernels, Horner, two
+// independent chains); quadrant by select.  Straight-line and branch-free: the calls of a block are emitted next to each other, so the
+// chains of different arguments interleave.  |error| < 2.5e-16 absolute for |a| <= 2^45 = 3.5e13 (tests/test_host_logic.py: 2e6 arguments
+// against libm's long double routines; measured flat at 1.7e-16 up to 2^47, then the estimate of k is off by a visible fraction); beyond
+// 2^45, where neighbouring doubles are 0.008 rad apart, and for NaN / inf the pair is NaN (libm returns the sine of the exact double there:
+// a limit of this engine, README.md).  An inlined library fallback for that
+// range was built and costs 25-35 registers in every kernel that evaluates a model with trigonometric terms (profiles/tuning_notes.md).
+__device__ __forceinline__ void sincos_fast(const double a_in, double& s, double& c) {
+  const double a = (fabs(a_in) <= 35184372088832.0) ? a_in : __builtin_nan("");
+  const double k = rint(a * 6.36619772367581382433e-01);
+  double r = fma(-k, 1.5707963267948966e+00, a);
+  r = fma(-k, 6.123233995736766e-17, r);
+  r = fma(-k, -1.4973849048591698e-33, r);
+  const double z = r * r;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double sr = fma(r * z, ps, r);
+  const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
+  const int q = (int)fma(-4.0, floor(0.25 * k), k);      // k mod 4 (k is an integer below 2^45: exact)
+  const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
+}
+}  // namespace rn
+"""
+
+
 class HipPrinter(C99CodePrinter):
   """C99 printer with power strength-reduction suitable for fp64 device code."""
 
@@ -119,7 +162,7 @@ class Block:
     stmts = []
     if exprs:
       repl, reduced = sp.cse(exprs, symbols=sp.numbered_symbols(self.tmp_prefix), optimizations='basic', order='none')
-      # sin / cos: ONE rn::sincos_fast per distinct argument (templates/ekf_hip_rt.h says why), placed where its argument becomes
+      # sin / cos: ONE rn::sincos_fast per distinct argument (SINCOS_FAST above says why), placed where its argument becomes
       # available (the calls that land at the same place are emitted next to each other: straight-line code, their chains interleave)
       trig, where = {}, {}
       defined = {sym: i for i, (sym, _) in enumerate(repl)}

@@ -251,7 +251,6 @@ def test_lowered_sin_cos_pairs_and_their_accuracy(tmp_path):
   import subprocess
   import sympy as sp
   from rednose_amd.codegen.lower import Block
-  from test_emit_host import HDR, _function_text
   a, b = sp.symbols("a b")
   blk = Block()
   blk.add("o0", sp.sin(a) * sp.cos(a) + sp.sin(2 * a * b))
@@ -264,9 +263,8 @@ def test_lowered_sin_cos_pairs_and_their_accuracy(tmp_path):
   tmp = [i for i, ln in enumerate(stmts) if ln.startswith("const double t1 = 2.0*a*b")][0]
   assert [i for i, ln in enumerate(stmts) if "rn::sincos_fast(t1," in ln][0] == tmp + 1
   assert "rn::sincos_fast(a," in stmts[0] and "rn::sincos_fast(b," in stmts[1]
-  hdr = open(HDR, encoding="utf-8").read()
-  src = "\n".join(["#include <cmath>", "#define __device__", "#define __forceinline__ inline", "namespace rn {",
-                   _function_text(hdr, "sincos_fast"), "}",
+  from rednose_amd.codegen.lower import SINCOS_FAST
+  src = "\n".join(["#include <cmath>", "#define __device__", "#define __forceinline__ inline", SINCOS_FAST,
                    'extern "C" void sc(const double* a, double* s, double* c, double* rs, double* rc, long n) {',
                    "  for (long i = 0; i < n; i++) { rn::sincos_fast(a[i], s[i], c[i]); rs[i] = (double)sinl((long double)a[i]); rc[i] = (double)cosl((long double)a[i]); } }"])
   cpp, lib = tmp_path / "sc.cpp", tmp_path / "libsc.so"
