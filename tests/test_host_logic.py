@@ -287,3 +287,31 @@ def test_lowered_sin_cos_pairs_and_their_accuracy(tmp_path):
   ob = [np.zeros(5) for _ in range(4)]
   fn(bad.ctypes.data_as(dp), *[o.ctypes.data_as(dp) for o in ob], ctypes.c_long(5))
   assert np.isnan(ob[0]).all() and np.isnan(ob[1]).all()
+
+
+def test_bench_prints_counter_traffic_only_for_the_build_it_was_taken_on(tmp_path):
+  """bench.measured_traffic: a record of profiles/pmc_traffic.json applies to the library whose digest it names, or to a later build the
+  record lists under `carried_to` (then the JSON line says so); any other build gets None -- never a number measured on different code."""
+  import json
+  import sys
+  sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+  import bench
+  recs = json.load(open(os.path.join(os.path.dirname(__file__), "..", "profiles", "pmc_traffic.json"), encoding="utf-8"))
+  label, rec = next((k, v) for k, v in recs.items() if isinstance(v, dict) and v.get("carried_to"))
+  lib = rec["lib"]
+  bench.TRAFFIC_CARRIED.clear()
+  (tmp_path / f"{lib}.digest").write_text(rec["lib_digest"], encoding="utf-8")
+  assert bench.measured_traffic(label, lib, str(tmp_path)) == rec["hbm_bytes_per_launch"] and not bench.TRAFFIC_CARRIED
+  (tmp_path / f"{lib}.digest").write_text(rec["carried_to"][0], encoding="utf-8")
+  assert bench.measured_traffic(label, lib, str(tmp_path)) == rec["hbm_bytes_per_launch"]
+  assert label in bench.TRAFFIC_CARRIED and rec["lib_digest"][:12] in bench.TRAFFIC_CARRIED[label]
+  bench.TRAFFIC_CARRIED.clear()
+  (tmp_path / f"{lib}.digest").write_text("0" * 64, encoding="utf-8")
+  assert bench.measured_traffic(label, lib, str(tmp_path)) is None and not bench.TRAFFIC_CARRIED
+  assert bench.measured_traffic("no_such_section", lib, str(tmp_path)) is None
+  # the shipped libraries: every record applies to the build in generated/ (directly or carried)
+  gen = os.path.join(os.path.dirname(__file__), "..", "generated")
+  if os.path.exists(os.path.join(gen, "kinematic6.digest")):
+    for k, v in recs.items():
+      if isinstance(v, dict) and "lib" in v:
+        assert bench.measured_traffic(k, v["lib"], gen) is not None, k
