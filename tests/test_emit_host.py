@@ -394,7 +394,7 @@ extern "C" void host_run(double* x, double* P, const double* Q, const double* R,
   return ctypes.CDLL(str(lib)), kinds, zmax
 
 
-@pytest.mark.parametrize("name,qdiag", [("kinematic9", 1), ("rand11", 0), ("live", 1), ("live", 0)])
+@pytest.mark.parametrize("name,qdiag", [("kinematic9", 1), ("rand11", 0), ("rand24", 1), ("live", 1), ("live", 0)])
 def test_generated_lane_group_fused_run_on_the_host(tmp_path, name, qdiag):
   from oracle_lib import OracleLib
   from rednose_amd.codegen.spec import build_spec
@@ -847,7 +847,7 @@ extern "C" __attribute__((visibility("default"))) void host_wide_run(int grid, d
   return ctypes.CDLL(str(lib)), FPW
 
 
-@pytest.mark.parametrize("name", ["kinematic9", "live_maha"])
+@pytest.mark.parametrize("name", ["kinematic9", "rand24", "live_maha"])
 def test_lane_group_fused_run_kernel_on_the_host(tmp_path, name):
   """k_run of the lane-group family, filtered trace and flags included, against the oracle's batch_run: a ragged last tile, fewer
   workgroups than tiles, a schedule mixing every non-feature kind with dt = 0 steps, gated observations, an unknown kind (flag 8,
