@@ -39,6 +39,12 @@
  *     the correction Ck (Pk1_n - Pk1_k) Ck^T; the filtered covariance itself enters the sum as given:
  *     Ps[k] = Pf[k] + correction.  On a trace written by batch_run (symmetric to rounding) that is the reference's
  *     rts_smooth to rounding.
+ *
+ * Elementary functions of the model's expressions.  sqrt, reciprocals and negative half-integer powers are evaluated from the
+ * hardware seeds with Newton steps (within an ulp or two of libm; IEEE answers kept at 0 and infinity).  sin / cos of one
+ * argument come from one in-line routine accurate to 2e-16 ABSOLUTE for |a| <= 2^45 rad; beyond that (neighbouring doubles are
+ * 0.008 rad apart there), and for NaN / inf, both are NaN -- the reference's libm returns the sine of the exact double instead.
+ * A filter whose state drives a trigonometric argument that far comes back non-finite and is flagged (flag bit 1), not silently wrong.
  */
 #ifndef REDNOSE_AMD_FILTER_H
 #define REDNOSE_AMD_FILTER_H
