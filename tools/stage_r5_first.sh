@@ -10,5 +10,6 @@ O=gpurun_out/r5a; mkdir -p $O
 cp profiles/pmc_traffic.json $O/pmc_traffic.json 2>/dev/null
 ( time timeout 300 python bench.py ) > $O/bench_default.json 2> $O/bench_default.err
 ( time timeout 100 python bench.py --steps 20 --warmup 5 --no-extras ) > $O/bench_short.json 2> $O/bench_short.err
+[ -x tools/issue_probe ] || hipcc --offload-arch=gfx950 -O3 -Wno-unused-result tools/issue_probe.hip -o tools/issue_probe > /dev/null 2>&1
 timeout 60 tools/issue_probe > $O/issue_probe.txt 2>&1
 tail -5 $O/tests.log; tail -3 $O/collect.log; cut -c1-400 $O/bench_short.json
