@@ -459,7 +459,12 @@ __global__ {bounds} void k_rts3(const double* __restrict__ xf, const double* __r
     fp64 FMA issues ~40 cycles after its predecessor when the wavefront is alone on its SIMD, two sums per slot left the chains
     24 cycles apart)."""
     pieces = [(j, h) for j in range(E) for h in (0, 1)]
-    NP = 4
+    NP = tuning.current().rts3_np
+
+    def tree(ts):        # pairwise sum of the partial sums: (s0 + s1) + (s2 + s3) for four
+      while len(ts) > 1:
+        ts = [f"({ts[i]} + {ts[i + 1]})" if i + 1 < len(ts) else ts[i] for i in range(0, len(ts), 2)]
+      return ts[0][1:-1] if ts[0].startswith("(") else ts[0]
 
     def acc(s_, j, kk):
       return f"{out}{s_}[{j}]" if kk % NP == 0 else f"{tmp}{kk % NP}_{s_}_{j}"
@@ -480,7 +485,7 @@ __global__ {bounds} void k_rts3(const double* __restrict__ xf, const double* __r
            f"{acc(s, j, kk)} = fma({coef}{s}[{kk}], {opname}{j}_{kk}, {acc(s, j, kk)});") for s in Sj))
       pins = [f"{out}{s}[{j}]" for s in Sj]
       if h == 1:
-        body.append("      " + " ".join(f"{out}{s}[{j}] = ({out}{s}[{j}] + {tmp}1_{s}_{j}) + ({tmp}2_{s}_{j} + {tmp}3_{s}_{j});" for s in Sj))
+        body.append("      " + " ".join(f"{out}{s}[{j}] = {tree([f'{out}{s}[{j}]'] + [f'{tmp}{q}_{s}_{j}' for q in range(1, NP)])};" for s in Sj))
       else:
         pins += [f"{tmp}{q}_{s}_{j}" for s in Sj for q in range(1, NP)]
       _region(b, head, body, pins)

@@ -73,7 +73,7 @@ def _tl_arg(call=False):
   return ", (int)(t % 3)" if call else ", const int tl_t"
 
 
-def _rank_pass(E, Z, R, src, op, coef, JB=4):
+def _rank_pass(E, Z, R, src, op, coef, JB=None):
   """Straight-line rank-Z pass over the register rows: row_s[j] op= sum_z coef_s[z] * src[z][j] for all j, in blocks of JB
   columns.  Two things hipcc does not do by itself here:
     * the broadcast operands of block b + 1 are loaded before the FMAs of block b and a compiler fence closes every block, so
@@ -82,6 +82,8 @@ def _rank_pass(E, Z, R, src, op, coef, JB=4):
     * inside a block the FMAs are emitted term by term ACROSS the block's JB * R entries, so consecutive instructions belong to
       different accumulation chains: a dependent fp64 FMA issues ~40 cycles after its predecessor with one wavefront per SIMD
       (tools/fp64_ilp.hip), entry-by-entry order made every FMA wait for the one before it."""
+  from rednose_amd.codegen import tuning
+  JB = JB or tuning.current().run_jb
   out = []
   blocks = [list(range(j, min(j + JB, E))) for j in range(0, E, JB)]
   sg = "-=" if op == "-=" else "+="
