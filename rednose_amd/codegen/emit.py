@@ -28,11 +28,12 @@ SMALL_MAX_E = 7    # lane-per-filter register budget: x, P and the update's temp
 #   no_model_defaults  the per-model tuning defaults (two wavefronts per SIMD) spilled -> general structure
 #   rts_one_wave       the smoother spilled under the two-wavefronts-per-SIMD budget -> full register file
 #   no_rts             the smoother still touches scratch -> library without batch_rts (forward filter unaffected)
+#   no_rts4            the smoother with register-broadcast operands (emit_rts4, two wavefronts per SIMD) spilled -> emit_rts3
 #   no_rts3            the smoother in the fused run's layout (emit_rts3) spilled -> rn::k_rts_group
 #   no_run_blk         the blocked fused run of a lane-per-filter model (emit_small.run_kernel_blk) spilled -> k_run serves untraced runs too
 #   no_run             the fused multi-step run of a model above 32 error states touches scratch -> library without batch_run
 #                      (status ERR_UNSUPPORTED, the step-granular entry points cover such models)
-FALLBACKS = ("force_wide", "no_model_defaults", "no_rts3", "rts_one_wave", "no_rts", "no_run", "no_run_blk")
+FALLBACKS = ("force_wide", "no_model_defaults", "no_rts4", "no_rts3", "rts_one_wave", "no_rts", "no_run", "no_run_blk")
 _active = frozenset()      # fallbacks of the emit() call in progress
 
 
@@ -176,8 +177,11 @@ def _emit(spec):
   # smoother.  Lane-per-filter models: rn::k_rts (state and covariance of a filter in one lane's registers).  Lane-group
   # models, MSCKF ones included (their main block is smoothed, ekf_sym.py:675-686): rn::k_rts_group.
   group_rts = fam == "wide"
-  from rednose_amd.codegen import emit_rts3
-  use_rts3 = (group_rts and E <= 32 and emit_rts3.applicable(spec) and tuning.current().rts3 and "no_rts3" not in _active and "no_rts" not in _active)
+  from rednose_amd.codegen import emit_rts3, emit_rts4
+  use_rts4 = (group_rts and emit_rts4.applicable(spec) and tuning.current().rts4 and "no_rts4" not in _active and "no_rts3" not in _active and "no_rts" not in _active)
+  use_rts3 = (not use_rts4 and group_rts and E <= 32 and emit_rts3.applicable(spec) and tuning.current().rts3 and "no_rts3" not in _active and "no_rts" not in _active)
+  if use_rts4:
+    src.append(emit_rts4.kernel(spec))
   if use_rts3:
     src.append(emit_rts3.kernel(spec))
   has_rts = (group_rts or (fam == "small" and spec.dim_main == spec.dim_x and spec.dim_main_err == spec.dim_err)) and "no_rts" not in _active
@@ -378,7 +382,9 @@ int {name}_batch_predict_update_{k.kind}{sfx}(double *x, double *P, const double
   hdr.append(f"int {name}_batch_run(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts, int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, double *trace_x, double *trace_P, const double *ea, const int32_t *augment, void *stream);")
 
   if has_rts:
-    if use_rts3:
+    if use_rts4:
+      launch = emit_rts4.launch(spec)
+    elif use_rts3:
       launch = emit_rts3.launch(spec)
     elif group_rts:
       GLr = 16 if M <= 16 else (32 if M <= 32 else 64)

@@ -1,0 +1,479 @@
+"""Kernel family W, smoother `k_rts4`: the RTS backward pass with EVERY BROADCAST OPERAND TAKEN FROM REGISTERS (`row_newbcast`).
+
+Reference: the Python-only `EKF_sym.rts_smooth` (/root/reference/rednose/helpers/ekf_sym.py:651-690); per backward step k
+    Fk = F(xk_k, t[k+1] - t[k]);  Ck = solve(Pk1_k, Fk Pk_k^T)^T;  xk_n = err(xk_k, Ck inv_err(xk1_k, xk1_n));
+    Pk_n = Pk_k + Ck (Pk1_n - Pk1_k) Ck^T
+with the predicted pair (xk1_k, Pk1_k) recomputed from the filtered one (templates/ekf_hip_rts.h explains the recursion's quirks,
+which are kept: start from the PREDICTED pair of the last step, in-place renormalisation of xk1_n).
+
+Why a fourth smoother.  `k_rts3` (emit_rts3.py) runs ONE wavefront per SIMD (two row sets of 132 registers each + an LDS image per
+filter) and takes every operand another lane owns through LDS: one 8-byte broadcast read feeds three FMAs, four wavefronts share a
+CU's LDS, and a lone wavefront issues an fp64 instruction every ~10 cycles (a dependent one every ~27-40): 0.25 of the HBM roofline
+for two rounds, whatever was moved inside it (profiles/tuning_notes.md).  CDNA3/4 have exactly one cross-lane form for fp64
+arithmetic: `v_fmac_f64_dpp ... row_newbcast:L` -- lane L of every 16-lane row feeds all 16 lanes of that row, at the plain FMA's
+issue rate (tools/dpp_probe.hip: 5.4-5.8 cycles per instruction with two wavefronts per SIMD, 6.5 alone; semantics checked there).
+So here a filter is ONE 16-LANE ROW (4 filters per wavefront), lane c owns rows c and c + 16 of every matrix, and
+  * the right-looking L D L^T factorisation, both substitutions and both E^3 products read the other lanes' rows straight out of
+    their registers: no LDS broadcast, no LDS round trip inside a dependent chain, 22 independent accumulation chains per pass;
+  * the smoothed covariance of step k + 1 is CARRIED in registers (k_rts3 stored it and read it back: +11 % traffic, a wait for
+    the previous step's stores in the middle of every step);
+  * at most two row sets (2 x 88 registers for 22 error states) + one half set are live at any point, the third matrix of each
+    phase waits in the filter's single E x E image of LDS -- 19.5 KB per wavefront for live: EIGHT wavefronts per CU, two per
+    SIMD, which is what hides the dependent chains (pivot reciprocals, the one-lane scalar phase) that a lone wavefront exposes.
+The price: 22 of 32 row slots busy (k_rts3: 22 of 24), i.e. ~1.15 x the vector instructions per filter-step.
+
+  step k (image I per filter; register row sets in capitals):
+    Pk_k HBM -> I (one coalesced asynchronous burst); lead lanes evaluate f / F non-zeros (scal_predict) meanwhile
+    rows of Pk_k <- I (lower triangle mirrored: the batch_rts contract);  rows of A = Pk_k Fk^T (row-local, sparse) -> I
+    Pp <- rows of Pk1_k = (columns of A) Fk^T + dt Q;   D <- PS - Pp  (PS: smoothed covariance of step k + 1, carried)
+    Pp <- its L D L^T factor, right-looking: column j scaled by the broadcast pivot's reciprocal, trailing columns updated with
+          v_fmac_f64_dpp (unscaled entry of row m from lane m, own scaled entry as the other factor)
+    per row slot: Y <- row of A from I; forward substitution, scaling, backward substitution (axpy form, 21 .. 1 independent
+          FMAs per pivot); Y = row of Ck -> I
+    state: delta = Ck inv_err(xk1_k, xk1_n), xk_n = err(xk_k, delta)  (lead lanes + one E-term dot per row)
+    T <- Ck D per row slot (coefficients: the lane's own row of Ck from I; operands: rows of D by row_newbcast)
+    CK <- I;  U = T Ck^T per row slot (operands: rows of Ck by row_newbcast); symmetric: slot 0 forms columns 0 .. 15 only
+    I <- U (mirrored);  Pk_n = Pk_k + U: one coalesced read-add-write over the tile's records, the sum also goes back into I
+    PS <- rows of I
+
+Generated for ordinary (non-MSCKF) lane-group models with an even number of error states whose 4 images + vectors fit 20 KB of
+LDS (8 .. 22 error states: live); every other lane-group model keeps k_rts3 / rn::k_rts_group.
+"""
+from rednose_amd.codegen.emit_common import term, sum_terms
+
+GL = 16            # lanes per filter: one DPP row
+FPW = 4            # filters per wavefront
+LDS_BUDGET = 20480  # bytes per wavefront: eight wavefronts on a CU's 160 KB
+
+
+MACROS = r"""
+// ---- fp64 cross-lane operands without LDS: lane L of every 16-lane row feeds the row (the only DPP form double-precision ALU
+// instructions have on gfx90a / gfx94x / gfx950).  tools/dpp_probe.hip: semantics, and the same issue rate as a plain v_fma_f64.
+// EXEC must be full where these execute (a disabled source lane is not a valid source): the kernel keeps them out of divergent code.
+#ifndef RN4_FMAC
+#define RN4_FMAC(acc, src, coef, L)  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #L " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(coef))
+#define RN4_FNMAC(acc, src, coef, L) asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:" #L " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(coef))
+// (s_nop 1: a DPP read of a register the previous vector instruction wrote wants two wait states; inline asm is opaque to hipcc's hazard pass)
+#define RN4_BC(dst, src, L)          asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:" #L " row_mask:0xf bank_mask:0xf" : "=v"(dst) : "v"(src))
+#endif
+"""
+
+
+def _ind(lines, n=2):
+  pad = " " * n
+  return [pad + s for s in lines]
+
+
+def rows_per_lane(spec):
+  return -(-spec.dim_err // GL)
+
+
+def lds_bytes(spec, slot):
+  D, E = spec.dim_x, spec.dim_err
+  return 8 * (FPW * E * E + 2 + FPW * slot + 2 * (FPW * D + 2) + FPW * E + 2)
+
+
+def applicable(spec):
+  from rednose_amd.codegen import emit_rts3
+  if not emit_rts3.applicable(spec):
+    return False
+  E = spec.dim_err
+  if E % 2 or E < 8 or E > 2 * GL:
+    return False
+  lay, _ = emit_rts3._tables(spec)           # pylint: disable=protected-access
+  return lds_bytes(spec, lay.SLOT) <= LDS_BUDGET
+
+
+def kernel(spec):
+  from rednose_amd.codegen import emit_rts3
+  D, E = spec.dim_x, spec.dim_err
+  EE = E * E
+  R = rows_per_lane(spec)
+  S = range(R)
+  RS = -(-E // R)        # rows per slot: row r lives in slot r // RS of lane r % RS (22 states: 2 x 11 -- balanced slots keep the block lower
+                         # triangles of the symmetric matrices at 11 + 22 columns per lane instead of 16 + 22, and lanes RS .. 15 idle)
+  scal, lay = emit_rts3._scal_text(spec)      # pylint: disable=protected-access
+  _, Fs = emit_rts3._tables(spec)             # pylint: disable=protected-access
+  scal = scal.replace("scal_predict_s(", "scal_predict_s4(")
+  quat = "".join(f" rn::normalize_quat<{D}>(xv, {q});" for q in spec.quaternion_idxs)
+  b = []
+  A = b.append
+
+  def slot_of(r):
+    return r // RS
+
+  def lane_of(r):
+    return r % RS
+
+  def last_row(s):       # last row index a slot can hold
+    return min(E, RS * s + RS) - 1
+
+  def ncol(s):           # columns a row slot keeps of a SYMMETRIC matrix: up to its last row (block lower triangle)
+    return last_row(s) + 1
+
+  def rows_decl(name, sym_=False):
+    return " ".join(f"double {name}{s}[{ncol(s) if sym_ else E}];" for s in S)
+
+  def lower_rows(name, ind="      ", src="sI", rc="rq", full=True):
+    """rows of a symmetric matrix from the LOWER triangle of the image: entry j of row r is M[r][j] for j <= r, M[j][r] above
+    (full=False: only the columns up to the slot's last row)."""
+    for s in S:
+      lo, hi = RS * s, min(E, RS * s + RS)
+      if lo:
+        A("#pragma unroll")
+        A(f"{ind}for (int j = 0; j < {lo}; j++) {name}{s}[j] = {src}[{rc}{s} * {E} + j];")
+      A("#pragma unroll")
+      A(f"{ind}for (int j = {lo}; j < {hi}; j++) {name}{s}[j] = {src}[(j <= {rc}{s}) ? {rc}{s} * {E} + j : j * {E} + {rc}{s}];")
+      if hi < E and full:
+        A("#pragma unroll")
+        A(f"{ind}for (int j = {hi}; j < {E}; j++) {name}{s}[j] = {src}[j * {E} + {rc}{s}];")
+
+  A(f"// ---- smoother, operands by row_newbcast: {GL} lanes x {R} rows per filter, {FPW} filters per wavefront (emit_rts4.py) ----")
+  A(MACROS)
+  A(f"constexpr int RTS4_SLOT = {lay.SLOT};")
+  A(scal)
+  qd_decl = "\n".join(f"  const double qd{s} = gQ[((c < {RS} && (c + {RS * s}) < {E}) ? (c + {RS * s}) : 0) * {E + 1}];" for s in S)
+  A(f"""
+__global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, const double* __restrict__ Pf, const double* __restrict__ ts,
+    const int64_t T, const double* __restrict__ gQ, const int64_t n, const int norm_quats, double* __restrict__ xs,
+    double* __restrict__ Ps, const double* __restrict__ xl, const double* __restrict__ Pl) {{
+  __shared__ __attribute__((aligned(16))) double s_I[{FPW} * {EE} + 2];          // the one matrix image per filter (see emit_rts4.py)
+  __shared__ __attribute__((aligned(16))) double s_sl[{FPW} * RTS4_SLOT];        // x' = f(xk_k), F non-zeros, dt
+  __shared__ __attribute__((aligned(16))) double s_xk[{FPW} * {D} + 2];          // xk_k
+  __shared__ __attribute__((aligned(16))) double s_xn[{FPW} * {D} + 2];          // xk1_n, then xk_n
+  __shared__ __attribute__((aligned(16))) double s_dv[{FPW} * {E} + 2];          // inv_err(xk1_k, xk1_n), then Ck delta
+  const int lane = threadIdx.x;
+  const int g = lane / {GL};
+  const int c = lane % {GL};
+  int qoff = 0;
+  for (int i = lane; i < {EE}; i += 64) qoff |= (i / {E} != i % {E}) && (gQ[i] != 0.0);
+  const bool qdiag = !__any(qoff);      // a diagonal process noise (the usual case) lives in registers
+{qd_decl}
+  const int64_t tiles = (n + {FPW} - 1) / {FPW};
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
+    const int64_t base = tile * {FPW};
+    const int cnt = (n - base) < {FPW} ? (int)(n - base) : {FPW};
+    const bool live = g < cnt;
+    const int gg = live ? g : 0;
+    const bool lead = live && c == 0;
+    double* sI = s_I + gg * {EE};
+    double* sl = s_sl + gg * RTS4_SLOT;
+    double* sxk = s_xk + gg * {D};
+    double* sxn = s_xn + gg * {D};
+    double* sdv = s_dv + gg * {E};
+    int ct = c, lt = lane;      // opaque per tile: index arithmetic derived from them is not hoisted to the kernel's entry (where it was ~80 spilled registers)
+    asm volatile("" : "+v"(ct), "+v"(lt));""")
+  for s in S:
+    A(f"    const int rr{s} = ct + {RS * s}; const bool ok{s} = live && ct < {RS} && rr{s} < {E}; const int rc{s} = (ct < {RS} && rr{s} < {E}) ? rr{s} : 0;")
+  A("    if (T == 1) {      // nothing to smooth, the single estimate's predicted pair is not available: the filtered pair passes through")
+  A(f"      if (Ps != Pf) {{ for (int i = lane; i < cnt * {EE}; i += 64) Ps[base * {EE} + i] = Pf[base * {EE} + i]; }}")
+  A(f"      if (xs != xf) {{ for (int i = lane; i < cnt * {D}; i += 64) xs[base * {D} + i] = xf[base * {D} + i]; }}")
+  A("      continue;")
+  A("    }")
+  XT = -(-(FPW * D) // 64)
+  A(f"    double xnext[{XT}];      // filtered state of the next step to process, in flight across the loop's back edge")
+  A("#pragma unroll")
+  A(f"    for (int it = 0; it < {XT}; it++) {{ const int i = lane + 64 * it; xnext[it] = xf[((T - 2) * n + base) * {D} + (i < cnt * {D} ? i : 0)]; }}")
+  A(f"    {rows_decl('ps', True)}      // rows of the smoothed covariance of step k + 1 (block lower triangle), carried from step to step; D = Pk1_n - Pk1_k inside a step")
+  for s in S:
+    A("#pragma unroll")
+    A(f"    for (int j = 0; j < {ncol(s)}; j++) ps{s}[j] = 0.0;")
+  A("    if (Pl != nullptr) {      // newest smoothed covariance := the predicted one of the last step as passed in (ekf_sym.py:658-659): through the image,")
+  A("      // like every later step's (lower triangle mirrored), and out to Ps[T - 1]")
+  A(f"      rn::async_copy_g2l<{FPW} * {EE}>(Pl + base * {EE}, cnt * {EE}, s_I, lt);")
+  A(f"      for (int i = lt; i < cnt * {EE}; i += 64) Ps[((T - 1) * n + base) * {EE} + i] = Pl[base * {EE} + i];")
+  A("      rn::async_wait();")
+  A("      rn::wave_lds_sync();")
+  lower_rows("ps", ind="      ", rc="rc", full=False)
+  A("      rn::wave_lds_sync();")
+  A("    }")
+  A("    for (int64_t k = T - 2; k >= 0; k--) {")
+  A("      const bool first = (k == T - 2);")
+  A("      int lb = lane;")
+  A('      asm volatile("" : "+v"(lb));         // opaque copy of the lane index: the copies\' index arithmetic stays inside the step')
+  A("      int " + ", ".join(f"rq{s} = rc{s}" for s in S) + ";      // (same for the row indices: hoisted out of the step loop, the LDS addresses they feed were ~150 spilled registers)")
+  A('      asm volatile("" : ' + ", ".join(f'"+v"(rq{s})' for s in S) + ");")
+  A("      RN_RTS_STAMP(0);")
+  A("      // ---- A. filtered pair of step k: Pk_k -> image in one coalesced burst, xk_k -> LDS ----")
+  A(f"      rn::async_copy_g2l<{FPW} * {EE}>(Pf + (k * n + base) * {EE}, cnt * {EE}, s_I, lb);      // no register staging: lands under the scalar phase")
+  A("#pragma unroll")
+  A(f"      for (int it = 0; it < {XT}; it++) {{ const int i = lb + 64 * it; if (i < cnt * {D}) s_xk[i] = xnext[it]; }}")
+  A("      const double dt = ts[k + 1] - ts[k];")
+  A("      rn::wave_lds_sync();")
+  A("      RN_RTS_STAMP(1);")
+  A("      // ---- B. f(xk_k) [renormalised like the forward pass], non-zeros of Fk: once per filter -> slot ----")
+  A("      if (lead) scal_predict_s4(sxk, dt, sl, norm_quats & 1);")
+  A("      rn::async_wait();")
+  A("      rn::wave_lds_sync();")
+  A("      {")
+  A(f"        {rows_decl('pf')}      // rows of Pk_k (lower triangle mirrored: the contract of batch_rts, include/rednose_amd_filter.h)")
+  lower_rows("pf", ind="        ")
+  A("        rn::wave_lds_sync();      // every lane has its rows: the image takes A")
+  A("        RN_RTS_STAMP(2);")
+  A("        // ---- C. rows of A = Pk_k Fk^T (row-local, F's structural zeros cost nothing): the right-hand sides; they wait in the image,")
+  A("        // whose columns are the rows of Fk Pk_k (P = P^T up to rounding, as in the fused run's predict) ----")
+  for s in S:
+    for i0 in range(0, E, 8):      # (in pieces behind scheduling boundaries: left alone hipcc forms all 2 E sums before it stores the first)
+      A(f"        if (ok{s}) {{")
+      for i in range(i0, min(E, i0 + 8)):
+        A(f"          sI[rq{s} * {E} + {i}] = {sum_terms(term(cf, f'pf{s}[{kk}]') for kk, cf in Fs.row_nz(i))};")
+      A("        }")
+      A("        __builtin_amdgcn_sched_barrier(0);")
+  A("      }")
+  A("      rn::wave_lds_sync();")
+  A(f"      {rows_decl('a', True)}      // rows of Pk1_k up to each slot's last row (symmetric: the block lower triangle is all anything reads), then its L D L^T factor (unit lower triangle, reciprocal pivots on the diagonal)")
+  A("      if (qdiag) {")
+  for s in S:
+    A("        {")
+    A(f"          double col[{E}];")
+    A(f"          const double dq = dt * qd{s};")
+    A("#pragma unroll")
+    A(f"          for (int m = 0; m < {E}; m++) col[m] = sI[m * {E} + rq{s}];      // column of A = row of Fk Pk_k")
+    for j in range(ncol(s)):
+      diag = f" + (rq{s} == {j} ? dq : 0.0)" if RS * s <= j < RS * (s + 1) else ""
+      A(f"          a{s}[{j}] = {sum_terms(term(cf, f'col[{m}]') for m, cf in Fs.row_nz(j))}{diag};")
+    A("        }")
+    A("        __builtin_amdgcn_sched_barrier(0);")
+  A("      } else {")
+  for s in S:
+    A("        {")
+    A(f"          double col[{E}], q[{(E + 1) // 2}];")
+    A("#pragma unroll")
+    A(f"          for (int m = 0; m < {E}; m++) col[m] = sI[m * {E} + rq{s}];      // column of A = row of Fk Pk_k")
+    for j in range(ncol(s)):
+      A(f"          a{s}[{j}] = {sum_terms(term(cf, f'col[{m}]') for m, cf in Fs.row_nz(j))};")
+    A("          rn::wave_lds_sync();      // (scheduling boundary: the column is dead before the row of Q is requested)")
+    H2 = (ncol(s) + 1) // 2
+    for lo_, hi_ in ((0, H2), (H2, ncol(s))):
+      A("#pragma unroll")
+      A(f"          for (int j = {lo_}; j < {hi_}; j++) q[j - {lo_}] = gQ[rq{s} * {E} + j];")
+      A("#pragma unroll")
+      A(f"          for (int j = {lo_}; j < {hi_}; j++) a{s}[j] = fma(dt, q[j - {lo_}], a{s}[j]);")
+    A("        }")
+  A("      }")
+  A("      RN_RTS_STAMP(3);")
+  A("      // ---- D. recursion start / difference matrix (the image keeps A: the substitutions take their right-hand sides from it) ----")
+  A("      if (first) {")
+  A("        // newest estimate := the predicted pair of the last step (passed in, or recomputed just now): ekf_sym.py:658-659")
+  A("        if (live) {       // (two loops, not one select between a global and an LDS source: hipcc 7.2 trips over the generic pointer)")
+  A(f"          if (xl != nullptr) {{ for (int i = c; i < {D}; i += {GL}) sxn[i] = xl[(base + gg) * {D} + i]; }}")
+  A(f"          else {{ for (int i = c; i < {D}; i += {GL}) sxn[i] = sl[{lay.OFF_X} + i]; }}")
+  A("        }")
+  A("        if (Pl == nullptr) {      // (a covariance that was passed in went into ps* before the loop)")
+  A(f"          double* __restrict__ po = Ps + ((k + 1) * n + base + gg) * {EE};      // the recomputed Pk1_k leaves mirrored from the block lower triangle the lanes hold")
+  for s in S:
+    A("#pragma unroll")
+    A(f"          for (int j = 0; j < {ncol(s)}; j++) {{ ps{s}[j] = a{s}[j]; if (ok{s}) po[rr{s} * {E} + j] = a{s}[j]; }}")
+    if RS * s:
+      A("#pragma unroll")
+      A(f"          for (int j = 0; j < {RS * s}; j++) {{ if (ok{s}) po[j * {E} + rr{s}] = a{s}[j]; }}")
+  A("        }")
+  A("      }")
+  A("      if (lead && (norm_quats & 2)) {")
+  A(f"        double xv[{D}];")
+  A("#pragma unroll")
+  A(f"        for (int i = 0; i < {D}; i++) xv[i] = sxn[i];")
+  A(f"       {quat}")
+  A("#pragma unroll")
+  A(f"        for (int i = 0; i < {D}; i++) sxn[i] = xv[i];")
+  A("      }")
+  A("      rn::wave_lds_sync();")
+  A("      {")
+  A("        int lo = lane;")
+  A('        asm volatile("" : "+v"(lo));')
+  A(f"        for (int i = lo; i < cnt * {D}; i += 64) xs[((k + 1) * n + base) * {D} + i] = s_xn[i];      // smoothed state of step k + 1 (after its renormalisation)")
+  A("      }")
+  A("      // state, first half: delta = inv_err(xk1_k, xk1_n) by the lead lanes (its chain runs under the factorisation of the other wavefront)")
+  A("      if (lead) {")
+  A(f"        double xb[{D}], xn1[{D}], delta[{E}];")
+  A("#pragma unroll")
+  A(f"        for (int i = 0; i < {D}; i++) {{ xb[i] = sl[{lay.OFF_X} + i]; xn1[i] = sxn[i]; }}")
+  A("        inv_err_fun(xb, xn1, delta);")
+  A("#pragma unroll")
+  A(f"        for (int i = 0; i < {E}; i++) sdv[i] = delta[i];")
+  A("      }")
+  for s in S:
+    A("#pragma unroll")
+    A(f"      for (int j = 0; j < {ncol(s)}; j++) {{ ps{s}[j] -= a{s}[j]; rn::pin(ps{s}[j]); }}      // D = Pk1_n - Pk1_k, block lower triangle (the product takes D[kk][j] = D[j][kk] from whichever lane holds it).  (pinned: hipcc sinks the subtraction to its first use after the substitutions and keeps BOTH operands -- a copy of Pk1_k beside its factor -- alive until then)")
+  A("      RN_RTS_STAMP(4);")
+  A("      // ---- E. L D L^T of Pk1_k, right-looking, lower triangle.  Column j: the pivot comes from lane j by row_newbcast, every lane")
+  A("      // forms its reciprocal (v_rcp_f64 + two Newton steps) and its scaled entries; the trailing update of column m reads the")
+  A("      // UNSCALED entry (m, j) from lane m's register and multiplies with the lane's own scaled entry.  Column j + 1 is")
+  A("      // completed first and its pivot's reciprocal chain started before the rest of column j's update is issued. ----")
+
+  def upd_slots(m):          # slots that hold a row >= m
+    return [s for s in S if last_row(s) >= m]
+
+  A("      double dj_0;")
+  A(f"      RN4_BC(dj_0, a{slot_of(0)}[0], {lane_of(0)});")
+  A("      double id_0 = rn::fast_recip(dj_0);")
+  for s in S:
+    if last_row(s) > 0:
+      A(f"      double l{s}_0 = a{s}[0] * id_0;")
+  for j in range(E):
+    if j + 1 < E:
+      m = j + 1
+      for s in upd_slots(m):
+        A(f"      RN4_FNMAC(a{s}[{m}], a{slot_of(m)}[{j}], l{s}_{j}, {lane_of(m)});")
+      A(f"      double dj_{m};")
+      A(f"      RN4_BC(dj_{m}, a{slot_of(m)}[{m}], {lane_of(m)});")
+      A(f"      const double id_{m} = rn::fast_recip(dj_{m});")
+      for m2 in range(j + 2, E):
+        for s in upd_slots(m2):
+          A(f"      RN4_FNMAC(a{s}[{m2}], a{slot_of(m2)}[{j}], l{s}_{j}, {lane_of(m2)});")
+    for s in S:
+      if last_row(s) >= j:
+        if last_row(s) > j:
+          A(f"      a{s}[{j}] = (rr{s} == {j}) ? id_{j} : l{s}_{j};")
+        else:
+          A(f"      a{s}[{j}] = id_{j};")
+    if j + 1 < E:
+      for s in S:
+        if last_row(s) > j + 1:
+          A(f"      const double l{s}_{j + 1} = a{s}[{j + 1}] * id_{j + 1};")
+  A("      RN_RTS_STAMP(5);")
+  A("      // ---- F. Ck^T = Pk1_k^-1 M, one row slot at a time (its right-hand side = the lane's row of A, waiting in the image):")
+  A("      // forward substitution with the unit factor, scaling by the reciprocal pivots, backward substitution, all in axpy form --")
+  A("      // the factor's entry comes from its owner's register by row_newbcast, 21 .. 1 independent FMAs per pivot. ----")
+  for s in S:
+    A("      {")
+    A(f"        double y[{E}];")
+    A("#pragma unroll")
+    A(f"        for (int j = 0; j < {E}; j++) y[j] = sI[rq{s} * {E} + j];")
+    for m in range(E):
+      for i in range(m + 1, E):
+        A(f"        RN4_FNMAC(y[{i}], a{slot_of(i)}[{m}], y[{m}], {lane_of(i)});")
+    for m in range(E):
+      A(f"        {{ double t_; RN4_BC(t_, a{slot_of(m)}[{m}], {lane_of(m)}); y[{m}] *= t_; }}")
+    for m in range(E - 1, 0, -1):
+      for i in range(m - 1, -1, -1):
+        A(f"        RN4_FNMAC(y[{i}], a{slot_of(m)}[{i}], y[{m}], {lane_of(m)});")
+    A(f"        if (ok{s}) {{")
+    A("#pragma unroll")
+    A(f"          for (int j = 0; j < {E}; j++) sI[rq{s} * {E} + j] = y[j];      // row of Ck (each lane overwrites the row it read)")
+    A("        }")
+    A("      }")
+  A("      rn::wave_lds_sync();")
+  A("      RN_RTS_STAMP(6);")
+  A("      // ---- H. T = Ck D, one row slot at a time: coefficients = the lane's row of Ck, operands = rows of D from their owners ----")
+  A(f"      {rows_decl('t')}")
+  A("      double " + ", ".join(f"dx{s}" for s in S) + ";      // state, second half: Ck delta (one E-term dot per row), formed while the row of Ck is in registers anyway")
+  for s in S:
+    A("      {")
+    A(f"        double ck[{E}];")
+    A("#pragma unroll")
+    A(f"        for (int j = 0; j < {E}; j++) ck[j] = sI[rq{s} * {E} + j];")
+    A("        {")
+    A(f"          double de[{E}];")
+    A("#pragma unroll")
+    A(f"          for (int j = 0; j < {E}; j++) de[j] = sdv[j];")
+    A(f"          dx{s} = (" + " + ".join(f"ck[{j}]*de[{j}]" for j in range(0, E, 2)) + ") + (" + (" + ".join(f"ck[{j}]*de[{j}]" for j in range(1, E, 2)) or "0.0") + ");")
+    A(f"          rn::pin(dx{s});")
+    A("        }")
+    A("        rn::wave_lds_sync();      // (compiler fence: delta is re-read by the next slot instead of staying in 2 E registers under this slot's product)")
+    A("#pragma unroll")
+    A(f"        for (int j = 0; j < {E}; j++) t{s}[j] = 0.0;")
+    for kk in range(E):
+      for j in range(E):
+        if j < ncol(slot_of(kk)):
+          A(f"        RN4_FMAC(t{s}[{j}], ps{slot_of(kk)}[{j}], ck[{kk}], {lane_of(kk)});")
+        else:            # D[kk][j] above the block triangle of row kk: D[j][kk] from row j's lane
+          A(f"        RN4_FMAC(t{s}[{j}], ps{slot_of(j)}[{kk}], ck[{kk}], {lane_of(j)});")
+    A("      }")
+  A("      RN_RTS_STAMP(7);")
+  A("      // ---- I. U = T Ck^T: operands = rows of Ck from their owners' registers.  U is symmetric (D is, up to rounding): a row slot")
+  A("      // forms the columns up to its last row, the upper-right block is mirrored inside the image ----")
+  A(f"      {rows_decl('ck')}")
+  for s in S:
+    A("#pragma unroll")
+    A(f"      for (int j = 0; j < {E}; j++) ck{s}[j] = sI[rq{s} * {E} + j];")
+  A("      rn::wave_lds_sync();      // every lane has read delta and has its rows of Ck: the buffer takes Ck delta, the image U")
+  for s in S:
+    A(f"      if (ok{s}) sdv[rr{s}] = dx{s};")
+  for s in reversed(S):
+    ncol = last_row(s) + 1
+    A("      {")
+    A(f"        double u[{ncol}];")
+    A("#pragma unroll")
+    A(f"        for (int j = 0; j < {ncol}; j++) u[j] = 0.0;")
+    for kk in range(E):
+      for j in range(ncol):
+        A(f"        RN4_FMAC(u[{j}], ck{slot_of(j)}[{kk}], t{s}[{kk}], {lane_of(j)});")
+    A(f"        if (ok{s}) {{")
+    A("#pragma unroll")
+    A(f"          for (int j = 0; j < {ncol}; j++) sI[rq{s} * {E} + j] = u[j];")
+    A("        }")
+    A("      }")
+  A("      rn::wave_lds_sync();")
+  A("      RN_RTS_STAMP(8);")
+  A("      // ---- J. Pk_n = Pk_k + U leaves: one coalesced read-add-write over the tile's records; the sum also returns to the image,")
+  A("      // from which every lane takes its rows of the smoothed covariance for the next (older) step ----")
+  if any(last_row(s) + 1 < E for s in S):
+    A("      {      // upper-right blocks: U[r][j] = U[j][r] for the columns beyond a slot's last row")
+    for s in S:
+      ncol = last_row(s) + 1
+      if ncol < E:
+        A(f"        if (ok{s}) {{")
+        A(f"          double m_[{E - ncol}];")
+        A("#pragma unroll")
+        A(f"          for (int j = {ncol}; j < {E}; j++) m_[j - {ncol}] = sI[j * {E} + rq{s}];")
+        A("#pragma unroll")
+        A(f"          for (int j = {ncol}; j < {E}; j++) sI[rq{s} * {E} + j] = m_[j - {ncol}];")
+        A("        }")
+    A("      }")
+    A("      rn::wave_lds_sync();")
+  IT = -(-(FPW * EE // 2) // 64)
+  A("      {")
+  A("        typedef double rts4_d2 __attribute__((ext_vector_type(2)));")
+  A("        int le = lane;")
+  A('        asm volatile("" : "+v"(le));')
+  A(f"        const rts4_d2* __restrict__ in2 = reinterpret_cast<const rts4_d2*>(Pf + (k * n + base) * {EE});")
+  A(f"        rts4_d2* __restrict__ out2 = reinterpret_cast<rts4_d2*>(Ps + (k * n + base) * {EE});")
+  A(f"        const int nv = cnt * {EE // 2};")
+  A(f"        rts4_d2 v[{IT}];")
+  A("#pragma unroll")
+  A(f"        for (int it = 0; it < {IT}; it++) {{ const int idx = le + 64 * it; v[it] = in2[idx < nv ? idx : nv - 1]; }}")
+  A("        if (k > 0) {")
+  A("#pragma unroll")
+  A(f"          for (int it = 0; it < {XT}; it++) {{ const int i = lane + 64 * it; xnext[it] = xf[((k - 1) * n + base) * {D} + (i < cnt * {D} ? i : 0)]; }}")
+  A("        }")
+  A("        if (lead) {      // state update, last part: one lane per filter, while the loads above are in flight")
+  A(f"          double xa[{D}], xnew[{D}], delta[{E}];")
+  A("#pragma unroll")
+  A(f"          for (int i = 0; i < {D}; i++) xa[i] = sxk[i];")
+  A("#pragma unroll")
+  A(f"          for (int i = 0; i < {E}; i++) delta[i] = sdv[i];")
+  A("          err_fun(xa, delta, xnew);")
+  A("#pragma unroll")
+  A(f"          for (int i = 0; i < {D}; i++) sxn[i] = xnew[i];       // xk_n: becomes xk1_n of the next (older) step")
+  A("        }")
+  A("#pragma unroll")
+  A(f"        for (int it = 0; it < {IT}; it++) {{")
+  A("          const int idx = le + 64 * it;")
+  A("          if (idx < nv) {")
+  A("            rts4_d2* im = reinterpret_cast<rts4_d2*>(s_I + 2 * idx);")
+  A("            const rts4_d2 w_ = v[it] + *im;")
+  A("            out2[idx] = w_;")
+  A("            *im = w_;")
+  A("          }")
+  A("        }")
+  A("      }")
+  A("      rn::wave_lds_sync();")
+  A('      asm volatile("" : ' + ", ".join(f'"+v"(rq{s})' for s in S) + ");      // (fresh addresses: those of the step's first row read are not worth registers across the step)")
+  lower_rows("ps", full=False)
+  A("      rn::wave_lds_sync();      // every lane has its rows: the image is free for the next step's burst")
+  A("      RN_RTS_STAMP(9);")
+  A("      RN_RTS_STAMP(10);")
+  A("    }")
+  A("    // ---- the oldest smoothed state goes out un-normalised (ekf_sym.py:665-667 never reaches it); its covariance left above ----")
+  A(f"    for (int i = lane; i < cnt * {D}; i += 64) xs[base * {D} + i] = s_xn[i];")
+  A("    rn::wave_lds_sync();")
+  A("  }")
+  A("}")
+  return "\n".join(b)
+
+
+def launch(spec):
+  return f"""  const int64_t tiles = (n + {FPW - 1}) / {FPW};
+  hipLaunchKernelGGL(k_rts4, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     xf, Pf, ts, T, Q, n, norm_quats, xs, Ps, x_last, P_last);"""

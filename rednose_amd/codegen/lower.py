@@ -167,11 +167,15 @@ class Block:
       trig, where = {}, {}
       defined = {sym: i for i, (sym, _) in enumerate(repl)}
       for e in [sub for _, sub in repl] + list(reduced):
-        for node in sp.preorder_traversal(e):          # (encounter order: the names must not depend on a set's iteration order)
+        # post-order: the argument of an outer call may itself contain a sin / cos that CSE left in place (sin(x + cos(y))); the
+        # inner pair is then registered -- and, landing at the same place, emitted -- BEFORE the call that reads it.  (Encounter
+        # order otherwise: the names must not depend on a set's iteration order.)
+        for node in sp.postorder_traversal(e):
           if isinstance(node, (sp.sin, sp.cos)) and node.args[0] not in trig:
             arg = node.args[0]
             trig[arg] = f"{self.tmp_prefix}sc{len(trig)}"
-            where[arg] = max([defined[q] + 1 for q in arg.free_symbols if q in defined] + [0])
+            inner = [where[t.args[0]] for t in arg.atoms(sp.sin, sp.cos)]
+            where[arg] = max([defined[q] + 1 for q in arg.free_symbols if q in defined] + inner + [0])
       pr = HipPrinter(self.names, trig)
 
       def trig_group(i):

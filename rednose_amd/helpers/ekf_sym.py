@@ -75,6 +75,8 @@ def gen_code(folder, name, f_sym, dt_sym, x_sym, obs_eqs, dim_x, dim_err, eskf_p
         usage, bad = fall_back("no_run_blk", "a blocked fused run spills registers: the step-at-a-time k_run serves fused runs instead")
       if bad and rn_emit.family(spec, ()) == "small":
         usage, bad = fall_back("force_wide", f"lane-per-filter kernels {bad} spill registers: regenerating in the lane-group family")
+      if "k_rts4" in bad:
+        usage, bad = fall_back("no_rts4", "the register-broadcast smoother spills under its two-wavefronts-per-SIMD budget: the fused run's layout instead")
       if "k_rts3" in bad:
         usage, bad = fall_back("no_rts3", "the smoother in the fused run's layout spills registers: lane-group smoother instead")
       if "k_run" in bad and usage["k_run"]["scratch"] > 0 and rn_emit.family(spec, tuple(fallbacks)) == "wide":

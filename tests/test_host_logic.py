@@ -289,6 +289,42 @@ def test_lowered_sin_cos_pairs_and_their_accuracy(tmp_path):
   assert np.isnan(ob[0]).all() and np.isnan(ob[1]).all()
 
 
+def test_nested_trigonometric_arguments_are_declared_before_use(tmp_path):
+  """A sin / cos whose argument contains another one that CSE leaves in place (single use: sin(x + cos(y))): the inner pair has to be
+  computed before the call that reads it.  The lowered block is compiled for the host and compared with libm."""
+  import ctypes
+  import subprocess
+  import sympy as sp
+  from rednose_amd.codegen.lower import Block, SINCOS_FAST
+  x, y = sp.symbols("x y")
+  blk = Block(names={x: "v[0]", y: "v[1]"})
+  blk.add("o[0]", sp.sin(x + sp.cos(y)))
+  blk.add("o[1]", sp.cos(sp.sin(y * sp.cos(x)) + x))
+  stmts, _ = blk.lower(decl="")
+  declared = set()
+  for ln in stmts:
+    for name in __import__("re").findall(r"\b(tsc\d+)_[sc]\b", ln.split("rn::sincos_fast(")[-1] if "rn::sincos_fast(" in ln else ln):
+      assert name in declared or ln.startswith(f"double {name}_s"), ln
+    if ln.startswith("double tsc"):
+      arg = ln.split("rn::sincos_fast(")[1].split(",")[0]
+      for name in __import__("re").findall(r"\b(tsc\d+)_[sc]\b", arg):
+        assert name in declared, f"{name} used before its declaration: {ln}"
+      declared.add(ln.split()[1].split("_")[0])
+  src = "\n".join(["#include <cmath>", "#define __device__", "#define __forceinline__ inline", SINCOS_FAST,
+                   'extern "C" void blk(const double* v, double* o) {'] + ["  " + s_ for s_ in stmts] + ["}"])
+  cpp, lib = tmp_path / "nt.cpp", tmp_path / "libnt.so"
+  cpp.write_text(src, encoding="utf-8")
+  res = subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", str(cpp), "-o", str(lib)], capture_output=True, text=True)
+  assert res.returncode == 0, res.stderr[-2000:]
+  fn = ctypes.CDLL(str(lib)).blk
+  dp = ctypes.POINTER(ctypes.c_double)
+  for vx, vy in ((0.3, -1.2), (2.5, 0.7), (-4.0, 3.1)):
+    v, o = np.array([vx, vy]), np.zeros(2)
+    fn(v.ctypes.data_as(dp), o.ctypes.data_as(dp))
+    want = [np.sin(vx + np.cos(vy)), np.cos(np.sin(vy * np.cos(vx)) + vx)]
+    assert np.allclose(o, want, rtol=0, atol=1e-15), (o, want)
+
+
 def test_bench_prints_counter_traffic_only_for_the_build_it_was_taken_on(tmp_path):
   """bench.measured_traffic: a record of profiles/pmc_traffic.json applies to the library whose digest it names, or to a later build the
   record lists under `carried_to` (then the JSON line says so); any other build gets None -- never a number measured on different code."""
