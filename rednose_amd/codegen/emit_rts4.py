@@ -70,7 +70,7 @@ def rows_per_lane(spec):
 
 def lds_bytes(spec, slot):
   D, E = spec.dim_x, spec.dim_err
-  return 8 * (FPW * E * E + 2 + FPW * slot + 2 * (FPW * D + 2) + FPW * E + 2)
+  return 8 * (FPW * E * E + 2 + FPW * slot + 2 * (FPW * D + 2) + FPW * E + 2 + E + 2 * FPW * (GL - -(-E // rows_per_lane(spec))) + 2)
 
 
 def applicable(spec):
@@ -97,7 +97,20 @@ def kernel(spec):
   scal = scal.replace("scal_predict_s(", "scal_predict_s4(")
   quat = "".join(f" rn::normalize_quat<{D}>(xv, {q});" for q in spec.quaternion_idxs)
   b = []
-  A = b.append
+  # Issue priority: the two E^3 products (stamps 7 .. 9) are straight FMA streams that can run any time; everything else in a step is a chain of
+  # dependent latencies (LDS round trips, the pivots' reciprocals, the one-lane scalar phase, memory).  With the products at priority 0 and the
+  # rest at 3 the co-resident wavefront's chains issue ahead of this one's FMA stream: 8.31 -> 7.73 ms on 8 192 x 300 steps, same call
+  # (other windows measured: products + substitutions low 8.07, substitutions only 8.27, levels 1 / 2 instead of 3: 7.85; tools/rts4_time.py).
+  PRIO = (7, 9, 3)
+
+  def A(line):
+    b.append(line)
+    if PRIO and line.strip().startswith("RN_RTS_STAMP("):
+      st = int(line.strip()[len("RN_RTS_STAMP("):].split(")")[0])
+      if st == PRIO[0]:
+        b.append("      __builtin_amdgcn_s_setprio(0);")
+      elif st == PRIO[1]:
+        b.append(f"      __builtin_amdgcn_s_setprio({PRIO[2]});")
 
   def slot_of(r):
     return r // RS
@@ -123,7 +136,7 @@ def kernel(spec):
         A("#pragma unroll")
         A(f"{ind}for (int j = 0; j < {lo}; j++) {name}{s}[j] = {src}[{rc}{s} * {E} + j];")
       A("#pragma unroll")
-      A(f"{ind}for (int j = {lo}; j < {hi}; j++) {name}{s}[j] = {src}[(j <= {rc}{s}) ? {rc}{s} * {E} + j : j * {E} + {rc}{s}];")
+      A(f"{ind}for (int j = {lo}; j < {hi}; j++) {name}{s}[j] = {src}[{E} * max({rc}{s}, j) + min({rc}{s}, j)];      // (max / min / mad: no compare-select pair per entry)")
       if hi < E and full:
         A("#pragma unroll")
         A(f"{ind}for (int j = {hi}; j < {E}; j++) {name}{s}[j] = {src}[j * {E} + {rc}{s}];")
@@ -142,13 +155,13 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   __shared__ __attribute__((aligned(16))) double s_xk[{FPW} * {D} + 2];          // xk_k
   __shared__ __attribute__((aligned(16))) double s_xn[{FPW} * {D} + 2];          // xk1_n, then xk_n
   __shared__ __attribute__((aligned(16))) double s_dv[{FPW} * {E} + 2];          // inv_err(xk1_k, xk1_n), then Ck delta
+  __shared__ __attribute__((aligned(16))) double s_trash[{E} + 2 * {FPW * (GL - RS)} + 2];      // where the idle lanes' row stores go (no predicated regions around LDS stores): overlapping rows, 16 bytes apart
   const int lane = threadIdx.x;
   const int g = lane / {GL};
   const int c = lane % {GL};
   int qoff = 0;
   for (int i = lane; i < {EE}; i += 64) qoff |= (i / {E} != i % {E}) && (gQ[i] != 0.0);
-  const bool qdiag = !__any(qoff);      // a diagonal process noise (the usual case) lives in registers
-{qd_decl}
+  const bool qdiag = !__any(qoff);      // a diagonal process noise (the usual case): its row entry is requested at the head of every step
   const int64_t tiles = (n + {FPW} - 1) / {FPW};
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
     const int64_t base = tile * {FPW};
@@ -166,14 +179,16 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   for s in S:
     A(f"    const int rr{s} = ct + {RS * s}; const bool ok{s} = live && ct < {RS} && rr{s} < {E}; const int rc{s} = (ct < {RS} && rr{s} < {E}) ? rr{s} : 0;")
   A("    if (T == 1) {      // nothing to smooth, the single estimate's predicted pair is not available: the filtered pair passes through")
-  A(f"      if (Ps != Pf) {{ for (int i = lane; i < cnt * {EE}; i += 64) Ps[base * {EE} + i] = Pf[base * {EE} + i]; }}")
-  A(f"      if (xs != xf) {{ for (int i = lane; i < cnt * {D}; i += 64) xs[base * {D} + i] = xf[base * {D} + i]; }}")
+  A(f"      if (Ps != Pf) {{ for (int i = lt; i < cnt * {EE}; i += 64) Ps[base * {EE} + i] = Pf[base * {EE} + i]; }}")
+  A(f"      if (xs != xf) {{ for (int i = lt; i < cnt * {D}; i += 64) xs[base * {D} + i] = xf[base * {D} + i]; }}")
   A("      continue;")
   A("    }")
   XT = -(-(FPW * D) // 64)
-  A(f"    double xnext[{XT}];      // filtered state of the next step to process, in flight across the loop's back edge")
-  A("#pragma unroll")
-  A(f"    for (int it = 0; it < {XT}; it++) {{ const int i = lane + 64 * it; xnext[it] = xf[((T - 2) * n + base) * {D} + (i < cnt * {D} ? i : 0)]; }}")
+  IT = -(-(FPW * EE // 2) // 64)
+  ITF = (FPW * EE // 2) // 64          # iterations of the coalesced passes that are whole for a full tile
+  A("    // xk_k of the first step to process; every later one is committed to LDS by the step before it (nothing read from memory crosses the")
+  A("    // loop's back edge in registers: hipcc waits for such a value with vmcnt(0) at the loop header -- behind the previous step's stores)")
+  A(f"    for (int i = lt; i < cnt * {D}; i += 64) s_xk[i] = xf[((T - 2) * n + base) * {D} + i];")
   A(f"    {rows_decl('ps', True)}      // rows of the smoothed covariance of step k + 1 (block lower triangle), carried from step to step; D = Pk1_n - Pk1_k inside a step")
   for s in S:
     A("#pragma unroll")
@@ -187,62 +202,113 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   lower_rows("ps", ind="      ", rc="rc", full=False)
   A("      rn::wave_lds_sync();")
   A("    }")
+  A("    double dtc = ts[T - 1] - ts[T - 2];      // the step's time difference, read one step ahead (a scalar load's latency at the head of every step otherwise)")
+  if PRIO:
+    A(f"    __builtin_amdgcn_s_setprio({PRIO[2]});")
   A("    for (int64_t k = T - 2; k >= 0; k--) {")
   A("      const bool first = (k == T - 2);")
-  A("      int lb = lane;")
+  A("      int lb = lt;")
   A('      asm volatile("" : "+v"(lb));         // opaque copy of the lane index: the copies\' index arithmetic stays inside the step')
   A("      int " + ", ".join(f"rq{s} = rc{s}" for s in S) + ";      // (same for the row indices: hoisted out of the step loop, the LDS addresses they feed were ~150 spilled registers)")
   A('      asm volatile("" : ' + ", ".join(f'"+v"(rq{s})' for s in S) + ");")
+  A(f"      double* strash = s_trash + 2 * ((g * {GL - RS} + (ct >= {RS} ? ct - {RS} : ct)) % {max(1, FPW * (GL - RS))});      // (an idle lane's own 16 bytes of every row store: stores of many lanes to ONE address serialise)")
+  for s in S:
+    A(f"      double* sw{s} = ok{s} ? sI + rq{s} * {E} : strash;      // the lane's row of the image as a store target (idle lanes: a trash row)")
+  for s in S:
+    A(f"      const double qd{s} = gQ[rq{s} * {E + 1}];      // (not kept across steps: four registers of a kernel that has none to spare)")
   A("      RN_RTS_STAMP(0);")
   A("      // ---- A. filtered pair of step k: Pk_k -> image in one coalesced burst, xk_k -> LDS ----")
-  A(f"      rn::async_copy_g2l<{FPW} * {EE}>(Pf + (k * n + base) * {EE}, cnt * {EE}, s_I, lb);      // no register staging: lands under the scalar phase")
+  A(f"      if (cnt == {FPW}) {{      // (full tile: unguarded transfers -- sixteen predicated regions otherwise)")
+  A(f"        const double* __restrict__ gp = Pf + (k * n + base) * {EE};")
   A("#pragma unroll")
-  A(f"      for (int it = 0; it < {XT}; it++) {{ const int i = lb + 64 * it; if (i < cnt * {D}) s_xk[i] = xnext[it]; }}")
-  A("      const double dt = ts[k + 1] - ts[k];")
+  A(f"        for (int it = 0; it < {IT}; it++) {{")
+  A(f"          if (it < {ITF} || lb + 64 * it < {FPW * EE // 2})")
+  A("            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + 2 * (lb + 64 * it)), rn::lds_offset_ptr(s_I + 2 * 64 * it), 16, 0, 0);")
+  A("        }")
+  A("      } else {")
+  A(f"        rn::async_copy_g2l<{FPW} * {EE}>(Pf + (k * n + base) * {EE}, cnt * {EE}, s_I, lb);      // no register staging: lands under the scalar phase")
+  A("      }")
+  A("      const double dt = dtc;")
   A("      rn::wave_lds_sync();")
   A("      RN_RTS_STAMP(1);")
   A("      // ---- B. f(xk_k) [renormalised like the forward pass], non-zeros of Fk: once per filter -> slot ----")
   A("      if (lead) scal_predict_s4(sxk, dt, sl, norm_quats & 1);")
   A("      rn::async_wait();")
   A("      rn::wave_lds_sync();")
+  A("      RN_RTS_STAMP(2);")
   A("      {")
   A(f"        {rows_decl('pf')}      // rows of Pk_k (lower triangle mirrored: the contract of batch_rts, include/rednose_amd_filter.h)")
   lower_rows("pf", ind="        ")
   A("        rn::wave_lds_sync();      // every lane has its rows: the image takes A")
-  A("        RN_RTS_STAMP(2);")
+  A("        RN_RTS_STAMP(3);")
   A("        // ---- C. rows of A = Pk_k Fk^T (row-local, F's structural zeros cost nothing): the right-hand sides; they wait in the image,")
   A("        // whose columns are the rows of Fk Pk_k (P = P^T up to rounding, as in the fused run's predict) ----")
-  for s in S:
-    for i0 in range(0, E, 8):      # (in pieces behind scheduling boundaries: left alone hipcc forms all 2 E sums before it stores the first)
-      A(f"        if (ok{s}) {{")
-      for i in range(i0, min(E, i0 + 8)):
-        A(f"          sI[rq{s} * {E} + {i}] = {sum_terms(term(cf, f'pf{s}[{kk}]') for kk, cf in Fs.row_nz(i))};")
-      A("        }")
-      A("        __builtin_amdgcn_sched_barrier(0);")
+  # Both passes of the predict touch only the rows of Fk that have entries off the diagonal; their coefficients are read from the slot
+  # in GROUPS, the next group requested before the current group's FMAs (read where it is used, every pair of FMAs waited for its own
+  # LDS round trip: 3.5 us of a 24 us step; all 33 at once cost 66 registers under two row sets).
+  busy = [j for j in range(E) if any(m != j or cf[0] != 'one' for m, cf in Fs.row_nz(j))]
+  groups, cur, ncoef = [], [], 0
+  for j in busy:
+    nv_ = sum(1 for _, cf in Fs.row_nz(j) if cf[0] == 'var')
+    if cur and ncoef + nv_ > 10:
+      groups.append(cur)
+      cur, ncoef = [], 0
+    cur.append(j)
+    ncoef += nv_
+  if cur:
+    groups.append(cur)
+
+  def grouped(tag, ind, emit_row):
+    """emit_row(j, reg_term) -> C lines for row j of Fk, with the coefficients of the groups software-pipelined one group ahead."""
+    regname = {}
+
+    def gl(grp):
+      out = []
+      for j in grp:
+        for _, cf in Fs.row_nz(j):
+          if cf[0] == 'var' and cf[1] not in regname:
+            regname[cf[1]] = f"{tag}{len(regname)}"
+            out.append(f"{ind}const double {regname[cf[1]]} = {cf[1]};")
+      return out
+
+    def reg_term(cf, operand):
+      return f"{regname[cf[1]]}*{operand}" if cf[0] == 'var' else term(cf, operand)
+    b.extend(gl(groups[0]) if groups else [])
+    for gi, grp in enumerate(groups):
+      if gi + 1 < len(groups):
+        b.extend(gl(groups[gi + 1]))
+      A(f"{ind}__builtin_amdgcn_sched_barrier(0);")
+      for j in grp:
+        b.extend(ind + ln for ln in emit_row(j, reg_term))
+    A(f"{ind}__builtin_amdgcn_sched_barrier(0);")
+
+  for s in S:      # the columns Fk leaves alone first: most of the row set is dead before the sums are formed
+    A("#pragma unroll")
+    A(f"        for (int j = 0; j < {E}; j++) {{ if (" + (" && ".join(f"j != {jb}" for jb in busy) or "true") + f") sw{s}[j] = pf{s}[j]; }}")
+  A("        __builtin_amdgcn_sched_barrier(0);")
+  grouped("fp", "        ", lambda j, rt: [f"sw{s}[{j}] = {sum_terms(rt(cf, f'pf{s}[{kk}]') for kk, cf in Fs.row_nz(j))};" for s in S])
   A("      }")
   A("      rn::wave_lds_sync();")
   A(f"      {rows_decl('a', True)}      // rows of Pk1_k up to each slot's last row (symmetric: the block lower triangle is all anything reads), then its L D L^T factor (unit lower triangle, reciprocal pivots on the diagonal)")
+  for s in S:      # second pass, one row slot at a time: rows of Pk1_k = (columns of A) Fk^T
+    A("      {")
+    A(f"        double col[{E}];")
+    A("#pragma unroll")
+    A(f"        for (int m = 0; m < {E}; m++) col[m] = sI[m * {E} + rq{s}];      // column of A = row of Fk Pk_k")
+    grouped(f"fq{s}_", "        ", lambda j, rt, s=s: ([f"a{s}[{j}] = {sum_terms(rt(cf, f'col[{m}]') for m, cf in Fs.row_nz(j))};"] if j < ncol(s) else []))
+    for j in range(ncol(s)):
+      if j not in busy:
+        A(f"        a{s}[{j}] = col[{j}];")
+    A("      }")
   A("      if (qdiag) {")
   for s in S:
-    A("        {")
-    A(f"          double col[{E}];")
-    A(f"          const double dq = dt * qd{s};")
-    A("#pragma unroll")
-    A(f"          for (int m = 0; m < {E}; m++) col[m] = sI[m * {E} + rq{s}];      // column of A = row of Fk Pk_k")
-    for j in range(ncol(s)):
-      diag = f" + (rq{s} == {j} ? dq : 0.0)" if RS * s <= j < RS * (s + 1) else ""
-      A(f"          a{s}[{j}] = {sum_terms(term(cf, f'col[{m}]') for m, cf in Fs.row_nz(j))}{diag};")
-    A("        }")
-    A("        __builtin_amdgcn_sched_barrier(0);")
+    A(f"        const double dq{s} = dt * qd{s};")
+    for j in range(RS * s, min(E, RS * (s + 1))):
+      A(f"        a{s}[{j}] += (rq{s} == {j} ? dq{s} : 0.0);")
   A("      } else {")
   for s in S:
     A("        {")
-    A(f"          double col[{E}], q[{(E + 1) // 2}];")
-    A("#pragma unroll")
-    A(f"          for (int m = 0; m < {E}; m++) col[m] = sI[m * {E} + rq{s}];      // column of A = row of Fk Pk_k")
-    for j in range(ncol(s)):
-      A(f"          a{s}[{j}] = {sum_terms(term(cf, f'col[{m}]') for m, cf in Fs.row_nz(j))};")
-    A("          rn::wave_lds_sync();      // (scheduling boundary: the column is dead before the row of Q is requested)")
+    A(f"          double q[{(ncol(s) + 1) // 2}];")
     H2 = (ncol(s) + 1) // 2
     for lo_, hi_ in ((0, H2), (H2, ncol(s))):
       A("#pragma unroll")
@@ -251,7 +317,7 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
       A(f"          for (int j = {lo_}; j < {hi_}; j++) a{s}[j] = fma(dt, q[j - {lo_}], a{s}[j]);")
     A("        }")
   A("      }")
-  A("      RN_RTS_STAMP(3);")
+  A("      RN_RTS_STAMP(4);")
   A("      // ---- D. recursion start / difference matrix (the image keeps A: the substitutions take their right-hand sides from it) ----")
   A("      if (first) {")
   A("        // newest estimate := the predicted pair of the last step (passed in, or recomputed just now): ekf_sym.py:658-659")
@@ -263,12 +329,13 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   A(f"          double* __restrict__ po = Ps + ((k + 1) * n + base + gg) * {EE};      // the recomputed Pk1_k leaves mirrored from the block lower triangle the lanes hold")
   for s in S:
     A("#pragma unroll")
-    A(f"          for (int j = 0; j < {ncol(s)}; j++) {{ ps{s}[j] = a{s}[j]; if (ok{s}) po[rr{s} * {E} + j] = a{s}[j]; }}")
+    A(f"          for (int j = 0; j < {ncol(s)}; j++) {{ if (ok{s}) po[rr{s} * {E} + j] = a{s}[j]; }}")
     if RS * s:
       A("#pragma unroll")
       A(f"          for (int j = 0; j < {RS * s}; j++) {{ if (ok{s}) po[j * {E} + rr{s}] = a{s}[j]; }}")
   A("        }")
   A("      }")
+  A("      rn::wave_lds_sync();")
   A("      if (lead && (norm_quats & 2)) {")
   A(f"        double xv[{D}];")
   A("#pragma unroll")
@@ -279,23 +346,19 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   A("      }")
   A("      rn::wave_lds_sync();")
   A("      {")
-  A("        int lo = lane;")
+  A("        int lo = lb;")
   A('        asm volatile("" : "+v"(lo));')
   A(f"        for (int i = lo; i < cnt * {D}; i += 64) xs[((k + 1) * n + base) * {D} + i] = s_xn[i];      // smoothed state of step k + 1 (after its renormalisation)")
   A("      }")
+  A("      // D = Pk1_n - Pk1_k as fma(-1, Pk1_k, Pk1_n) -- the subtraction, bit for bit.  When the recursion starts from the predicted pair it has just")
+  A("      // recomputed, Pk1_n IS Pk1_k: the carried rows are still zero and the weight is 0, so D = 0 without a copy of the row set")
+  A("      const double dw = (first && Pl == nullptr) ? 0.0 : -1.0;")
   A("      // state, first half: delta = inv_err(xk1_k, xk1_n) by the lead lanes (its chain runs under the factorisation of the other wavefront)")
-  A("      if (lead) {")
-  A(f"        double xb[{D}], xn1[{D}], delta[{E}];")
-  A("#pragma unroll")
-  A(f"        for (int i = 0; i < {D}; i++) {{ xb[i] = sl[{lay.OFF_X} + i]; xn1[i] = sxn[i]; }}")
-  A("        inv_err_fun(xb, xn1, delta);")
-  A("#pragma unroll")
-  A(f"        for (int i = 0; i < {E}; i++) sdv[i] = delta[i];")
-  A("      }")
+  A(f"      if (lead) inv_err_fun(sl + {lay.OFF_X}, sxn, sdv);      // (straight from / to LDS: staged through arrays, the two states were 4 D registers next to two row sets)")
   for s in S:
     A("#pragma unroll")
-    A(f"      for (int j = 0; j < {ncol(s)}; j++) {{ ps{s}[j] -= a{s}[j]; rn::pin(ps{s}[j]); }}      // D = Pk1_n - Pk1_k, block lower triangle (the product takes D[kk][j] = D[j][kk] from whichever lane holds it).  (pinned: hipcc sinks the subtraction to its first use after the substitutions and keeps BOTH operands -- a copy of Pk1_k beside its factor -- alive until then)")
-  A("      RN_RTS_STAMP(4);")
+    A(f"      for (int j = 0; j < {ncol(s)}; j++) {{ ps{s}[j] = fma(dw, a{s}[j], ps{s}[j]); rn::pin(ps{s}[j]); }}      // D = Pk1_n - Pk1_k, block lower triangle (the product takes D[kk][j] = D[j][kk] from whichever lane holds it).  (pinned: hipcc sinks the subtraction to its first use after the substitutions and keeps BOTH operands -- a copy of Pk1_k beside its factor -- alive until then)")
+  A("      RN_RTS_STAMP(5);")
   A("      // ---- E. L D L^T of Pk1_k, right-looking, lower triangle.  Column j: the pivot comes from lane j by row_newbcast, every lane")
   A("      // forms its reciprocal (v_rcp_f64 + two Newton steps) and its scaled entries; the trailing update of column m reads the")
   A("      // UNSCALED entry (m, j) from lane m's register and multiplies with the lane's own scaled entry.  Column j + 1 is")
@@ -331,7 +394,7 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
       for s in S:
         if last_row(s) > j + 1:
           A(f"      const double l{s}_{j + 1} = a{s}[{j + 1}] * id_{j + 1};")
-  A("      RN_RTS_STAMP(5);")
+  A("      RN_RTS_STAMP(6);")
   A("      // ---- F. Ck^T = Pk1_k^-1 M, one row slot at a time (its right-hand side = the lane's row of A, waiting in the image):")
   A("      // forward substitution with the unit factor, scaling by the reciprocal pivots, backward substitution, all in axpy form --")
   A("      // the factor's entry comes from its owner's register by row_newbcast, 21 .. 1 independent FMAs per pivot. ----")
@@ -348,13 +411,11 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
     for m in range(E - 1, 0, -1):
       for i in range(m - 1, -1, -1):
         A(f"        RN4_FNMAC(y[{i}], a{slot_of(m)}[{i}], y[{m}], {lane_of(m)});")
-    A(f"        if (ok{s}) {{")
     A("#pragma unroll")
-    A(f"          for (int j = 0; j < {E}; j++) sI[rq{s} * {E} + j] = y[j];      // row of Ck (each lane overwrites the row it read)")
-    A("        }")
+    A(f"        for (int j = 0; j < {E}; j++) sw{s}[j] = y[j];      // row of Ck (each lane overwrites the row it read; idle lanes: the trash row)")
     A("      }")
   A("      rn::wave_lds_sync();")
-  A("      RN_RTS_STAMP(6);")
+  A("      RN_RTS_STAMP(7);")
   A("      // ---- H. T = Ck D, one row slot at a time: coefficients = the lane's row of Ck, operands = rows of D from their owners ----")
   A(f"      {rows_decl('t')}")
   A("      double " + ", ".join(f"dx{s}" for s in S) + ";      // state, second half: Ck delta (one E-term dot per row), formed while the row of Ck is in registers anyway")
@@ -363,13 +424,19 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
     A(f"        double ck[{E}];")
     A("#pragma unroll")
     A(f"        for (int j = 0; j < {E}; j++) ck[j] = sI[rq{s} * {E} + j];")
-    A("        {")
-    A(f"          double de[{E}];")
-    A("#pragma unroll")
-    A(f"          for (int j = 0; j < {E}; j++) de[j] = sdv[j];")
-    A(f"          dx{s} = (" + " + ".join(f"ck[{j}]*de[{j}]" for j in range(0, E, 2)) + ") + (" + (" + ".join(f"ck[{j}]*de[{j}]" for j in range(1, E, 2)) or "0.0") + ");")
-    A(f"          rn::pin(dx{s});")
-    A("        }")
+    A(f"        double dxa{s} = 0.0, dxb{s} = 0.0;")
+    for c0_ in range(0, E, 8):      # (delta in pieces of eight: all E at once are 2 E registers next to three row sets)
+      c1_ = min(E, c0_ + 8)
+      A("        {")
+      A(f"          double de[{c1_ - c0_}];")
+      A("#pragma unroll")
+      A(f"          for (int j = {c0_}; j < {c1_}; j++) de[j - {c0_}] = sdv[j];")
+      for j in range(c0_, c1_):
+        A(f"          dx{'ab'[j & 1]}{s} = fma(ck[{j}], de[{j - c0_}], dx{'ab'[j & 1]}{s});")
+      A(f"          rn::pin(dxa{s}); rn::pin(dxb{s});")
+      A("        }")
+    A(f"        dx{s} = dxa{s} + dxb{s};")
+    A(f"        rn::pin(dx{s});")
     A("        rn::wave_lds_sync();      // (compiler fence: delta is re-read by the next slot instead of staying in 2 E registers under this slot's product)")
     A("#pragma unroll")
     A(f"        for (int j = 0; j < {E}; j++) t{s}[j] = 0.0;")
@@ -380,7 +447,7 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
         else:            # D[kk][j] above the block triangle of row kk: D[j][kk] from row j's lane
           A(f"        RN4_FMAC(t{s}[{j}], ps{slot_of(j)}[{kk}], ck[{kk}], {lane_of(j)});")
     A("      }")
-  A("      RN_RTS_STAMP(7);")
+  A("      RN_RTS_STAMP(8);")
   A("      // ---- I. U = T Ck^T: operands = rows of Ck from their owners' registers.  U is symmetric (D is, up to rounding): a row slot")
   A("      // forms the columns up to its last row, the upper-right block is mirrored inside the image ----")
   A(f"      {rows_decl('ck')}")
@@ -389,23 +456,48 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
     A(f"      for (int j = 0; j < {E}; j++) ck{s}[j] = sI[rq{s} * {E} + j];")
   A("      rn::wave_lds_sync();      // every lane has read delta and has its rows of Ck: the buffer takes Ck delta, the image U")
   for s in S:
-    A(f"      if (ok{s}) sdv[rr{s}] = dx{s};")
-  for s in reversed(S):
-    ncol = last_row(s) + 1
+    A(f"      *(ok{s} ? sdv + rq{s} : strash) = dx{s};")
+  A("      typedef double rts4_d2 __attribute__((ext_vector_type(2)));")
+  A("      int le = lb;")
+  A('      asm volatile("" : "+v"(le));')
+  A(f"      const rts4_d2* __restrict__ in2 = reinterpret_cast<const rts4_d2*>(Pf + (k * n + base) * {EE});")
+  A(f"      rts4_d2* __restrict__ out2 = reinterpret_cast<rts4_d2*>(Ps + (k * n + base) * {EE});")
+  A(f"      const int nv = cnt * {EE // 2};")
+  A(f"      rts4_d2 v[{IT}];")
+  A(f"      double xnext[{XT}];      // filtered state of the next (older) step")
+  # U in column blocks of one slot's rows each, ordered so that row sets die early: a block of columns [RS q, RS q + RS) broadcasts only
+  # slot q's rows of Ck.  Last slot first, its own (diagonal) block first: after it slot R - 1's rows of Ck are dead; the last block of
+  # all is slot 0's, under which the tile's filtered records for the final read-add-write are requested (below).
+  blocks = [(s_, q) for s_ in reversed(S) for q in reversed(range(s_ + 1))]
+  for bi, (s, q) in enumerate(blocks):
+    c0, c1 = RS * q, min(E, RS * q + RS)
+    if bi == len(blocks) - 1:
+      # The tile's filtered records for the final read-add-write are requested HERE, in front of the last product block: the other
+      # slots' rows of T and of Ck are dead, their registers take the loads, and the HBM / Infinity Cache round trip passes under the
+      # block's FMAs instead of being waited for after them.
+      A(f"      if (cnt == {FPW}) {{")
+      A("#pragma unroll")
+      A(f"        for (int it = 0; it < {IT}; it++) {{ const int idx = le + 64 * it; v[it] = in2[(it < {ITF} || idx < {FPW * EE // 2}) ? idx : {FPW * EE // 2 - 1}]; }}")
+      A("      } else {")
+      A("#pragma unroll")
+      A(f"        for (int it = 0; it < {IT}; it++) {{ const int idx = le + 64 * it; v[it] = in2[idx < nv ? idx : nv - 1]; }}")
+      A("      }")
+      A("#pragma unroll")
+      A(f"      for (int it = 0; it < {XT}; it++) {{ const int i = le + 64 * it; xnext[it] = xf[((k > 0 ? k - 1 : 0) * n + base) * {D} + (i < cnt * {D} ? i : 0)]; }}")
+      A("      __builtin_amdgcn_sched_barrier(0);")
     A("      {")
-    A(f"        double u[{ncol}];")
+    A(f"        double u[{c1 - c0}];")
     A("#pragma unroll")
-    A(f"        for (int j = 0; j < {ncol}; j++) u[j] = 0.0;")
+    A(f"        for (int j = 0; j < {c1 - c0}; j++) u[j] = 0.0;")
     for kk in range(E):
-      for j in range(ncol):
-        A(f"        RN4_FMAC(u[{j}], ck{slot_of(j)}[{kk}], t{s}[{kk}], {lane_of(j)});")
-    A(f"        if (ok{s}) {{")
+      for j in range(c0, c1):
+        A(f"        RN4_FMAC(u[{j - c0}], ck{q}[{kk}], t{s}[{kk}], {lane_of(j)});")
     A("#pragma unroll")
-    A(f"          for (int j = 0; j < {ncol}; j++) sI[rq{s} * {E} + j] = u[j];")
-    A("        }")
+    A(f"        for (int j = 0; j < {c1 - c0}; j++) sw{s}[{c0} + j] = u[j];")
     A("      }")
+    A("      __builtin_amdgcn_sched_barrier(0);")
   A("      rn::wave_lds_sync();")
-  A("      RN_RTS_STAMP(8);")
+  A("      RN_RTS_STAMP(9);")
   A("      // ---- J. Pk_n = Pk_k + U leaves: one coalesced read-add-write over the tile's records; the sum also returns to the image,")
   A("      // from which every lane takes its rows of the smoothed covariance for the next (older) step ----")
   if any(last_row(s) + 1 < E for s in S):
@@ -413,40 +505,41 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
     for s in S:
       ncol = last_row(s) + 1
       if ncol < E:
-        A(f"        if (ok{s}) {{")
+        A("        {")
         A(f"          double m_[{E - ncol}];")
         A("#pragma unroll")
         A(f"          for (int j = {ncol}; j < {E}; j++) m_[j - {ncol}] = sI[j * {E} + rq{s}];")
         A("#pragma unroll")
-        A(f"          for (int j = {ncol}; j < {E}; j++) sI[rq{s} * {E} + j] = m_[j - {ncol}];")
+        A(f"          for (int j = {ncol}; j < {E}; j++) sw{s}[j] = m_[j - {ncol}];")
         A("        }")
     A("      }")
     A("      rn::wave_lds_sync();")
-  IT = -(-(FPW * EE // 2) // 64)
-  A("      {")
-  A("        typedef double rts4_d2 __attribute__((ext_vector_type(2)));")
-  A("        int le = lane;")
-  A('        asm volatile("" : "+v"(le));')
-  A(f"        const rts4_d2* __restrict__ in2 = reinterpret_cast<const rts4_d2*>(Pf + (k * n + base) * {EE});")
-  A(f"        rts4_d2* __restrict__ out2 = reinterpret_cast<rts4_d2*>(Ps + (k * n + base) * {EE});")
-  A(f"        const int nv = cnt * {EE // 2};")
-  A(f"        rts4_d2 v[{IT}];")
+  A("      if (lead) {      // state update, last part: one lane per filter, while the loads above are in flight")
+  A(f"        double xa[{D}], xnew[{D}], delta[{E}];")
   A("#pragma unroll")
-  A(f"        for (int it = 0; it < {IT}; it++) {{ const int idx = le + 64 * it; v[it] = in2[idx < nv ? idx : nv - 1]; }}")
-  A("        if (k > 0) {")
+  A(f"        for (int i = 0; i < {D}; i++) xa[i] = sxk[i];")
   A("#pragma unroll")
-  A(f"          for (int it = 0; it < {XT}; it++) {{ const int i = lane + 64 * it; xnext[it] = xf[((k - 1) * n + base) * {D} + (i < cnt * {D} ? i : 0)]; }}")
+  A(f"        for (int i = 0; i < {E}; i++) delta[i] = sdv[i];")
+  A("        err_fun(xa, delta, xnew);")
+  A("#pragma unroll")
+  A(f"        for (int i = 0; i < {D}; i++) sxn[i] = xnew[i];       // xk_n: becomes xk1_n of the next (older) step")
+  A("      }")
+  A("      dtc = k > 0 ? ts[k] - ts[k - 1] : 0.0;")
+  A("      rn::wave_lds_sync();      // the lead lanes have read xk_k: the buffer takes the next step's")
+  A("#pragma unroll")
+  A(f"      for (int it = 0; it < {XT}; it++) {{ const int i = le + 64 * it; if (i < cnt * {D}) s_xk[i] = xnext[it]; }}")
+  A(f"      if (cnt == {FPW}) {{      // full tile: the first {ITF} passes of the wavefront are whole")
+  A("#pragma unroll")
+  A(f"        for (int it = 0; it < {IT}; it++) {{")
+  A("          const int idx = le + 64 * it;")
+  A(f"          if (it < {ITF} || idx < {FPW * EE // 2}) {{")
+  A("            rts4_d2* im = reinterpret_cast<rts4_d2*>(s_I + 2 * idx);")
+  A("            const rts4_d2 w_ = v[it] + *im;")
+  A("            out2[idx] = w_;")
+  A("            *im = w_;")
+  A("          }")
   A("        }")
-  A("        if (lead) {      // state update, last part: one lane per filter, while the loads above are in flight")
-  A(f"          double xa[{D}], xnew[{D}], delta[{E}];")
-  A("#pragma unroll")
-  A(f"          for (int i = 0; i < {D}; i++) xa[i] = sxk[i];")
-  A("#pragma unroll")
-  A(f"          for (int i = 0; i < {E}; i++) delta[i] = sdv[i];")
-  A("          err_fun(xa, delta, xnew);")
-  A("#pragma unroll")
-  A(f"          for (int i = 0; i < {D}; i++) sxn[i] = xnew[i];       // xk_n: becomes xk1_n of the next (older) step")
-  A("        }")
+  A("      } else {")
   A("#pragma unroll")
   A(f"        for (int it = 0; it < {IT}; it++) {{")
   A("          const int idx = le + 64 * it;")
@@ -462,11 +555,14 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   A('      asm volatile("" : ' + ", ".join(f'"+v"(rq{s})' for s in S) + ");      // (fresh addresses: those of the step's first row read are not worth registers across the step)")
   lower_rows("ps", full=False)
   A("      rn::wave_lds_sync();      // every lane has its rows: the image is free for the next step's burst")
-  A("      RN_RTS_STAMP(9);")
   A("      RN_RTS_STAMP(10);")
   A("    }")
   A("    // ---- the oldest smoothed state goes out un-normalised (ekf_sym.py:665-667 never reaches it); its covariance left above ----")
-  A(f"    for (int i = lane; i < cnt * {D}; i += 64) xs[base * {D} + i] = s_xn[i];")
+  A("    {")
+  A("      int lz = lane;")
+  A('      asm volatile("" : "+v"(lz));')
+  A(f"      for (int i = lz; i < cnt * {D}; i += 64) xs[base * {D} + i] = s_xn[i];")
+  A("    }")
   A("    rn::wave_lds_sync();")
   A("  }")
   A("}")

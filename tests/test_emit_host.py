@@ -931,7 +931,167 @@ def test_lane_group_fused_run_kernel_on_the_host(tmp_path, name):
   assert np.array_equal(tP2[1], tP2[0]) == (dts[1] == 0.0)
 
 
-# Not emulated here: the smoother kernel (emit_rts3).  A wavefront executes in lockstep, so a lane may overwrite LDS that another
+# ---- register-broadcast smoother on the host (emit_rts4.kernel: k_rts4) ----------------------------------------------------------------
+# The kernel's cross-lane traffic is (a) LDS, ordered by rn::wave_lds_sync() -- written so that every read of another lane's data has a
+# fence between it and the write before AND the overwrite after it, which is what threads and barriers need --, and (b) the three
+# row_newbcast macros (v_fmac_f64_dpp / v_mov_b64_dpp on the device), restated here as an exchange through a 64-entry array between two
+# barriers: lane L of every 16-lane row feeds the row.  Everything else is the generated text.
+
+_RTS4_HOST = r"""
+static double g_bc[64];
+inline double host_row_bcast(double v, int L) {
+  g_bc[threadIdx.x] = v;
+  pthread_barrier_wait(&g_bar);
+  const double r = g_bc[(threadIdx.x & ~15) + L];
+  pthread_barrier_wait(&g_bar);
+  return r;
+}
+#define RN4_FMAC(acc, src, coef, L)  (acc) = std::fma(host_row_bcast((src), (L)), (coef), (acc))
+#define RN4_FNMAC(acc, src, coef, L) (acc) = std::fma(-host_row_bcast((src), (L)), (coef), (acc))
+#define RN4_BC(dst, src, L)          (dst) = host_row_bcast((src), (L))
+#define RN_RTS_STAMP(i) do { } while (0)
+#define __builtin_amdgcn_s_setprio(x)
+using std::max; using std::min; using std::fma;
+typedef void* lds_void_ptr_host;
+inline void __builtin_amdgcn_global_load_lds(const void* g, void* lds_base, int bytes, int, int) {      // one 16-byte piece per lane: base + lane * 16
+  std::memcpy(static_cast<char*>(lds_base) + 16 * threadIdx.x, g, bytes);
+}
+"""
+
+
+def _rts4_host_library(tmp_path, spec):
+  from rednose_amd.codegen import emit_rts4, tuning
+  from rednose_amd.codegen.emit_common import routine_device_function
+  hdr = open(HDR, encoding="utf-8").read()
+  helpers = "\n".join(_function_text(hdr, f) for f in ("rsqrt_pow", "sincos_fast", "normalize_quat"))
+  with tuning.using_model(spec):
+    assert emit_rts4.applicable(spec)
+    text = emit_rts4.kernel(spec)
+  routines = "\n".join(routine_device_function(r)[0] for r in spec.routines() if r.name in ("err_fun", "inv_err_fun"))
+  text = re.sub(r'asm volatile\("" : ((?:"\+v"\(\w+\)(?:, )?)+)\);', ";", text)
+  text = text.replace("__builtin_amdgcn_sched_barrier", "rn::sched_barrier_")
+  text = text.replace("__attribute__((ext_vector_type(2)))", "__attribute__((vector_size(16)))")
+  text = text.replace("(const __attribute__((address_space(1))) void*)", "(const void*)")
+  text = re.sub(r"(__device__ \w+ (?:void|int) scal_\w+\(.*?\n}\n)", lambda m: m.group(1).replace("rn::wave_lds_sync();", ";"), text, flags=re.S)
+  entry = """
+extern "C" __attribute__((visibility("default"))) void host_rts4(int grid, const double* xf, const double* Pf, const double* ts, int64_t T, const double* Q, int64_t n,
+    int norm_quats, double* xs, double* Ps, const double* xl, const double* Pl) {
+  run_grid(grid, [&] { k_rts4(xf, Pf, ts, T, Q, n, norm_quats, xs, Ps, xl, Pl); });
+}"""
+  prelude = _KERNEL_PRELUDE.replace("inline void pin(double&) {}", "inline void pin(double&) {}\n" + _WIDE_COPIES + "inline void* lds_offset_ptr(double* p) { return p; }\n")
+  prelude = prelude.replace("namespace rn {", _WAVE_VOTES + _RTS4_HOST + "namespace rn {", 1)
+  src = "\n".join([prelude, helpers, "}  // namespace rn", routines, text, _RUN_GRID, entry])
+  cpp, lib = tmp_path / f"{spec.name}_rts4_host.cpp", tmp_path / f"lib{spec.name}_rts4_host.so"
+  cpp.write_text(src, encoding="utf-8")
+  res = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fno-gnu-unique", "-fvisibility=hidden", "-Wno-unknown-pragmas", "-Wno-attributes",
+                        "-ffp-contract=off", str(cpp), "-o", str(lib)], capture_output=True, text=True)
+  assert res.returncode == 0, res.stderr[-4000:]
+  fn = ctypes.CDLL(str(lib)).host_rts4
+  dp = ctypes.POINTER(ctypes.c_double)
+  fn.argtypes = [ctypes.c_int, dp, dp, dp, ctypes.c_int64, dp, ctypes.c_int64, ctypes.c_int, dp, dp, dp, dp]
+  return fn
+
+
+@pytest.mark.timeout(900, method="thread")
+def test_register_broadcast_smoother_on_the_host_live(tmp_path):
+  """k_rts4 of the live model, whole kernel, against the reference's own rts_smooth (tests/golden/live_rts.npz, produced by running the
+  reference class): one full tile and a ragged one, quaternion renormalisation, the recursion started from the recomputed predicted pair."""
+  from conftest import golden
+  from rednose_amd.codegen.spec import build_spec
+  M, mdl, kw, _ = _wide_model("live")
+  spec = build_spec(**dict(mdl), **kw)
+  fn = _rts4_host_library(tmp_path, spec)
+  g = golden("live_rts.npz")
+  # the LAST eight estimates of the golden trajectory: a backward recursion's values there depend on nothing older (62 emulated steps take minutes)
+  T0, n = len(g["t"]) - 8, 6
+  T = 8
+  xf = np.ascontiguousarray(np.tile(g["xk_k"][T0:, None, :], (1, n, 1)))
+  Pf = np.ascontiguousarray(np.tile(g["Pk_k"][T0:, None], (1, n, 1, 1)))
+  # the contract of batch_rts: the LOWER triangle of every covariance is read.  Filter 1 gets garbage above the diagonal.
+  iu = np.triu_indices(22, 1)
+  Pf[:, 1, iu[0], iu[1]] = 1e30
+  xs, Ps = np.full((T + 2, n, 23), 7.0), np.full((T + 2, n, 22, 22), 7.0)
+  ts = np.ascontiguousarray(g["t"][T0:], dtype=np.float64)
+  Q = np.ascontiguousarray(M.Q, dtype=np.float64)
+  dp = ctypes.POINTER(ctypes.c_double)
+  ptr = lambda a: a.ctypes.data_as(dp)      # noqa: E731
+  fn(1, ptr(xf), ptr(Pf), ptr(ts), T, ptr(Q), n, 3, ptr(xs[1:]), ptr(Ps[1:]), None, None)
+  assert (xs[0] == 7.0).all() and (xs[T + 1] == 7.0).all() and (Ps[0] == 7.0).all() and (Ps[T + 1] == 7.0).all()      # guard rows
+  X, P = xs[1:T + 1], Ps[1:T + 1]
+  sel = [(i, int(k) - T0) for i, k in enumerate(g["Ps_smooth_idx"]) if int(k) >= T0]
+  assert len(sel) >= 2
+  for j in range(n):
+    assert_close(X[:, j], g["xs_smooth"][T0:], rtol=1e-8, floor=1e-8, what=f"smoothed live states, filter {j}")
+    if j != 1:
+      assert_close(np.stack([P[k, j] for _, k in sel]).reshape(len(sel), -1), np.stack([g["Ps_smooth"][i] for i, _ in sel]).reshape(len(sel), -1),
+                   rtol=1e-8, floor=1e-8, what=f"smoothed live covs, filter {j}")
+  # filter 1: what it wrote below the diagonal is what the others wrote (its garbage was never read), above it the garbage plus the correction
+  il = np.tril_indices(22)
+  assert_close(P[:T - 1, 1][:, il[0], il[1]], P[:T - 1, 0][:, il[0], il[1]], rtol=1e-12, floor=1e-14, what="lower triangle of the filter with garbage above the diagonal")
+  qn = np.linalg.norm(X[1:, 0, 3:7], axis=1)
+  assert np.abs(qn - 1).max() < 1e-14
+
+
+@pytest.mark.timeout(900, method="thread")
+@pytest.mark.parametrize("name", ["rand8", "randz10"])
+def test_register_broadcast_smoother_on_the_host_one_row_per_lane(tmp_path, name):
+  """k_rts4 with ONE row slot (8 / 10 error states): a numpy restatement of ekf_sym.py:651-690 on the oracle's f / F, every filter and
+  step; the newest pair passed in (x_last, P_last) and recomputed; in place (Ps == Pf)."""
+  from oracle_lib import OracleLib
+  from rednose_amd.codegen.spec import build_spec
+  import examples.random_kf as R
+  M = getattr(R, "Random8Kalman" if name == "rand8" else "RandomWideObs10Kalman")
+  spec = build_spec(**M.model())
+  fn = _rts4_host_library(tmp_path, spec)
+  o = OracleLib(M.name)
+  D = spec.dim_x
+  rng = np.random.default_rng(D)
+  n, T = 7, 6
+  X = M.initial_x[None, None] + rng.normal(size=(T, n, D)) * 0.3
+  A = rng.normal(size=(T, n, D, D)) * 0.2
+  P = np.diag(M.initial_P_diag)[None, None] + A @ A.transpose(0, 1, 3, 2)
+  ts = np.cumsum(rng.uniform(0.005, 0.03, size=T))
+  Q = np.ascontiguousarray(M.Q, dtype=np.float64)
+  dp = ctypes.POINTER(ctypes.c_double)
+  ptr = lambda a: a.ctypes.data_as(dp)      # noqa: E731
+
+  def reference(xl, Pl):
+    xs, Ps = X.copy(), P.copy()
+    for j in range(n):
+      x1n = P1n = None
+      for k in range(T - 2, -1, -1):
+        dt = ts[k + 1] - ts[k]
+        x1k = np.zeros(D); Fk = np.zeros(D * D)
+        o.call("f_fun", X[k, j].copy(), float(dt), x1k); o.call("F_fun", X[k, j].copy(), float(dt), Fk)
+        Fk = Fk.reshape(D, D)
+        Pkk = np.tril(P[k, j]) + np.tril(P[k, j], -1).T
+        P1k = Fk @ Pkk @ Fk.T + dt * Q
+        if k == T - 2:
+          x1n, P1n = (x1k.copy(), P1k.copy()) if xl is None else (xl[j].copy(), np.tril(Pl[j]) + np.tril(Pl[j], -1).T)
+          xs[T - 1, j], Ps[T - 1, j] = x1n, (P1k if Pl is None else Pl[j])
+        Ck = np.linalg.solve(P1k, Fk @ Pkk.T).T
+        xs[k, j] = X[k, j] + Ck @ (x1n - x1k)
+        Ps[k, j] = P[k, j] + Ck @ (P1n - P1k) @ Ck.T
+        x1n, P1n = xs[k, j].copy(), np.tril(Ps[k, j]) + np.tril(Ps[k, j], -1).T
+    return xs, Ps
+  xl = X[T - 1] + rng.normal(size=(n, D)) * 0.01
+  Bl = rng.normal(size=(n, D, D)) * 0.1
+  Pl = P[T - 1] + Bl @ Bl.transpose(0, 2, 1)
+  for tag, a_xl, a_Pl in (("recomputed newest pair", None, None), ("newest pair passed in", xl, Pl)):
+    xr, Pr = reference(a_xl, a_Pl)
+    xs, Ps = np.full((T + 2, n, D), 7.0), np.full((T + 2, n, D, D), 7.0)
+    fn(2, ptr(np.ascontiguousarray(X)), ptr(np.ascontiguousarray(P)), ptr(ts), T, ptr(Q), n, 0, ptr(xs[1:]), ptr(Ps[1:]),
+       None if a_xl is None else ptr(np.ascontiguousarray(a_xl)), None if a_Pl is None else ptr(np.ascontiguousarray(a_Pl)))
+    assert (xs[0] == 7.0).all() and (xs[T + 1] == 7.0).all() and (Ps[0] == 7.0).all() and (Ps[T + 1] == 7.0).all()
+    assert_close(xs[1:T + 1].reshape(T * n, -1), xr.reshape(T * n, -1), rtol=1e-9, floor=1e-11, what=f"{name} smoothed x ({tag})")
+    assert_close(Ps[1:T + 1].reshape(T * n, -1), Pr.reshape(T * n, -1), rtol=1e-8, floor=1e-10, what=f"{name} smoothed P ({tag})")
+  # in place: outputs aliased onto the inputs give the same bits
+  Xi, Pi = np.ascontiguousarray(X.copy()), np.ascontiguousarray(P.copy())
+  fn(1, ptr(Xi), ptr(Pi), ptr(ts), T, ptr(Q), n, 0, ptr(Xi), ptr(Pi), ptr(np.ascontiguousarray(xl)), ptr(np.ascontiguousarray(Pl)))
+  assert np.array_equal(Xi, xs[1:T + 1]) and np.array_equal(Pi, Ps[1:T + 1])
+
+
+# Not emulated here: the smoother kernel in the fused run's layout (emit_rts3, the fallback of k_rts4).  A wavefront executes in lockstep, so a lane may overwrite LDS that another
 # lane has read earlier in program order without any fence in between (only write -> read across lanes needs one); k_rts3 leans on
 # that inside its scheduling regions.  Threads and barriers at rn::wave_lds_sync() do not reproduce it: a first attempt matched the
 # reference's recursion exactly for the newest two estimates and raced on the older ones.  The fused-run test above

@@ -45,7 +45,7 @@ def spec_of(name, cache="/tmp/rts4_dev"):
 
 def unit_text(spec):
   D, E, M = spec.dim_x, spec.dim_err, spec.dim_main_err
-  src = ['#include "ekf_hip_rt.h"', '#include "ekf_hip_rts.h"', "", "namespace {",
+  src = (["#define RN_RTS_TL 1"] if os.environ.get("RTS4_TL") else []) + ['#include "ekf_hip_rt.h"', '#include "ekf_hip_rts.h"', "", "namespace {",
          f"constexpr int DIM = {D};", f"constexpr int EDIM = {E};", f"constexpr int MEDIM = {M};", ""]
   for var in spec.global_vars:
     src.append(f"__device__ double {var.name} = 0.0;")
@@ -59,19 +59,25 @@ def unit_text(spec):
 {emit_rts4.launch(spec)}
   return (int)hipGetLastError();
 }}""")
+  if os.environ.get("RTS4_TL"):
+    src.append("""extern "C" int rts4_dev_timeline(unsigned long long *out) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rn::g_rts_tl), sizeof(unsigned long long) * 256 * 16, 0, hipMemcpyDeviceToHost);
+}""")
   return "\n".join(src)
 
 
 def main():
   name = sys.argv[1] if len(sys.argv) > 1 else "live_maha"
   out = sys.argv[2] if len(sys.argv) > 2 else "/tmp/rts4_dev"
+  os.makedirs(out, exist_ok=True)
   spec = spec_of(name)
   text = unit_text(spec)
   fn = os.path.join(out, f"{name}_rts4.hip")
   with open(fn, "w", encoding="utf-8") as f:
     f.write(text)
   t0 = time.time()
-  cmd = [rb.find_hipcc()] + rb.HIPCC_FLAGS + os.environ.get("RN_HIPCC_FLAGS", "").split() + ["-Rpass-analysis=kernel-resource-usage", "-I", TEMPLATE_DIR, "-x", "hip", fn, "-o",
+  cmd = [rb.find_hipcc()] + rb.HIPCC_FLAGS + ([] if os.environ.get("RTS4_NO_MODEL_FLAGS") else rb.model_flags(text)) + os.environ.get("RN_HIPCC_FLAGS", "").split() + ["-Rpass-analysis=kernel-resource-usage", "-I", TEMPLATE_DIR, "-x", "hip", fn, "-o",
                                                   os.path.join(out, f"lib{name}_rts4.so")]
   if os.environ.get("RTS4_ASM"):
     cmd = [c for c in cmd if c not in ("-shared",)] + ["-S", "--cuda-device-only"]
