@@ -46,6 +46,7 @@ STEADY_GROUP = 50              # launches per group of the steady-state warm-up 
 STEADY_MIN_S = 0.1             # ... its minimum duration (clocks keep rising for milliseconds after the first launches)
 STEADY_CAP_S = 0.5             # ... and its time limit
 MEDIAN_GROUP = 10              # fewest launches between two markers of the timed region (launch-duration distribution)
+COLD_LAUNCHES = 20             # launches of the cold sample (run_model): the first ones after >= 100 ms of idle
 FP64_VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9     # 256 CUs x 4 SIMDs x 16 fp64 lanes per clock x 2.4 GHz = 39.3 T lane-instructions/s
 #                                               (78.6 TFLOP/s vector fp64 counts an FMA as two)
 
@@ -324,6 +325,16 @@ def run_model(torch, dist, model, n, K, W, dev, rank, world, only_kind=None):
     return a, b
 
   x_keep, P_keep = f.x.clone(), f.P.clone()
+  # The COLD figure, reported next to the steady one (top-level "cold_launch_us"): the mean of the first COLD_LAUNCHES launches after the
+  # device has idled >= 100 ms -- what a caller that steps a batch once in a while sees (empty queue, clocks down): host -> doorbell ->
+  # command processor -> dispatch is exposed until the host is ahead (profiles/r4_short_run_per_launch.txt: 35.8 / 19.7 / 18.4 us, then flat).
+  torch.cuda.synchronize()
+  time.sleep(0.12)
+  a_, b_ = untimed_group(0, COLD_LAUNCHES)
+  torch.cuda.synchronize()
+  cold_us = a_.elapsed_time(b_) * 1e3 / COLD_LAUNCHES
+  f.x.copy_(x_keep)
+  f.P.copy_(P_keep)
   if os.environ.get("RN_BENCH_NO_STEADY") != "1":
     t_warm = time.perf_counter()
     prev = None
@@ -373,7 +384,7 @@ def run_model(torch, dist, model, n, K, W, dev, rank, world, only_kind=None):
   zdims = [f.zdims[sched[i][0]] for i in range(W, W + K)]
   bytes_per_step = 8.0 * (2 * (D + E * E) + 2 * float(np.mean(zdims)))
   return dict(M=M, D=D, E=E, Z=float(np.mean(zdims)), wall=wall, dev_ms=dev_ms, bytes_per_step=bytes_per_step, gen=gen,
-              kinds=sorted(set(s[0] for s in sched[W:W + K])), steady=steady,
+              kinds=sorted(set(s[0] for s in sched[W:W + K])), steady=steady, cold_launch_us=cold_us,
               launch_us_median=float(np.median(groups)) if groups else None, launch_us_groups=len(groups),
               group_us=[round(g_, 3) for g_ in groups] if os.environ.get("RN_BENCH_MARK_EVERY") else None)
 
@@ -701,6 +712,11 @@ def main():
       "n_gpus": dist.get_world_size() if use_dist else 1,        # the ranks that actually ran (the process group's own count)
       "steps": K,
       "warmup": W,
+      # launches of the same entry point that ran BEFORE the W warm-up steps and are part of neither W nor K (the cold sample and the
+      # steady-state groups: steady_state_warmup below), and the mean duration of a launch on the idle device -- top-level, so that a
+      # reader of the line sees what "warmup" does not say
+      "untimed_launches": int(r["steady"]["launches"]) + COLD_LAUNCHES,
+      "cold_launch_us": round(r["cold_launch_us"], 3),
       "ms_per_step": wall_max * 1e3 / K,
       "higher_is_better": True,
       "scaling": scaling,
@@ -708,8 +724,8 @@ def main():
       "dtype": "f64",
       "data": "synthetic",
       "config": {"workload": f"{M.name} (D={D}, E={E}, Z={r['Z']:g}) fused predict+update, step-granular (state round-trips HBM each step), "
-                             f"batch {n} on rank 0, shared R, scalar dt; device warmed to steady state before the timed region "
-                             f"({r['steady']['launches']} extra untimed launches, <= {STEADY_CAP_S} s, see steady_state_warmup)", "batch_per_gpu": n,
+                             f"batch {n} on rank 0, shared R, scalar dt", "batch_per_gpu": n,
+                 "steady_state": f"device warmed to steady state before the timed region: {r['steady']['launches']} extra untimed launches (<= {STEADY_CAP_S} s), see untimed_launches / cold_launch_us / steady_state_warmup",
                  "global_batch": int(round(steps_total / K)), "parallelism": f"batch-sharded x{world}, no data-path collective"},
       "roofline": hbm_roofline(r["bytes_per_step"] * n, launch_s, kern, traffic=measured_traffic(f"{M.name}_b{n}", M.name, r["gen"]),
                                launch_us_median=r["launch_us_median"], launch_us_median_groups=r["launch_us_groups"]),

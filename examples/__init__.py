@@ -65,3 +65,20 @@ def ensure_generated(names=None, folder=GENERATED_DIR):
   for n in (names or table.keys()):
     table[n](folder)
   return folder
+
+
+EXACT_DIR = os.path.join(GENERATED_DIR, "exact")      # reference builds with IEEE division / sqrt and the library's sin / cos (tuning knob exact_math)
+
+
+def ensure_exact(names=("live",)):
+  """The named filters built with RN_TUNE=exact_math=1 under generated/exact/ (what the fast elementary functions are measured
+  against: tests/test_gpu_live.py).  Part of __graft_entry__.build(), so the GPU box finds them prebuilt."""
+  old = os.environ.get("RN_TUNE")
+  os.environ["RN_TUNE"] = ",".join(v for v in (old, "exact_math=1") if v)
+  try:
+    return ensure_generated(list(names), folder=EXACT_DIR)
+  finally:
+    if old is None:
+      del os.environ["RN_TUNE"]
+    else:
+      os.environ["RN_TUNE"] = old

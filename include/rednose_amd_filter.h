@@ -34,11 +34,17 @@
  *     result is the reference's on THAT matrix, to rounding.  Against the reference run on the asymmetric matrix itself the
  *     difference is first order in (P - P^T) / 2, like any perturbation of P0 of that size.  The final P and the covariance
  *     trace come back symmetric to rounding (lane-per-filter models: exactly).
+ *     WHICH MODE IS THE REFERENCE'S: the step-granular one.  A caller that needs the reference's result for a T-step schedule on a
+ *     covariance with a skew part walks the schedule with batch_predict_update_k -- BatchedEKF.run(..., exact=True) does exactly that
+ *     (trace, flags and residuals included; tests/test_gpu_asymmetric.py::test_run_exact_is_the_reference_on_the_asymmetric_matrix_itself:
+ *     1e-10 against the oracle on the asymmetric matrix); batch_run is the fast path for covariances that are symmetric up to
+ *     rounding, which is every covariance a filter produces itself.
  *   - batch_rts factors the predicted covariance by Cholesky and keeps Pk1_n - Pk1_k as a packed triangle.  It reads the
  *     LOWER triangle (diagonal included) of every covariance it is given -- Pf[k], P_last -- mirrored, for the gain Ck and
  *     the correction Ck (Pk1_n - Pk1_k) Ck^T; the filtered covariance itself enters the sum as given:
  *     Ps[k] = Pf[k] + correction.  On a trace written by batch_run (symmetric to rounding) that is the reference's
- *     rts_smooth to rounding.
+ *     rts_smooth to rounding.  (The reference's own backward step is triangle-dependent on such input too: its gain comes from
+ *     scipy.linalg.solve(..., assume_a='pos'), i.e. LAPACK posv on ONE triangle of Pk1_k, ekf_sym.py:677.)
  *
  * Elementary functions of the model's expressions.  sqrt, reciprocals and negative half-integer powers are evaluated from the
  * hardware seeds with Newton steps (within an ulp or two of libm; IEEE answers kept at 0 and infinity).  sin / cos of one

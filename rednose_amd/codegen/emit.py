@@ -133,6 +133,7 @@ def _emit(spec):
   src = [f"// GENERATED by rednose_amd.helpers.ekf_sym.gen_code for filter '{name}' -- do not edit.",
          f"// DIM={D} EDIM={E} MEDIM={M} kinds={[k.kind for k in spec.kinds]} family={fam}",
          *(["#define RN_RTS_TL 1"] if (fam == "wide" and tuning.current().wide_timeline) else []),
+         *(["#define RN_EXACT_MATH 1"] if tuning.current().exact_math else []),
          '#include "ekf_hip_rt.h"', '#include "ekf_hip_rts.h"', "", "namespace {",
          f"constexpr int DIM = {D};", f"constexpr int EDIM = {E};", f"constexpr int MEDIM = {M};", ""]
 

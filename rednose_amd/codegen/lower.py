@@ -36,6 +36,11 @@ SINCOS_FAST = r"""namespace rn {
 // a limit of this engine, README.md).  An inlined library fallback for that
 // range was built and costs 25-35 registers in every kernel that evaluates a model with trigonometric terms (profiles/tuning_notes.md).
 __device__ __forceinline__ void sincos_fast(const double a_in, double& s, double& c) {
+#ifdef RN_EXACT_MATH      // tuning knob exact_math=1: the library's routines (full range; what the fast pair is measured against)
+  s = sin(a_in);
+  c = cos(a_in);
+  return;
+#endif
   const double a = (fabs(a_in) <= 35184372088832.0) ? a_in : __builtin_nan("");
   const double k = rint(a * 6.36619772367581382433e-01);
   double r = fma(-k, 1.5707963267948966e+00, a);

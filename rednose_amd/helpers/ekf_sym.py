@@ -730,7 +730,7 @@ class BatchedEKF:
     if replay is not None:
       fl_new = self.flags.clone()
       self._ring_replay(replay)
-      self.flags = fl_new
+      self.flags.copy_(fl_new)        # (into the SAME buffer: bind_step() captured its address)
     if bool(dropped.any()):
       self.flags |= dropped.to(torch.uint8) * 32
     if keep_estimate:
@@ -839,7 +839,7 @@ class BatchedEKF:
         dt = torch.where(act, tt - self.filter_time, torch.zeros_like(tt))
         fl = self.flags.clone()
         self._masked_step(kind, zin, Rd, 1, ea, dt, act.to(torch.uint8))
-        self.flags = torch.where(act, self.flags, fl)              # flags of the filters this replay did not touch stay
+        self.flags.copy_(torch.where(act, self.flags, fl))         # flags of the filters this replay did not touch stay (same buffer: bind_step() holds its address)
         self.filter_time = torch.where(act, tt, self.filter_time)
         self._ring_push(act, self.filter_time, kind, z_obs, Rd, 1, ea)
 
@@ -943,7 +943,7 @@ class BatchedEKF:
     return ~(self.maha_dist(kind, z, R, extra_args) > chi2_ppf(maha_thresh, self.zdims[kind]))
 
   # -- fused multi-step run -------------------------------------------------------------------------
-  def run(self, ts, kinds, zs, Rs=None, trace=False, flags=False, out=None, filters=None, extra_args=None, augment=None):
+  def run(self, ts, kinds, zs, Rs=None, trace=False, flags=False, out=None, filters=None, extra_args=None, augment=None, exact=False):
     """T predict+update steps in ONE launch; x and P stay on chip between steps.
 
     ts (T,) observation times, kinds (T,) observation kinds -- the schedule is shared by all filters;
@@ -956,6 +956,11 @@ class BatchedEKF:
     filters = (lo, hi): run only filters lo .. hi-1 of the batch (their x / P records are contiguous); N above is then
     hi - lo.  extra_args (T, N, EA): per filter and step extra arguments for the kinds that take them (MSCKF feature tracks:
     the landmark; rows of other kinds are ignored); augment (T,) bool: MSCKF window shift after that step.
+    exact=True: the REFERENCE'S result for this schedule on any input covariance, symmetric or not -- the schedule is walked with the
+    step-granular kernels, which multiply with both halves of P and solve with S as a general matrix like ekf_c.c:24,100-101,115
+    (one launch per step: the state crosses HBM every step).  The default (fused launch) computes on (P + P^T) / 2, which is the
+    same thing for the covariances a filter produces itself and differs at first order in a caller-supplied skew part
+    (include/rednose_amd_filter.h).
     Returns (ys, trace_x, trace_P, flags) with None for outputs not requested.
     """
     torch = self._torch
@@ -1011,11 +1016,12 @@ class BatchedEKF:
     if augment is not None:
       assert self.msckf, "augment: MSCKF models only"
       ag = torch.as_tensor(np.asarray(augment, dtype=np.int32).reshape(T), device=self.device)
-    if self._has_batch_run():
+    if self._has_batch_run() and not exact:
       self._call("batch_run", self._p(xv), self._p(Pv), self._p(self.Q), self._p(kd), self._p(dd), T, self._p(zs),
                  self._p(Rd), nb, self.norm_quats, self._p(fl), self._p(tx), self._p(tP), self._p(ea), self._p(ag), self._stream())
     else:
-      self._run_stepwise(xv, Pv, kinds, dts, zs, Rd, nb, fl, tx, tP, ea, None if augment is None else np.asarray(augment).reshape(T))
+      self._run_stepwise(xv, Pv, kinds, dts, zs, Rd, nb, fl, tx, tP, ea, None if augment is None else np.asarray(augment).reshape(T),
+                         symmetrise=not exact)
     if nb == self.batch:          # a strict subset leaves the orchestrator's clock alone: the other filters have not moved
       if ag is not None and self.msckf:
         for t_, a_ in zip(ts, np.asarray(augment).reshape(T)):
@@ -1034,11 +1040,12 @@ class BatchedEKF:
     fn.restype = ctypes.c_int
     return bool(fn())
 
-  def _run_stepwise(self, xv, Pv, kinds, dts, zs, Rd, nb, fl, tx, tP, ea, augment):
-    """run() for a library without the fused multi-step kernel: the same schedule, one fused predict + update launch per step
-    through the step-granular entry points (same results as the reference's per-call path; the state crosses HBM every step)."""
-    # one contract for run(), whichever path serves it: the fused kernels read (P + P^T) / 2 (include/rednose_amd_filter.h)
-    Pv.copy_(0.5 * (Pv + Pv.transpose(1, 2)))
+  def _run_stepwise(self, xv, Pv, kinds, dts, zs, Rd, nb, fl, tx, tP, ea, augment, symmetrise=True):
+    """run() for a library without the fused multi-step kernel, and run(exact=True) for every library: the same schedule, one fused
+    predict + update launch per step through the step-granular entry points (same results as the reference's per-call path; the
+    state crosses HBM every step)."""
+    if symmetrise:      # one contract for the default run(), whichever path serves it: the fused kernels read (P + P^T) / 2 (include/rednose_amd_filter.h)
+      Pv.copy_(0.5 * (Pv + Pv.transpose(1, 2)))
     for t in range(len(kinds)):
       k = int(kinds[t])
       Z = self.zdims[k]

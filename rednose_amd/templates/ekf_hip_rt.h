@@ -348,6 +348,9 @@ __device__ __forceinline__ double pair_xchg(const double v) {
 // ~40 cycles for a lone wavefront (tools/fp64_ilp.hip: 40.7 cycles per FMA with one chain, 10.8 with eight), and the
 // factorisation sits on the critical path of every update.  No denormal / overflow scaling: d is a variance.
 __device__ __forceinline__ double fast_recip(const double d) {
+#ifdef RN_EXACT_MATH      // tuning knob exact_math=1 (codegen/tuning.py): IEEE division / square root and the library's sin, cos everywhere -- the
+  return 1.0 / d;         // build tests/test_gpu_live.py measures the fast primitives against
+#endif
   double r = __builtin_amdgcn_rcp(d);
   r = fma(fma(-d, r, 1.0), r, r);
   r = fma(fma(-d, r, 1.0), r, r);
@@ -369,6 +372,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 // 1 / sqrt(a) for a > 0: v_rsq_f64 seed + two Newton steps (same reasoning as fast_recip: sqrt followed by an IEEE
 // division is ~100 dependent instructions per pivot of a Cholesky factorisation).
 __device__ __forceinline__ double fast_rsqrt(const double a) {
+#ifdef RN_EXACT_MATH
+  return 1.0 / sqrt(a);
+#endif
   double y = __builtin_amdgcn_rsq(a);
   const double h = 0.5 * a;
   y = fma(y, fma(-h * y, y, 0.5), y);
@@ -382,12 +388,18 @@ __device__ __forceinline__ double fast_rsqrt(const double a) {
 // hardware seed's exact inf / 0 into NaN (inf * 0).  The seed IS the IEEE answer there, so it is returned whenever the refined value
 // is not finite: one compare + select at the end of the chain.  The factorisations keep the unguarded forms (their pivots are variances).
 __device__ __forceinline__ double safe_recip(const double d) {
+#ifdef RN_EXACT_MATH
+  return 1.0 / d;
+#endif
   const double r0 = __builtin_amdgcn_rcp(d);
   double r = fma(fma(-d, r0, 1.0), r0, r0);
   r = fma(fma(-d, r, 1.0), r, r);
   return (r - r == 0.0) ? r : r0;
 }
 __device__ __forceinline__ double safe_rsqrt(const double a) {
+#ifdef RN_EXACT_MATH
+  return 1.0 / sqrt(a);
+#endif
   const double y0 = __builtin_amdgcn_rsq(a);
   const double h = 0.5 * a;
   double y = fma(y0, fma(-h * y0, y0, 0.5), y0);

@@ -193,6 +193,36 @@ def test_fused_run_is_the_reference_on_the_symmetric_part(name, trace):
   assert 1e-9 < d < 1e3 * SKEW, f"{name}: distance to the run on the asymmetric matrix {d:.2e}"
 
 
+@pytest.mark.parametrize("name", MODELS)
+def test_run_exact_is_the_reference_on_the_asymmetric_matrix_itself(name):
+  """run(exact=True) walks the schedule with the step-granular kernels (both halves of P, S as a general matrix): the reference's own
+  result for a T-step schedule on a covariance with a skew part -- ekf_c.c:24,100-101,115 never symmetrise -- trace and flags included."""
+  n, T = 45, 9
+  torch, M, f, o, rng, x0, P0, kinds, quat = _setup(name, n, 29)
+  Pa = _skewed(P0, rng)
+  sched, ts, zs, Rt = _schedule(M, o, rng, x0, kinds, quat, T)
+  Rs = {int(k): np.atleast_2d(M.obs_noise[int(k)]) for k in kinds}
+  f.init_state(x0, Pa, 0.0)
+  ys, tx, tP, fl = f.run(ts, sched, zs.copy(), Rs, trace=True, flags=True, exact=True)
+  torch.cuda.synchronize()
+  dts = np.diff(np.concatenate([[0.0], ts]))
+  xa, Pa_, za = x0.copy(), Pa.copy(), zs.copy()
+  xf, Pf = np.zeros((T, n, x0.shape[1])), np.zeros((T, n) + P0.shape[1:])
+  fr = np.zeros((T, n), dtype=np.uint8)
+  o.batch_run(sched, dts, xa, Pa_, za, Rt, M.Q, quat_idx=quat, flags=fr, xf=xf, Pf=Pf)
+  assert_close(f.state(), xa, rtol=1e-10, floor=1e-11, what=f"{name} run(exact) x")
+  assert_close(f.covs().reshape(n, -1), Pa_.reshape(n, -1), rtol=1e-10, floor=1e-10, what=f"{name} run(exact) P")
+  assert_close(tx.cpu().numpy().reshape(T * n, -1), xf.reshape(T * n, -1), rtol=1e-10, floor=1e-11, what=f"{name} run(exact) trace x")
+  assert_close(tP.cpu().numpy().reshape(T * n, -1), Pf.reshape(T * n, -1), rtol=1e-10, floor=1e-10, what=f"{name} run(exact) trace P")
+  assert np.array_equal(fl.cpu().numpy() & 1, fr & 1)
+  yh = ys.cpu().numpy()
+  for t, k in enumerate(sched):
+    Z = o.zdim(int(k))
+    assert_close(yh[t][:, :Z], za[t][:, :Z], rtol=1e-9, atol=1e-10 * max(1.0, np.abs(zs).max()), what=f"{name} run(exact) y[{t}]")
+  # and it is NOT the symmetrised run: the two differ by the first-order effect of the skew part
+  assert _rel(f.covs(), _sym(Pa)) > 0 and _rel(Pa_, f.covs()) < 1e-9
+
+
 def _numpy_backward_step(o, M, name, quat, Xk, Pk_raw, dt, x1n, P1n_raw, newest, oldest):
   """One step of ekf_sym.py:651-690 under the contract of batch_rts: gain and correction from the lower triangles."""
   D, E = Xk.shape[0], Pk_raw.shape[0]

@@ -84,6 +84,56 @@ def test_single_calls_vs_oracle_strict(env, n):
       assert_close(y.cpu().numpy(), zr, rtol=1e-9, atol=1e-9, what=f"kind {k} fused={fused} y")
 
 
+def test_fast_elementary_functions_against_the_ieee_build(env):
+  """The non-IEEE primitives as a tested contract.  Every generated kernel evaluates reciprocals, reciprocal square roots and sin / cos
+  through hardware seeds + Newton steps and one in-line sincos (templates/ekf_hip_rt.h, codegen/lower.py); RN_TUNE=exact_math=1 builds
+  the same library with IEEE division / sqrt and the library's sin / cos (generated/exact/).  Same inputs through both:
+    * single calls (the golden states, every kind, fused predict + update): the two builds agree to 1e-12 of the row maximum on x and P;
+    * the 84-step IMU + GNSS stream of tests/golden/live_stream.npz, free-running: agreement after 84 launches is recorded in
+      gpurun_out/live_fast_vs_ieee.json and bounded by 1e-11 (states) / 1e-10 (covariances) of the row maximum."""
+  import json
+  import os
+  torch, gen, L = env
+  from examples import ensure_exact
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  gex = ensure_exact(["live"])
+  g = golden("live_single_steps.npz")
+  n = g["x_in"].shape[0]
+  fa = _filter(env, n)
+  fe = BatchedEKF(gex, "live", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22, batch=n, quaternion_idxs=[3])
+  rng = np.random.default_rng(8)
+  worst = {"x": 0.0, "P": 0.0}
+
+  def rel(a, b):
+    a, b = a.reshape(n, -1), b.reshape(n, -1)
+    return float((np.abs(a - b) / np.maximum(np.abs(b).max(axis=1, keepdims=True), 1e-300)).max())
+  for k in KINDS:
+    Z = 1 if k == 3 else 3
+    R = np.atleast_2d(L.obs_noise.get(k, np.eye(Z) * 0.1))
+    z = g[f"upd{k}_z"] + rng.normal(size=g[f"upd{k}_z"].shape) * 1e-3
+    for f in (fa, fe):
+      f.init_state(g["x_in"], g["P_in"], 0.0)
+      f.predict_and_update_batch(0.02, k, z.copy(), R)
+    torch.cuda.synchronize()
+    ex, eP = rel(fa.state(), fe.state()), rel(fa.covs(), fe.covs())
+    worst["x"], worst["P"] = max(worst["x"], ex), max(worst["P"], eP)
+    assert ex < 1e-12 and eP < 1e-12, f"kind {k}: fast vs IEEE build {ex:.2e} (x) {eP:.2e} (P) of the row maximum"
+  s = golden("live_stream.npz")
+  m = 3
+  fa, fe = _filter(env, m), BatchedEKF(gex, "live", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22, batch=m, quaternion_idxs=[3])
+  n = m
+  for f in (fa, fe):
+    f.init_state(s["x0"], s["P0"], None)
+    for k, t, z in zip(s["kinds"], s["ts"], s["zs"]):
+      f.predict_and_update_batch(float(t), int(k), np.tile(z, (m, 1)), L.obs_noise[int(k)])
+  torch.cuda.synchronize()
+  sx, sP = rel(fa.state(), fe.state()), rel(fa.covs(), fe.covs())
+  os.makedirs("gpurun_out", exist_ok=True)
+  with open("gpurun_out/live_fast_vs_ieee.json", "w", encoding="utf-8") as fh:
+    json.dump({"single_call_worst_of_row_max": worst, "stream_84_launches_of_row_max": {"x": sx, "P": sP}}, fh, indent=1)
+  assert sx < 1e-11 and sP < 1e-10, f"84-step stream: fast vs IEEE build {sx:.2e} (x) {sP:.2e} (P) of the row maximum"
+
+
 def test_stream_vs_reference_numpy(env):
   """84-step IMU@100Hz + GNSS stream of tests/golden/live_stream.npz (reference numpy path, renorm after predict and update)."""
   torch, gen, L = env
