@@ -59,11 +59,20 @@ def _renamed(cls, name, folder, **kw):
   gen_code(folder, **mdl, **kw)
 
 
+_ENSURED = set()      # (name, folder, tuning) checked in THIS process
+
+
 def ensure_generated(names=None, folder=GENERATED_DIR):
-  """Generate + compile the named example filters (skips up-to-date ones).  Returns the folder."""
+  """Generate + compile the named example filters (skips up-to-date ones).  Returns the folder.
+  A model is checked once per process, folder and tuning: the check itself re-emits the model's source to compare digests -- 15 s of
+  sympy work for the live model, which the GPU test suite used to repeat two dozen times (3 of its 11 minutes)."""
   table = model_table()
   for n in (names or table.keys()):
+    key = (n, os.path.abspath(folder), os.environ.get("RN_TUNE", ""), os.environ.get("RN_HIPCC_FLAGS", ""), os.environ.get("RN_ALLOW_SPILLS", ""))
+    if key in _ENSURED:
+      continue
     table[n](folder)
+    _ENSURED.add(key)
   return folder
 
 

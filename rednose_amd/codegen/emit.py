@@ -460,6 +460,9 @@ void {name}_predict(double *in_x, double *in_P, double *in_Q, double dt) {{
 
   hdr += ["#ifdef __cplusplus", "}", "#endif", ""]
   text = "\n".join(src) + "\n" + "\n".join(abi) + "\n"
+  if "rn::nullspace_residual<" in text:      # feature-track kinds: the residual in the reference's null-space basis (codegen/lower.py)
+    from rednose_amd.codegen.lower import NULLSPACE_RESIDUAL
+    text = text.replace('#include "ekf_hip_rts.h"\n', '#include "ekf_hip_rts.h"\n' + NULLSPACE_RESIDUAL, 1)
   if "rn::sincos_fast(" in text:      # the model has trigonometric terms: codegen/lower.py printed them through this helper
     from rednose_amd.codegen.lower import SINCOS_FAST
     text = text.replace('#include "ekf_hip_rts.h"\n', '#include "ekf_hip_rts.h"\n' + SINCOS_FAST, 1)

@@ -60,7 +60,7 @@ class RtsLayout:
     self.OFF_DT = D + self.nf
     n = self.OFF_DT + 1
     # fields the shared scalar functions of emit_wide2.device_functions address but the smoother never calls
-    self.OFF_HE = self.OFF_DX = self.OFF_Y = self.OFF_FL = self.OFF_RF = self.OFF_RP = n
+    self.OFF_HE = self.OFF_DX = self.OFF_Y = self.OFF_FL = self.OFF_RF = self.OFF_RP = self.OFF_YP = n
     self.zf = 0
     self.SLOT = n + 1 - (n & 1)
 

@@ -101,7 +101,14 @@ class Layout:
     self.zf = max([k.zdim for k in feat] + [0])
     self.OFF_RF = self.OFF_FL + 1
     self.OFF_RP = self.OFF_RF + (EADIM * self.zf + EADIM if feat else 0)
-    self.SLOT = _odd(self.OFF_RP + ((self.zf - EADIM) ** 2 if feat else 0))     # odd stride: lane-per-filter ds_*_b64 accesses hit 32 distinct bank pairs
+    # the residual of a feature-track kind exists twice: in the orthonormal basis of the reflectors (what the update consumes: OFF_YP)
+    # and in the reference's fullPivLu basis (what goes back into z: the Y field); the elimination's work space (EADIM Z + 2 Z doubles)
+    # lies over the reflector / projected-noise fields, which are written after it
+    self.OFF_YP = self.OFF_RP + ((self.zf - EADIM) ** 2 if feat else 0)
+    end = self.OFF_YP + ((self.zf - EADIM) if feat else 0)
+    if feat:
+      end = max(end, self.OFF_RF + EADIM * self.zf + 2 * self.zf)
+    self.SLOT = _odd(end)     # odd stride: lane-per-filter ds_*_b64 accesses hit 32 distinct bank pairs
 
 
 def _lowered_predict(spec):
@@ -247,14 +254,15 @@ def _lean_update(k, Hs, lay, E, rows_in_regs=False):
       for w in range(Z):
         b.append(f"HPH[{zi * Z + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))};")
   # S is solved as a GENERAL matrix (L D U): the step-granular kernels follow the reference on asymmetric covariances (ekf_c.c:100-101)
-  factor, gate, solve = innovation_solver(Z, True, [f"sl[{lay.OFF_Y + i}]" for i in range(Z)], k.maha_thresh if k.maha_test else None)
+  YO = lay.OFF_YP if feat else lay.OFF_Y      # the residual the update consumes (feature-track kinds: the one in the reflectors' basis)
+  factor, gate, solve = innovation_solver(Z, True, [f"sl[{YO + i}]" for i in range(Z)], k.maha_thresh if k.maha_test else None)
   b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}", factor, "int gated = 0;"]
   b += gate
   b.append(f"double kk[{Z}] = {{{', '.join(f'Gt_{zi}' for zi in range(Z))}}};")
   b.append(solve("kk"))
   if feat:     # the reference's numpy path ignores a measurement whose null-space projection failed (ekf_sym.py:589-591)
     b += ["if (rank_deficient != 0.0) {", "#pragma unroll", f"  for (int i = 0; i < {Z}; i++) kk[i] = 0.0;", "}"]
-  b.append("const double dxc = " + " + ".join(f"kk[{zi}]*sl[{lay.OFF_Y + zi}]" for zi in range(Z)) + ";")
+  b.append("const double dxc = " + " + ".join(f"kk[{zi}]*sl[{YO + zi}]" for zi in range(Z)) + ";")
   for zi in range(Z):
     c = f"Gt_{zi} - (" + " + ".join(f"kk[{w}]*HPH[{w * Z + zi}]" for w in range(Z)) + ")"
     kr = " + ".join(f"kk[{w}]*Rl[{w * Z + zi}]" for w in range(Z))
@@ -336,12 +344,13 @@ def device_functions(spec, lay_cls=None, sfx=""):
       b.append("if (PROJECT) {")
       hea = ", ".join(("0.0" if st[f"Hea_{i}_{j}"][0] == 'zero' else ("1.0" if st[f"Hea_{i}_{j}"][0] == 'one' else val(f"Hea_{i}_{j}")))
                       for i in range(Z) for j in range(EADIM))
-      b += [f"  double Hea[{Z * EADIM}] = {{{hea}}};", f"  double u[{EADIM * Z}], beta[{EADIM}];",
-            f"  const bool ok = rn::householder_qr<{Z}, {EADIM}>(Hea, u, beta);",
+      b += [f"  double Hea[{Z * EADIM}] = {{{hea}}};", f"  double u[{EADIM * Z}], beta[{EADIM}], yref[{Zp}];",
+            f"  const bool ok2 = rn::nullspace_residual<{Z}, {EADIM}>(Hea, y, sl + {lay.OFF_RF}, yref);      // y in the reference's basis (ekf_c.c:71-73), before the reflectors take that part of the slot",
+            f"  const bool ok = rn::householder_qr<{Z}, {EADIM}>(Hea, u, beta) && ok2;",
             f"  rn::apply_reflectors<{Z}, {EADIM}>(u, beta, y);",
             "#pragma unroll", f"  for (int i = 0; i < {EADIM * Z}; i++) sl[{lay.OFF_RF} + i] = u[i];",
             "#pragma unroll", f"  for (int i = 0; i < {EADIM}; i++) sl[{lay.OFF_RF + EADIM * Z} + i] = beta[i];",
-            "#pragma unroll", f"  for (int i = 0; i < {Zp}; i++) sl[{lay.OFF_Y} + i] = ok ? y[{EADIM} + i] : 0.0;",
+            "#pragma unroll", f"  for (int i = 0; i < {Zp}; i++) {{ sl[{lay.OFF_YP} + i] = ok ? y[{EADIM} + i] : 0.0; sl[{lay.OFF_Y} + i] = ok ? yref[i] : 0.0; }}",
             "#pragma unroll", f"  for (int i = {Zp}; i < {Z}; i++) sl[{lay.OFF_Y} + i] = z[i];      // y has Z - EADIM rows (ekf_c.c:120)",
             f"  sl[{lay.OFF_FL}] = ok ? 0.0 : 4.0;",
             f"  double Rm[{Z * Z}];", "#pragma unroll", f"  for (int i = 0; i < {Z * Z}; i++) Rm[i] = gRf[i];",

@@ -124,7 +124,10 @@ class RunLayout:
     self.zf = max([k.zdim for k in feat] + [0])
     self.OFF_RF = self.OFF_FL + 1
     self.OFF_RP = self.OFF_RF + (EADIM * self.zf + EADIM if feat else 0)
-    n = self.OFF_RP + ((self.zf - EADIM) ** 2 if feat else 0)
+    self.OFF_YP = self.OFF_RP + ((self.zf - EADIM) ** 2 if feat else 0)      # (see emit_wide2.Layout: the residual in the reflectors' basis, the elimination's work space)
+    n = self.OFF_YP + ((self.zf - EADIM) if feat else 0)
+    if feat:
+      n = max(n, self.OFF_RF + EADIM * self.zf + 2 * self.zf)
     self.SLOT = n + 1 - (n & 1)      # odd stride, as in the step kernels
 
 
@@ -249,7 +252,7 @@ def update_fn(spec, k):
   b += ["#pragma unroll", f"for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = R[i]; S[i] = HPH[i] + Rl[i]; }}", f"rn::spd_factor<{Z}>(S, L, iL);",
         "int gated = 0;"]
   if k.maha_test:
-    b += ["{", f"  double v[{Z}] = {{{', '.join(f'sl[{lay.OFF_Y + i}]' for i in range(Z))}}};", f"  rn::spd_forward<{Z}>(L, iL, v);",
+    b += ["{", f"  double v[{Z}] = {{{', '.join(f'sl[{(lay.OFF_YP if feat else lay.OFF_Y) + i}]' for i in range(Z))}}};", f"  rn::spd_forward<{Z}>(L, iL, v);",
           "  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(Z)) + ";", f"  if (d2 > {k.maha_thresh!r}) {{", "    gated = 1;",
           "#pragma unroll", f"    for (int i = 0; i < {Z * Z}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}",
           f"    rn::spd_factor<{Z}>(S, L, iL);", "  }", "}"]
@@ -258,7 +261,7 @@ def update_fn(spec, k):
     b.append(f"rn::spd_solve<{Z}>(L, iL, kk{s});                       // K[row][:]")
     if feat:     # the reference's numpy path ignores a measurement whose null-space projection failed (ekf_sym.py:589-591)
       b += ["if (rank_deficient != 0.0) {", "#pragma unroll", f"  for (int i = 0; i < {Z}; i++) kk{s}[i] = 0.0;", "}"]
-    b.append(f"const double dx{s} = " + " + ".join(f"kk{s}[{zi}]*sl[{lay.OFF_Y + zi}]" for zi in range(Z)) + ";")
+    b.append(f"const double dx{s} = " + " + ".join(f"kk{s}[{zi}]*sl[{(lay.OFF_YP if feat else lay.OFF_Y) + zi}]" for zi in range(Z)) + ";")
   # B = P - K G: every broadcast row of G feeds all R row slots
   b += _tl(12)
   b += _rank_pass(E, Z, R, "sG", "-=", "kk")

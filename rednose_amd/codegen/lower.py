@@ -68,6 +68,89 @@ __device__ __forceinline__ void sincos_fast(const double a_in, double& s, double
 """
 
 
+# Emitted once into the generated file of a model with feature-track kinds (emit.emit).
+NULLSPACE_RESIDUAL = r"""namespace rn {
+// The residual of a feature-track observation in the REFERENCE'S basis of the left null space of the extra-argument Jacobian:
+// /root/reference/rednose/templates/ekf_c.c:71-73 -- A = Hea^T.fullPivLu().kernel(); y = A^T y -- is what the reference writes back into z
+// (:120) and returns in its Estimate (ekf_sym.cc:164-184).  x and P do not depend on the basis (the update runs in the orthonormal one the
+// Householder reflectors give, templates/ekf_hip_rt.h), y does; so y alone is also formed here the way Eigen forms it: Gaussian
+// elimination of M = Hea^T (A x Z) with FULL pivoting, P M Q = L U, U = [U1 U2], kernel vectors Q [-U1^-1 U2 ; I] (column c has its 1 at
+// the (A + c)-th permuted position) -- the same loops as oracle/ekf_oracle.c:fullpiv_kernel, the same pivot choice on ties.  The pivots'
+// positions are run-time values: U, the permutation and a copy of y live in `w` (A Z + 2 Z doubles of the filter's LDS slot, dead at
+// this point of the scalar phase), indexed dynamically there -- register arrays indexed at run time would go to scratch memory.
+// Returns false (yout = 0) when Hea^T has rank < A by Eigen's threshold; the caller flags the observation as ignored.
+template <int Z, int A>
+__device__ __forceinline__ bool nullspace_residual(const double (&Hea)[Z * A], const double (&y)[Z], double* w, double (&yout)[Z - A]) {
+  double* U = w;
+  double* perm = w + A * Z;
+  double* yv = perm + Z;
+#pragma unroll
+  for (int i = 0; i < A; i++) {
+#pragma unroll
+    for (int j = 0; j < Z; j++) U[i * Z + j] = Hea[j * A + i];
+  }
+#pragma unroll
+  for (int j = 0; j < Z; j++) { perm[j] = (double)j; yv[j] = y[j]; }
+  int rank = 0;
+  double maxpiv = 0.0;
+#pragma unroll
+  for (int k = 0; k < A; k++) {
+    if (rank < k) break;
+    int pr = k, pc = k;
+    double best = 0.0;
+#pragma unroll
+    for (int i = k; i < A; i++) {
+#pragma unroll
+      for (int j = k; j < Z; j++) {
+        const double a = fabs(U[i * Z + j]);
+        if (a > best) { best = a; pr = i; pc = j; }
+      }
+    }
+    if (k == 0) maxpiv = best;
+    if (!(best > 2.220446049250313e-16 * Z * maxpiv)) break;
+    if (pr != k) {
+#pragma unroll
+      for (int j = 0; j < Z; j++) { const double t = U[k * Z + j]; U[k * Z + j] = U[pr * Z + j]; U[pr * Z + j] = t; }
+    }
+    if (pc != k) {
+#pragma unroll
+      for (int i = 0; i < A; i++) { const double t = U[i * Z + k]; U[i * Z + k] = U[i * Z + pc]; U[i * Z + pc] = t; }
+      const double t = perm[k]; perm[k] = perm[pc]; perm[pc] = t;
+    }
+#pragma unroll
+    for (int i = k + 1; i < A; i++) {
+      const double l = U[i * Z + k] / U[k * Z + k];
+#pragma unroll
+      for (int j = k; j < Z; j++) U[i * Z + j] -= l * U[k * Z + j];
+    }
+    rank++;
+  }
+  if (rank < A) {
+#pragma unroll
+    for (int c = 0; c < Z - A; c++) yout[c] = 0.0;
+    return false;
+  }
+#pragma unroll
+  for (int c = 0; c < Z - A; c++) {
+    double v[A];
+#pragma unroll
+    for (int i = A - 1; i >= 0; i--) {            // U1 v = -U2[:, c]
+      double acc = -U[i * Z + A + c];
+#pragma unroll
+      for (int p = i + 1; p < A; p++) acc -= U[i * Z + p] * v[p];
+      v[i] = acc / U[i * Z + i];
+    }
+    double r = yv[(int)perm[A + c]];
+#pragma unroll
+    for (int i = 0; i < A; i++) r += v[i] * yv[(int)perm[i]];
+    yout[c] = r;
+  }
+  return true;
+}
+}  // namespace rn
+"""
+
+
 class HipPrinter(C99CodePrinter):
   """C99 printer with power strength-reduction suitable for fp64 device code."""
 
