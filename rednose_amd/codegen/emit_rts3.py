@@ -459,7 +459,7 @@ __global__ {bounds} void k_rts3(const double* __restrict__ xf, const double* __r
     fp64 FMA issues ~40 cycles after its predecessor when the wavefront is alone on its SIMD, two sums per slot left the chains
     24 cycles apart)."""
     pieces = [(j, h) for j in range(E) for h in (0, 1)]
-    NP = tuning.current().rts3_np
+    NP = 4      # partial sums per slot (6 / 8 measured in round 5: 74.1 / 75.7 ms per config-4 chunk against 68.5 -- the pairwise tree's extra adds cost more than the longer chains hide)
 
     def tree(ts):        # pairwise sum of the partial sums: (s0 + s1) + (s2 + s3) for four
       while len(ts) > 1:

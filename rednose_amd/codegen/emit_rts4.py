@@ -406,8 +406,8 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
     for m in range(E):
       for i in range(m + 1, E):
         A(f"        RN4_FNMAC(y[{i}], a{slot_of(i)}[{m}], y[{m}], {lane_of(i)});")
-    for m in range(E):
-      A(f"        {{ double t_; RN4_BC(t_, a{slot_of(m)}[{m}], {lane_of(m)}); y[{m}] *= t_; }}")
+    for m in range(E):      # y[m] *= 1 / d_m as ONE multiply-add with the reciprocal pivot broadcast by the instruction itself (0 + (1 / d_m) y[m]: the product, bit for bit)
+      A(f"        {{ double t_ = 0.0; RN4_FMAC(t_, a{slot_of(m)}[{m}], y[{m}], {lane_of(m)}); y[{m}] = t_; }}")
     for m in range(E - 1, 0, -1):
       for i in range(m - 1, -1, -1):
         A(f"        RN4_FNMAC(y[{i}], a{slot_of(m)}[{i}], y[{m}], {lane_of(m)});")

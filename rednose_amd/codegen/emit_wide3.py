@@ -83,7 +83,7 @@ def _rank_pass(E, Z, R, src, op, coef, JB=None):
       different accumulation chains: a dependent fp64 FMA issues ~40 cycles after its predecessor with one wavefront per SIMD
       (tools/fp64_ilp.hip), entry-by-entry order made every FMA wait for the one before it."""
   from rednose_amd.codegen import tuning
-  JB = JB or tuning.current().run_jb
+  JB = JB or 4      # columns per block (6 and 8 measured in round 5: 21.21 / 20.90 ms per config-4 chunk against 21.04 / 21.24 -- noise; profiles/tuning_notes.md)
   out = []
   blocks = [list(range(j, min(j + JB, E))) for j in range(0, E, JB)]
   sg = "-=" if op == "-=" else "+="

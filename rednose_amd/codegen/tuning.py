@@ -18,8 +18,6 @@ variants do not overwrite generated/).  What each alternative measured: profiles
   exact_math   1 = IEEE division / square root and ocml sin / cos in place of the fast primitives (reference build for the accuracy tests; full sin / cos range)
   rts4         1 = smoother of lane-group models with register-broadcast operands (emit_rts4: 16 lanes x 2 rows, 4 filters per wavefront, two wavefronts per SIMD), 0 = rts3
   rts3         1 = smoother of lane-group models in the fused run's layout (emit_rts3: 8 filters per wavefront), 0 = rn::k_rts_group
-  run_jb       columns per block of the fused run's rank-Z passes (emit_wide3._rank_pass): JB x rows-per-lane independent FMA chains in flight
-  rts3_np      partial sums per row slot in the smoother's two products (emit_rts3.product): NP x rows-per-lane independent chains
 """
 import os
 from dataclasses import dataclass, fields
@@ -39,8 +37,6 @@ class Tuning:
   run_block: int = 0
   rts3: int = 1
   rts4: int = 1              # smoother with every cross-lane operand by row_newbcast, two wavefronts per SIMD (emit_rts4: even E, 8 .. 22 error states); 0 = emit_rts3
-  run_jb: int = 4            # prepared at the end of round 4 (profiles/r4_issue_probe.txt: a lone wavefront issues an fp64 FMA every 11.3 cycles with 8
-  rts3_np: int = 4           # independent chains, 8.4 with 16, 7.6 with 24, 7.1 with 32; both kernels run 12) -- not measured yet: profiles/tuning_notes.md
   exact_math: int = 0        # 1 = IEEE division / sqrt and the library's sin / cos instead of the hardware-seed + Newton primitives and rn::sincos_fast (a reference build for tests: tests/test_gpu_live.py)
   nt_trace: int = 1          # the fused run's covariance trace leaves with nontemporal stores (config 4 forward: 23.5 vs 24.5 ms per chunk, same call)
   wide_timeline: int = 0     # debug: lane 0 of the first 256 workgroups stamps s_memtime / the 100 MHz wall clock at every phase boundary of
