@@ -489,9 +489,10 @@ def config4_extra(torch, dev, rank, nb=16384, T=2100, chunk=8192):
     per = measured_traffic(label, "live_maha", gen) if (chunk == 8192 and T == 2100) else None
     return None if per is None else per * (nb / chunk)
 
-  try:          # the smoother kernel this library was built with (emit_rts3's k_rts3, or the lane-group rn::k_rts_group it falls back to)
+  try:          # the smoother kernel this library was built with (emit_rts4's k_rts4, its fallbacks: emit_rts3's k_rts3, the lane-group rn::k_rts_group)
     with open(os.path.join(gen, "live_maha.kernels.txt"), encoding="utf-8") as fh:
-      rts_kernel = "k_rts3" if "k_rts3" in fh.read() else "rn::k_rts_group"
+      kt = fh.read()
+      rts_kernel = "k_rts4" if "k_rts4" in kt else ("k_rts3" if "k_rts3" in kt else "rn::k_rts_group")
   except OSError:
     rts_kernel = "k_rts*"
   fwd_bytes = nb * T * 8.0 * ((23 + 484) + 2 * 3) + nb * T           # filtered trace written, z read, y written, flags

@@ -94,7 +94,7 @@ def msckf(label, n, reps):
 
 def config4(n=8192, T=2100):
   """One chunk of config 4 exactly as bench.config4_extra launches it: forward k_run writing trace + gate flags, backward
-  smoother (k_rts3) in place on that trace."""
+  smoother (k_rts4) in place on that trace."""
   if not (want("config4_forward") or want("config4_backward") or want("live_run_notrace")):
     return
   from examples.live_kf import LiveKalman as L

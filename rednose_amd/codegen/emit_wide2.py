@@ -20,6 +20,7 @@ The algebra and its order are unchanged (see emit_wide.py / emit_small.py docstr
 scalars changed.  Results agree with the first structure to rounding (different instruction streams contract
 FMAs differently), which tests/test_gpu_run.py bounds.
 """
+import os
 import re
 
 import sympy as sp
@@ -102,13 +103,9 @@ class Layout:
     self.OFF_RF = self.OFF_FL + 1
     self.OFF_RP = self.OFF_RF + (EADIM * self.zf + EADIM if feat else 0)
     # the residual of a feature-track kind exists twice: in the orthonormal basis of the reflectors (what the update consumes: OFF_YP)
-    # and in the reference's fullPivLu basis (what goes back into z: the Y field); the elimination's work space (EADIM Z + 2 Z doubles)
-    # lies over the reflector / projected-noise fields, which are written after it
+    # and in the reference's fullPivLu basis (what goes back into z: the Y field)
     self.OFF_YP = self.OFF_RP + ((self.zf - EADIM) ** 2 if feat else 0)
-    end = self.OFF_YP + ((self.zf - EADIM) if feat else 0)
-    if feat:
-      end = max(end, self.OFF_RF + EADIM * self.zf + 2 * self.zf)
-    self.SLOT = _odd(end)     # odd stride: lane-per-filter ds_*_b64 accesses hit 32 distinct bank pairs
+    self.SLOT = _odd(self.OFF_YP + ((self.zf - EADIM) if feat else 0))     # odd stride: lane-per-filter ds_*_b64 accesses hit 32 distinct bank pairs
 
 
 def _lowered_predict(spec):
@@ -345,7 +342,7 @@ def device_functions(spec, lay_cls=None, sfx=""):
       hea = ", ".join(("0.0" if st[f"Hea_{i}_{j}"][0] == 'zero' else ("1.0" if st[f"Hea_{i}_{j}"][0] == 'one' else val(f"Hea_{i}_{j}")))
                       for i in range(Z) for j in range(EADIM))
       b += [f"  double Hea[{Z * EADIM}] = {{{hea}}};", f"  double u[{EADIM * Z}], beta[{EADIM}], yref[{Zp}];",
-            f"  const bool ok2 = rn::nullspace_residual<{Z}, {EADIM}>(Hea, y, sl + {lay.OFF_RF}, yref);      // y in the reference's basis (ekf_c.c:71-73), before the reflectors take that part of the slot",
+            f"  const bool ok2 = rn::nullspace_residual<{Z}, {EADIM}>(Hea, y, yref);      // y in the reference's basis (ekf_c.c:71-73); Hea and y are modified below",
             f"  const bool ok = rn::householder_qr<{Z}, {EADIM}>(Hea, u, beta) && ok2;",
             f"  rn::apply_reflectors<{Z}, {EADIM}>(u, beta, y);",
             "#pragma unroll", f"  for (int i = 0; i < {EADIM * Z}; i++) sl[{lay.OFF_RF} + i] = u[i];",

@@ -126,8 +126,6 @@ class RunLayout:
     self.OFF_RP = self.OFF_RF + (EADIM * self.zf + EADIM if feat else 0)
     self.OFF_YP = self.OFF_RP + ((self.zf - EADIM) ** 2 if feat else 0)      # (see emit_wide2.Layout: the residual in the reflectors' basis, the elimination's work space)
     n = self.OFF_YP + ((self.zf - EADIM) if feat else 0)
-    if feat:
-      n = max(n, self.OFF_RF + EADIM * self.zf + 2 * self.zf)
     self.SLOT = n + 1 - (n & 1)      # odd stride, as in the step kernels
 
 

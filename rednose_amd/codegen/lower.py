@@ -75,27 +75,27 @@ NULLSPACE_RESIDUAL = r"""namespace rn {
 // (:120) and returns in its Estimate (ekf_sym.cc:164-184).  x and P do not depend on the basis (the update runs in the orthonormal one the
 // Householder reflectors give, templates/ekf_hip_rt.h), y does; so y alone is also formed here the way Eigen forms it: Gaussian
 // elimination of M = Hea^T (A x Z) with FULL pivoting, P M Q = L U, U = [U1 U2], kernel vectors Q [-U1^-1 U2 ; I] (column c has its 1 at
-// the (A + c)-th permuted position) -- the same loops as oracle/ekf_oracle.c:fullpiv_kernel, the same pivot choice on ties.  The pivots'
-// positions are run-time values: U, the permutation and a copy of y live in `w` (A Z + 2 Z doubles of the filter's LDS slot, dead at
-// this point of the scalar phase), indexed dynamically there -- register arrays indexed at run time would go to scratch memory.
-// Returns false (yout = 0) when Hea^T has rank < A by Eigen's threshold; the caller flags the observation as ignored.
+// the (A + c)-th permuted position) -- the loops of oracle/ekf_oracle.c:fullpiv_kernel, the same pivot choice on ties (first maximum in
+// row-major order).  The pivots' positions are run-time values; every array here is indexed STATICALLY and the exchanges are selects
+// (a register array indexed at run time goes to scratch memory, and a first version that kept U in the filter's LDS slot spent 3 us per
+// tile in ~20 dependent LDS round trips on the one lane per filter that runs this: feature36 launch 83.5 -> 89.8 us; this form: see
+// profiles/tuning_notes.md).  One division per pivot.  Returns false (yout = 0) when Hea^T has rank < A by Eigen's threshold.
 template <int Z, int A>
-__device__ __forceinline__ bool nullspace_residual(const double (&Hea)[Z * A], const double (&y)[Z], double* w, double (&yout)[Z - A]) {
-  double* U = w;
-  double* perm = w + A * Z;
-  double* yv = perm + Z;
+__device__ __forceinline__ bool nullspace_residual(const double (&Hea)[Z * A], const double (&y)[Z], double (&yout)[Z - A]) {
+  double U[A * Z];
+  int pm[Z];
 #pragma unroll
   for (int i = 0; i < A; i++) {
 #pragma unroll
     for (int j = 0; j < Z; j++) U[i * Z + j] = Hea[j * A + i];
   }
 #pragma unroll
-  for (int j = 0; j < Z; j++) { perm[j] = (double)j; yv[j] = y[j]; }
-  int rank = 0;
+  for (int j = 0; j < Z; j++) pm[j] = j;
+  bool full = true;
   double maxpiv = 0.0;
+  double ipv[A];
 #pragma unroll
   for (int k = 0; k < A; k++) {
-    if (rank < k) break;
     int pr = k, pc = k;
     double best = 0.0;
 #pragma unroll
@@ -103,32 +103,52 @@ __device__ __forceinline__ bool nullspace_residual(const double (&Hea)[Z * A], c
 #pragma unroll
       for (int j = k; j < Z; j++) {
         const double a = fabs(U[i * Z + j]);
-        if (a > best) { best = a; pr = i; pc = j; }
+        const bool gt = a > best;
+        best = gt ? a : best; pr = gt ? i : pr; pc = gt ? j : pc;
       }
     }
     if (k == 0) maxpiv = best;
-    if (!(best > 2.220446049250313e-16 * Z * maxpiv)) break;
-    if (pr != k) {
+    full = full && (best > 2.220446049250313e-16 * Z * maxpiv);
+    // rows k <-> pr (columns left of k hold nothing that is read again)
 #pragma unroll
-      for (int j = 0; j < Z; j++) { const double t = U[k * Z + j]; U[k * Z + j] = U[pr * Z + j]; U[pr * Z + j] = t; }
-    }
-    if (pc != k) {
+    for (int j = k; j < Z; j++) {
+      const double rk = U[k * Z + j];
+      double rp = rk;
 #pragma unroll
-      for (int i = 0; i < A; i++) { const double t = U[i * Z + k]; U[i * Z + k] = U[i * Z + pc]; U[i * Z + pc] = t; }
-      const double t = perm[k]; perm[k] = perm[pc]; perm[pc] = t;
+      for (int i = k + 1; i < A; i++) { rp = (pr == i) ? U[i * Z + j] : rp; U[i * Z + j] = (pr == i) ? rk : U[i * Z + j]; }
+      U[k * Z + j] = rp;
     }
+    // columns k <-> pc, and the permutation
+#pragma unroll
+    for (int i = 0; i < A; i++) {
+      const double ck = U[i * Z + k];
+      double cp = ck;
+#pragma unroll
+      for (int j = k + 1; j < Z; j++) { cp = (pc == j) ? U[i * Z + j] : cp; U[i * Z + j] = (pc == j) ? ck : U[i * Z + j]; }
+      U[i * Z + k] = cp;
+    }
+    {
+      const int pk = pm[k];
+      int pp = pk;
+#pragma unroll
+      for (int j = k + 1; j < Z; j++) { pp = (pc == j) ? pm[j] : pp; pm[j] = (pc == j) ? pk : pm[j]; }
+      pm[k] = pp;
+    }
+    ipv[k] = 1.0 / U[k * Z + k];
 #pragma unroll
     for (int i = k + 1; i < A; i++) {
-      const double l = U[i * Z + k] / U[k * Z + k];
+      const double l = U[i * Z + k] * ipv[k];
 #pragma unroll
       for (int j = k; j < Z; j++) U[i * Z + j] -= l * U[k * Z + j];
     }
-    rank++;
   }
-  if (rank < A) {
+  double yp[Z];      // y in pivot order
 #pragma unroll
-    for (int c = 0; c < Z - A; c++) yout[c] = 0.0;
-    return false;
+  for (int j = 0; j < Z; j++) {
+    double v = y[0];
+#pragma unroll
+    for (int m = 1; m < Z; m++) v = (pm[j] == m) ? y[m] : v;
+    yp[j] = v;
   }
 #pragma unroll
   for (int c = 0; c < Z - A; c++) {
@@ -138,14 +158,14 @@ __device__ __forceinline__ bool nullspace_residual(const double (&Hea)[Z * A], c
       double acc = -U[i * Z + A + c];
 #pragma unroll
       for (int p = i + 1; p < A; p++) acc -= U[i * Z + p] * v[p];
-      v[i] = acc / U[i * Z + i];
+      v[i] = acc * ipv[i];
     }
-    double r = yv[(int)perm[A + c]];
+    double r = yp[A + c];
 #pragma unroll
-    for (int i = 0; i < A; i++) r += v[i] * yv[(int)perm[i]];
-    yout[c] = r;
+    for (int i = 0; i < A; i++) r += v[i] * yp[i];
+    yout[c] = full ? r : 0.0;
   }
-  return true;
+  return full;
 }
 }  // namespace rn
 """

@@ -325,29 +325,40 @@ def test_nested_trigonometric_arguments_are_declared_before_use(tmp_path):
     assert np.allclose(o, want, rtol=0, atol=1e-15), (o, want)
 
 
-def test_bench_prints_counter_traffic_only_for_the_build_it_was_taken_on(tmp_path):
+def test_bench_prints_counter_traffic_only_for_the_build_it_was_taken_on(tmp_path, monkeypatch):
   """bench.measured_traffic: a record of profiles/pmc_traffic.json applies to the library whose digest it names, or to a later build the
-  record lists under `carried_to` (then the JSON line says so); any other build gets None -- never a number measured on different code."""
+  record lists under `carried_to` (then the JSON line says so); any other build gets None -- never a number measured on different code.
+  The mechanism is checked on a synthetic record file; the committed file is then checked against the libraries in generated/."""
   import json
   import sys
   sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
   import bench
-  recs = json.load(open(os.path.join(os.path.dirname(__file__), "..", "profiles", "pmc_traffic.json"), encoding="utf-8"))
-  label, rec = next((k, v) for k, v in recs.items() if isinstance(v, dict) and v.get("carried_to"))
-  lib = rec["lib"]
+  repo = tmp_path / "repo"
+  (repo / "profiles").mkdir(parents=True)
+  rec = {"lib": "demo", "lib_digest": "a" * 64, "hbm_bytes_per_launch": 12345.0, "carried_to": ["b" * 64], "carried_note": "arithmetic only"}
+  (repo / "profiles" / "pmc_traffic.json").write_text(json.dumps({"demo_section": rec, "plain_section": {"lib": "demo", "lib_digest": "c" * 64, "hbm_bytes_per_launch": 7.0}}), encoding="utf-8")
+  monkeypatch.setattr(bench, "REPO", str(repo))
+  label, lib = "demo_section", "demo"
   bench.TRAFFIC_CARRIED.clear()
   (tmp_path / f"{lib}.digest").write_text(rec["lib_digest"], encoding="utf-8")
   assert bench.measured_traffic(label, lib, str(tmp_path)) == rec["hbm_bytes_per_launch"] and not bench.TRAFFIC_CARRIED
   (tmp_path / f"{lib}.digest").write_text(rec["carried_to"][0], encoding="utf-8")
   assert bench.measured_traffic(label, lib, str(tmp_path)) == rec["hbm_bytes_per_launch"]
   assert label in bench.TRAFFIC_CARRIED and rec["lib_digest"][:12] in bench.TRAFFIC_CARRIED[label]
+  assert bench.measured_traffic("plain_section", lib, str(tmp_path)) is None      # no carried_to list: another build gets nothing
   bench.TRAFFIC_CARRIED.clear()
   (tmp_path / f"{lib}.digest").write_text("0" * 64, encoding="utf-8")
   assert bench.measured_traffic(label, lib, str(tmp_path)) is None and not bench.TRAFFIC_CARRIED
   assert bench.measured_traffic("no_such_section", lib, str(tmp_path)) is None
-  # the shipped libraries: every record applies to the build in generated/ (directly or carried)
+  monkeypatch.undo()
+  # the committed records: every one applies to the build in generated/ directly -- profiles/collect_and_bench.sh is the last GPU call of a round,
+  # on the shipped libraries, so nothing is carried
+  real = os.path.join(os.path.dirname(__file__), "..", "profiles", "pmc_traffic.json")
   gen = os.path.join(os.path.dirname(__file__), "..", "generated")
+  recs = json.load(open(real, encoding="utf-8"))
   if os.path.exists(os.path.join(gen, "kinematic6.digest")):
+    bench.TRAFFIC_CARRIED.clear()
     for k, v in recs.items():
       if isinstance(v, dict) and "lib" in v:
         assert bench.measured_traffic(k, v["lib"], gen) is not None, k
+    assert not bench.TRAFFIC_CARRIED, bench.TRAFFIC_CARRIED
