@@ -362,3 +362,26 @@ def test_bench_prints_counter_traffic_only_for_the_build_it_was_taken_on(tmp_pat
       if isinstance(v, dict) and "lib" in v:
         assert bench.measured_traffic(k, v["lib"], gen) is not None, k
     assert not bench.TRAFFIC_CARRIED, bench.TRAFFIC_CARRIED
+
+
+def test_register_broadcast_smoother_is_chosen_where_it_applies_and_falls_back():
+  """emit_rts4.applicable: ordinary lane-group models with an even number of error states whose four images fit 20 KB of LDS; the fallback
+  `no_rts4` (gen_code takes it when k_rts4 does not fit 256 registers without scratch) emits the fused run's layout (k_rts3) instead, and
+  libraries that contain k_rts4 ask for the exact register-pressure trackers (build.model_flags)."""
+  import examples.random_kf as R
+  from examples.kinematic9_kf import Kinematic9Kalman
+  from rednose_amd import build as rb
+  from rednose_amd.codegen import emit, emit_rts4
+  from rednose_amd.codegen.spec import build_spec
+  s8 = build_spec(**R.Random8Kalman.model())
+  assert emit_rts4.applicable(s8) and emit_rts4.rows_per_lane(s8) == 1
+  _, text = emit.emit(s8)
+  assert "void k_rts4(" in text and "void k_rts3(" not in text and "hipLaunchKernelGGL(k_rts4," in text
+  assert "v_fmac_f64_dpp" in text and "row_newbcast" in text
+  assert rb.model_flags(text) == rb.RTS4_FLAGS
+  _, text3 = emit.emit(s8, fallbacks=("no_rts4",))
+  assert "void k_rts3(" in text3 and "void k_rts4(" not in text3 and rb.model_flags(text3) == []
+  _, textg = emit.emit(s8, fallbacks=("no_rts4", "no_rts3"))
+  assert "k_rts_group<RtsModel>" in textg and "void k_rts3(" not in textg
+  assert not emit_rts4.applicable(build_spec(**Kinematic9Kalman.model()))        # odd number of error states
+  assert not emit_rts4.applicable(build_spec(**R.Random24Kalman.model()))        # four 24 x 24 images do not fit 20 KB
