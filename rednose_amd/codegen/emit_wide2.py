@@ -200,6 +200,112 @@ def _in_registers(smat, name):
   return m, loads
 
 
+WIDE_Z_LDS = 7      # observation dimension from which the general update keeps the innovation covariance in LDS (below: in registers)
+
+
+def wide_z(k):
+  return k.zdim >= WIDE_Z_LDS
+
+
+def wide_s_doubles(k):
+  """LDS doubles per filter of a wide kind's innovation covariance: S / its L D U factor in place, the reciprocal pivots, and a copy of
+  S for the gated second factorisation."""
+  Z = k.zdim
+  return Z * Z + Z + (Z * Z if k.maha_test else 0)
+
+
+def _wide_obs_update(k, Hs, lay, E):
+  """The general (reference-on-asymmetric-P) update for a WIDE observation kind: Z >= 7.  In registers the five Z x Z matrices of the
+  ordinary path (R, He P He^T, the gated copy, S, its factor) are 405 doubles for Z = 9 -- the 10-state test model with a 9-dimensional
+  kind shipped with 516 B of scratch.  Here S lives in the filter's LDS buffer sS: lane z < Z forms row z of S = G He^T + R (the
+  generation-time sparsity is in He's rows, the lane only picks its row of G), the group factors it IN PLACE as L D U without pivoting
+  -- column by column, lane i eliminating its own row against the broadcast pivot row (two fences per column) -- and every lane solves
+  its own right-hand side against the factor with broadcast reads.  R is read from memory where it is used (the gate's 1e16 as a scalar)."""
+  Z = k.zdim
+  ZZ = Z * Z
+  b = [f"double row[{E}];", "#pragma unroll", f"for (int j = 0; j < {E}; j++) row[j] = sP[cc * {E} + j];"]
+  b += [f"double col[{E}];", "#pragma unroll", f"for (int kq = 0; kq < {E}; kq++) col[kq] = sP[kq * {E} + cc];", "rn::wave_lds_sync();"]
+  b.append(f"double kk[{Z}];")
+  for zi in range(Z):
+    nz = Hs.row_nz(zi)
+    b.append(f"const double G_{zi} = {sum_terms(term(cf, f'col[{kk}]') for kk, cf in nz)};")
+    b.append(f"kk[{zi}] = {sum_terms(term(cf, f'row[{kk}]') for kk, cf in nz)};      // Gt")
+  b.append("if (act) { " + " ".join(f"sG[{zi} * {E} + cc] = G_{zi};" for zi in range(Z)) + " }")
+  b.append("rn::wave_lds_sync();")
+  b.append(f"static_assert({Z} <= {E}, \"a lane per row of the innovation covariance\");")
+  b.append(f"const bool zrow = act && cc < {Z};")
+  b.append(f"const int zc = cc < {Z} ? cc : 0;")
+  b.append(f"const double* gz_ = sG + zc * {E};")
+  b.append("{")
+  for w in range(Z):
+    b.append(f"  const double s_{w} = {sum_terms(term(cf, f'gz_[{j}]') for j, cf in Hs.row_nz(w))} + gR[zc * {Z} + {w}];")
+  b.append("  if (zrow) { " + " ".join(f"sS[cc * {Z} + {w}] = s_{w};" + (f" sS[{ZZ + Z} + cc * {Z} + {w}] = s_{w};" if k.maha_test else "") for w in range(Z)) + " }")
+  b.append("}")
+  b.append("rn::wave_lds_sync();")
+
+  def factor():
+    f = []
+    for j in range(Z):
+      f.append("{")
+      f.append(f"  const double id_ = rn::fast_recip(sS[{j * Z + j}]);")
+      if j + 1 < Z:
+        f.append(f"  double pj[{Z - j - 1}], rw[{Z - j - 1}];")
+        f += ["#pragma unroll", f"  for (int m = {j + 1}; m < {Z}; m++) {{ pj[m - {j + 1}] = sS[{j * Z} + m]; rw[m - {j + 1}] = sS[zc * {Z} + m]; }}"]
+        f.append(f"  const double l_ = sS[zc * {Z} + {j}] * id_;")
+      f.append("  rn::wave_lds_sync();")
+      f.append("  if (zrow) {")
+      if j + 1 < Z:
+        f.append(f"    if (cc > {j}) {{")
+        f.append(f"      sS[cc * {Z} + {j}] = l_;")
+        f += ["#pragma unroll", f"      for (int m = {j + 1}; m < {Z}; m++) sS[cc * {Z} + m] = rw[m - {j + 1}] - l_ * pj[m - {j + 1}];", "    }"]
+        f.append(f"    if (cc == {j}) {{")
+        f += ["#pragma unroll", f"      for (int m = {j + 1}; m < {Z}; m++) sS[{j * Z} + m] = pj[m - {j + 1}] * id_;", "    }"]
+      f.append(f"    if (cc == {j}) sS[{ZZ + j}] = id_;")
+      f.append("  }")
+      f.append("  rn::wave_lds_sync();")
+      f.append("}")
+    return f
+  b += factor()
+  b.append("int gated = 0;")
+  b.append("double rs = 1.0;")
+  if k.maha_test:
+    ys = [f"sl[{lay.OFF_Y + i}]" for i in range(Z)]
+    b += ["{", f"  double v[{Z}] = {{{', '.join(ys)}}}, w[{Z}] = {{{', '.join(ys)}}};"]
+    for i in range(Z):
+      if i:
+        b.append(f"  v[{i}] -= " + " + ".join(f"sS[{i * Z + kq}]*v[{kq}]" for kq in range(i)) + ";")
+        b.append(f"  w[{i}] -= " + " + ".join(f"sS[{kq * Z + i}]*w[{kq}]" for kq in range(i)) + ";")
+    b.append("  const double d2 = " + " + ".join(f"v[{i}]*w[{i}]*sS[{ZZ + i}]" for i in range(Z)) + ";")
+    b.append(f"  gated = d2 > {k.maha_thresh!r} ? 1 : 0;      // (uniform over the filter's lanes: every lane evaluates the same numbers)")
+    b.append("}")
+    b.append("rn::wave_lds_sync();")
+    b.append("if (gated) {      // R *= 1e16 (ekf_c.c:88-94) and a second factorisation, from the kept copy of S = He P He^T + R")
+    b.append("  rs = 1.0e16;")
+    b.append("  if (zrow) { " + " ".join(f"sS[cc * {Z} + {w}] = sS[{ZZ + Z} + cc * {Z} + {w}] + (1.0e16 - 1.0) * gR[cc * {Z} + {w}];" for w in range(Z)) + " }")
+    b.append("  rn::wave_lds_sync();")
+    b += ["  " + ln for ln in factor()]
+    b.append("}")
+  # kk <- (L D U)^-1 Gt: the factor by broadcast reads
+  for i in range(1, Z):
+    b.append(f"kk[{i}] -= " + " + ".join(f"sS[{i * Z + kq}]*kk[{kq}]" for kq in range(i)) + ";")
+  for i in range(Z - 1, -1, -1):
+    tail = "".join(f" - sS[{i * Z + kq}]*kk[{kq}]" for kq in range(i + 1, Z))
+    b.append(f"kk[{i}] = kk[{i}]*sS[{ZZ + i}]{tail};")
+  b.append("const double dxc = " + " + ".join(f"kk[{zi}]*sl[{lay.OFF_Y + zi}]" for zi in range(Z)) + ";")
+  for j in range(E):
+    b.append(f"row[{j}] -= " + " + ".join(f"kk[{zi}]*sG[{zi * E + j}]" for zi in range(Z)) + ";")
+  for zi in range(Z):
+    c = sum_terms(term(cf, f"row[{j}]") for j, cf in Hs.row_nz(zi))
+    kr = " + ".join(f"kk[{w}]*gR[{w * Z + zi}]" for w in range(Z))
+    b.append(f"const double Dm_{zi} = rs*({kr}) - ({c});")
+  b.append("if (act) { " + " ".join(f"sK[{zi} * {E} + cc] = kk[{zi}];" for zi in range(Z)) + f" sw[{lay.OFF_DX} + cc] = dxc; if (cc == 0) sw[{lay.OFF_FL}] = (double)gated; }}")
+  b.append("rn::wave_lds_sync();")
+  for j in range(E):
+    b.append(f"row[{j}] += " + " + ".join(f"Dm_{zi}*sK[{zi * E + j}]" for zi in range(Z)) + ";")
+  b += ["if (act) {", "#pragma unroll", f"  for (int j = 0; j < {E}; j++) sP[cc * {E} + j] = row[j];", "}", "rn::wave_lds_sync();"]
+  return b
+
+
 def _lean_update(k, Hs, lay, E, rows_in_regs=False):
   """Update with the Joseph correction Dm = K R - B He^T formed from Gt - K (He P He^T) (the same quantity, B = P - K G
   never materialised), only the columns of P that He touches read, and ONE pass over the lane's row:
@@ -437,6 +543,8 @@ def device_functions(spec, lay_cls=None, sfx=""):
       b = _lean_update(k, Hs, lay, E)
     elif k.He_sym is not None:
       b = _lean_update(k, Hs, lay, E, rows_in_regs=True)
+    elif Z >= WIDE_Z_LDS:
+      b = _wide_obs_update(k, Hs, lay, E)
     else:
       b = [f"double row[{E}], R[{Z * Z}];", "#pragma unroll", f"for (int j = 0; j < {E}; j++) row[j] = sP[cc * {E} + j];"]
       b += [f"double col[{E}];", "#pragma unroll", f"for (int kq = 0; kq < {E}; kq++) col[kq] = sP[kq * {E} + cc];"]
@@ -468,8 +576,9 @@ def device_functions(spec, lay_cls=None, sfx=""):
       for j in range(E):
         b.append(f"row[{j}] += " + " + ".join(f"Dm_{zi}*sK[{zi * E + j}]" for zi in range(Z)) + ";")
       b += ["if (act) {", "#pragma unroll", f"  for (int j = 0; j < {E}; j++) sP[cc * {E} + j] = row[j];", "}", "rn::wave_lds_sync();"]
+    ss_arg = ", double* sS" if wide_z(k) and lean != 1 and k.He_sym is None else ""
     out.append("\n".join([f"__device__ {INL} void mat_update_{k.kind}(double* sP, const double* __restrict__ gR, const double* sl, double* sw, "
-                          "double* sG, double* sK, const int cc, const bool act) {"] + _ind(b) + ["}"]))
+                          f"double* sG, double* sK{ss_arg}, const int cc, const bool act) {{"] + _ind(b) + ["}"]))
   return "\n".join(out).replace("{INL}", INL), lay
 
 
@@ -493,6 +602,7 @@ def kernels(spec):
     upd = k is not None
     Z = k.zdim if upd else 1
     ZZ = Z * Z
+    wide_s = upd and wide_z(k) and tune.wide_lean != 1 and k.He_sym is None
     tmpl = "template <bool DO_PREDICT>\n" if upd else ""
     dop = "DO_PREDICT" if upd else "true"
     sig_obs = ("double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const double* __restrict__ gea,\n    "
@@ -518,6 +628,8 @@ def kernels(spec):
       A(f"  __shared__ __attribute__((aligned(16))) double s_z[FT2 * {Z} + 2];")
       A(f"  __shared__ __attribute__((aligned(16))) double s_G[{FPW} * {Z * E}];")
       A(f"  __shared__ __attribute__((aligned(16))) double s_K[{FPW} * {Z * E}];")
+      if wide_s:
+        A(f"  __shared__ __attribute__((aligned(16))) double s_S[{FPW} * {wide_s_doubles(k)}];      // the wide kind's innovation covariance, factored in place (_wide_obs_update)")
     A("  __shared__ __attribute__((aligned(16))) double s_sl[FT2 * SLOT];")
     A("  const int lane = threadIdx.x;")
     A(f"  const int g = lane / {GL};")
@@ -560,7 +672,9 @@ def kernels(spec):
     A("    if (lane < cnt) {")
     A("      double* sl = s_sl + lane * SLOT;")
     A("      if (do_pred) {")
-    A("        const double dt = gdt != nullptr ? gdt[base + lane] : dt_scalar;")
+    A("        int ld_ = lane;")
+    A('        asm volatile("" : "+v"(ld_));      // (the address gdt + lane is otherwise formed at the kernel\'s entry and kept -- in scratch, where registers are short -- for this one use)')
+    A("        const double dt = gdt != nullptr ? gdt[base + ld_] : dt_scalar;")
     A(f"        scal_predict(s_x + lane * {D}, dt, sl, norm_quats);")
     A("      } else {")
     A(f"        scal_keep(s_x + lane * {D}, sl, {dop} ? norm_quats : 0);      // predict(dt = 0) still renormalises")
@@ -608,7 +722,8 @@ def kernels(spec):
     A(f"      if (do_pred) mat_predict(sPc + gg * {EE}, qcol, sl, cc, on);")
     TL("5 + 4 * p")
     if upd:
-      A(f"      mat_update_{k.kind}(sPc + gg * {EE}, r_per_filter ? gR + (base + {FPW} * p + gg) * {ZZ} : gR, sl, sl, s_G + gg * {Z * E}, s_K + gg * {Z * E}, cc, on);")
+      ss_ = f", s_S + gg * {wide_s_doubles(k)}" if wide_s else ""
+      A(f"      mat_update_{k.kind}(sPc + gg * {EE}, r_per_filter ? gR + (base + {FPW} * p + gg) * {ZZ} : gR, sl, sl, s_G + gg * {Z * E}, s_K + gg * {Z * E}{ss_}, cc, on);")
     TL("6 + 4 * p")
     A(f"      rn::copy_l2g_any<{PBUF}>(gPp, pcnt * {EE}, sPb, sh, lane);" if ODD else f"      rn::copy_l2g<{PBUF}>(gPp, pcnt * {EE}, sPb, lane);")
     TL("7 + 4 * p")

@@ -106,6 +106,24 @@ def test_step_kernels_do_not_spill(gen_dir, name):
       assert v["scratch"] == 0, f"{name}: {k} uses scratch memory ({v})"
 
 
+def test_no_generated_library_touches_scratch_memory(gen_dir):
+  """Every library that __graft_entry__.build() generated, not only the BASELINE / example models above: no kernel of any of them uses
+  scratch memory -- the 10-state test model with a 9-dimensional observation kind included (its innovation covariance is factored in LDS
+  since round 5: emit_wide2._wide_obs_update; it shipped with 516 B of scratch per lane before) and the 36-state MSCKF model.  (Spills
+  into accumulation registers -- the fused runs of the dense 17- / 24- / 40-state test models -- cost moves, not memory accesses.)"""
+  import glob
+  files = sorted(glob.glob(os.path.join(gen_dir, "*.kernels.txt")))
+  assert len(files) >= 6, files
+  for fn in files:
+    with open(fn, encoding="utf-8") as f:
+      for line in f:
+        if line.startswith("#") or line.startswith("kernel"):
+          continue
+        parts = line.split()
+        if parts[0].startswith("k_"):
+          assert int(parts[3]) == 0, f"{os.path.basename(fn)}: {parts[0]} uses {parts[3]} B of scratch per lane"
+
+
 def test_loader_backends(gen_dir):
   """load_code binds the same prototypes through either backend: cffi when importable (what the reference uses), ctypes
   otherwise or on request.  BatchedEKF always asks for ctypes (it passes ctypes pointers); a forced "cffi" without cffi
