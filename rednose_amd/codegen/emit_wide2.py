@@ -380,9 +380,11 @@ def _lean_update(k, Hs, lay, E, rows_in_regs=False):
   return b
 
 
-def device_functions(spec, lay_cls=None, sfx=""):
+def device_functions(spec, lay_cls=None, sfx="", xreg=False):
   """Phase functions of the three-phase kernels -> (text, slot layout).  With `lay_cls` / `sfx` only the scalar phases are
-  emitted, against another slot layout and under suffixed names (the fused run keeps a more compact slot, emit_wide3)."""
+  emitted, against another slot layout and under suffixed names (the fused run keeps a more compact slot, emit_wide3).
+  xreg=True: the state is not in the slot at all -- every function takes it as an array of the calling lane (emit_run2: the
+  scalar wavefront carries x in registers from step to step)."""
   D, E = spec.dim_x, spec.dim_err
   INL = "__forceinline__" if tuning.current().wide_inline else "__noinline__"
   pst, pstruct, F, f_vars = _lowered_predict(spec)
@@ -416,12 +418,14 @@ def device_functions(spec, lay_cls=None, sfx=""):
     b.append(f"x[{i}] = xn_{i};" if kind == 'expr' else f"x[{i}] = {float(val)!r};")
   b.append(normq)
   b.append(f"sl[{lay.OFF_DT}] = dt;")
-  b += ["#pragma unroll", f"for (int i = 0; i < {D}; i++) sl[{lay.OFF_X} + i] = x[i];"]
-  out.append("\n".join(["__device__ {INL} void scal_predict" + sfx + "(const double* xin, const double dt, double* sl, const int norm_quats) {"] + _ind(b) + ["}"]))
+  xw = "xin[i]" if xreg else f"sl[{lay.OFF_X} + i]"      # where the new state goes
+  xarg = "double* xin" if xreg else "const double* xin"
+  b += ["#pragma unroll", f"for (int i = 0; i < {D}; i++) {xw} = x[i];"]
+  out.append("\n".join(["__device__ {INL} void scal_predict" + sfx + f"({xarg}, const double dt, double* sl, const int norm_quats) {{"] + _ind(b) + ["}"]))
 
   b = [f"double x[{D}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = xin[i];", normq,
-       "#pragma unroll", f"for (int i = 0; i < {D}; i++) sl[{lay.OFF_X} + i] = x[i];"]
-  out.append("\n".join(["__device__ {INL} void scal_keep" + sfx + "(const double* xin, double* sl, const int norm_quats) {"] + _ind(b) + ["}"]))
+       "#pragma unroll", f"for (int i = 0; i < {D}; i++) {xw} = x[i];"] + (["(void)sl;"] if xreg else [])
+  out.append("\n".join(["__device__ {INL} void scal_keep" + sfx + f"({xarg}, double* sl, const int norm_quats) {{"] + _ind(b) + ["}"]))
 
   # ---- phase 1: scalars of each observation kind ---------------------------------------------------
   for k in spec.kinds:
@@ -429,7 +433,8 @@ def device_functions(spec, lay_cls=None, sfx=""):
     Z = k.zdim
     EA = ea_dim(k)
     feat = k.He_sym is not None
-    b = [f"double x[{D}], z[{Z}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = sl[{lay.OFF_X} + i];",
+    xr_ = "xr[i]" if xreg else f"sl[{lay.OFF_X} + i]"
+    b = [f"double x[{D}], z[{Z}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = {xr_};",
          "#pragma unroll", f"for (int i = 0; i < {Z}; i++) z[i] = zin[i];"]
     if EA:
       b += [f"double ea[{EA}];", "#pragma unroll", f"for (int i = 0; i < {EA}; i++) ea[i] = eain[i];"]
@@ -462,7 +467,7 @@ def device_functions(spec, lay_cls=None, sfx=""):
             f"    for (int c = 0; c < {Zp}; c++) sl[{lay.OFF_RP} + a * {Zp} + c] = Rm[({EADIM} + a) * {Z} + {EADIM} + c];", "  }",
             "} else {", "#pragma unroll", f"  for (int i = 0; i < {Z}; i++) sl[{lay.OFF_Y} + i] = y[i];", "}"]
     tmpl = "template <bool PROJECT>\n" if feat else ""
-    sig = "double* sl, const double* zin" + (", const double* eain" if EA else "") + (", const double* gRf" if feat else "")
+    sig = ("const double* xr, " if xreg else "") + "double* sl, const double* zin" + (", const double* eain" if EA else "") + (", const double* gRf" if feat else "")
     out.append("\n".join([f"{tmpl}__device__ {{INL}} void scal_obs_{k.kind}{sfx}({sig}) {{"] + _ind(b) + ["}"]))
 
   # ---- phase 3: error injection ----------------------------------------------------------------------
@@ -473,7 +478,7 @@ def device_functions(spec, lay_cls=None, sfx=""):
   for i in range(D):
     eblk.add(f"xi_{i}", sp.Matrix(spec.err_eqs[0])[i])
   estmts, est = eblk.lower()
-  b = [f"double x[{D}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = sl[{lay.OFF_X} + i];"]
+  b = [f"double x[{D}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = " + ("xout[i];" if xreg else f"sl[{lay.OFF_X} + i];")]
   b += list(estmts)
   for i in range(D):
     kind, val = est[f"xi_{i}"]

@@ -92,6 +92,14 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Rendezvous of a workgroup's wavefronts that exchange data through LDS ONLY (the two-wavefront fused run, codegen/emit_run2.py):
+// this wavefront's LDS traffic has completed, then s_barrier.  Deliberately not __syncthreads(): its workgroup-scope release also
+// waits for vmcnt(0), i.e. for every store the wavefront has in flight -- the fused run's covariance trace (32 KB per step) would
+// be drained at every barrier.
+__device__ __forceinline__ void wg_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Forces `v` to exist in registers at this point of the instruction stream (an empty volatile asm that "modifies" it):
 // arithmetic producing v cannot sink below, arithmetic consuming it cannot rise above.  No instruction is emitted.
 __device__ __forceinline__ void pin(double& v) { asm volatile("" : "+v"(v)); }
