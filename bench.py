@@ -493,8 +493,9 @@ def config4_extra(torch, dev, rank, nb=16384, T=2100, chunk=8192):
     with open(os.path.join(gen, "live_maha.kernels.txt"), encoding="utf-8") as fh:
       kt = fh.read()
       rts_kernel = "k_rts4" if "k_rts4" in kt else ("k_rts3" if "k_rts3" in kt else "rn::k_rts_group")
+      run_kernel = "k_run2" if "k_run2 " in kt else "k_run"
   except OSError:
-    rts_kernel = "k_rts*"
+    rts_kernel, run_kernel = "k_rts*", "k_run*"
   fwd_bytes = nb * T * 8.0 * ((23 + 484) + 2 * 3) + nb * T           # filtered trace written, z read, y written, flags
   bwd_bytes = nb * (T - 1) * 8.0 * 2 * (23 + 484)                     # filtered pair read, smoothed pair written
   return {"batch": nb, "T": T, "chunk_filters": chunk,
@@ -502,7 +503,7 @@ def config4_extra(torch, dev, rank, nb=16384, T=2100, chunk=8192):
           "combined_steps_per_s": nb * T / ((res["fwd_ms"] + res["bwd_ms"]) * 1e-3),
           "forward_ms": res["fwd_ms"], "backward_ms": res["bwd_ms"], "gated_fraction_of_gnss": res["gated"],
           "trace_bytes_per_chunk": int(T * chunk * (23 + 484) * 8),
-          "roofline_forward": hbm_roofline(fwd_bytes, res["fwd_ms"] * 1e-3, "k_run (trace + gate flags)", traffic=chunk_traffic("config4_forward")),
+          "roofline_forward": hbm_roofline(fwd_bytes, res["fwd_ms"] * 1e-3, f"{run_kernel} (trace + gate flags)", traffic=chunk_traffic("config4_forward")),
           "roofline_backward": hbm_roofline(bwd_bytes, res["bwd_ms"] * 1e-3, rts_kernel, traffic=chunk_traffic("config4_backward")),
           "note": "forward = fused batch_run writing the filtered trace + gate flags; backward = batch_rts recomputing the predicted pairs; "
                   "bytes: forward 4 104 B + 1 flag per filter-step, backward 8 112 B per filter-step"}

@@ -31,9 +31,10 @@ SMALL_MAX_E = 7    # lane-per-filter register budget: x, P and the update's temp
 #   no_rts4            the smoother with register-broadcast operands (emit_rts4, two wavefronts per SIMD) spilled -> emit_rts3
 #   no_rts3            the smoother in the fused run's layout (emit_rts3) spilled -> rn::k_rts_group
 #   no_run_blk         the blocked fused run of a lane-per-filter model (emit_small.run_kernel_blk) spilled -> k_run serves untraced runs too
+#   no_run2            the fused run with a scalar wavefront beside the matrix wavefront (emit_run2, two wavefronts per SIMD) spilled -> k_run (emit_wide3)
 #   no_run             the fused multi-step run of a model above 32 error states touches scratch -> library without batch_run
 #                      (status ERR_UNSUPPORTED, the step-granular entry points cover such models)
-FALLBACKS = ("force_wide", "no_model_defaults", "no_rts4", "no_rts3", "rts_one_wave", "no_rts", "no_run", "no_run_blk")
+FALLBACKS = ("force_wide", "no_model_defaults", "no_rts4", "no_rts3", "rts_one_wave", "no_rts", "no_run2", "no_run", "no_run_blk")
 _active = frozenset()      # fallbacks of the emit() call in progress
 
 
@@ -110,7 +111,8 @@ def _emit(spec):
   import types
   from rednose_amd.codegen import tuning
   if fam == "wide":
-    from rednose_amd.codegen import emit_wide2, emit_wide3
+    from rednose_amd.codegen import emit_run2, emit_wide2, emit_wide3
+    use_run2 = has_run and tuning.current().run2 and "no_run2" not in _active and emit_run2.applicable(spec)
     if not has_run:
       fam_mod = types.SimpleNamespace(
         kernels=lambda sp_: emit_wide2.kernels(sp_) + "\n" + emit_wide2.maha_kernels(sp_),
@@ -120,8 +122,10 @@ def _emit(spec):
       # step-granular kernels: three-phase structure (emit_wide2); fused multi-step run: state resident in registers, several
       # rows of P per lane (emit_wide3)
       fam_mod = types.SimpleNamespace(
-        kernels=lambda sp_: emit_wide2.kernels(sp_) + "\n" + emit_wide3.kernels(sp_) + "\n" + emit_wide2.maha_kernels(sp_),
-        launch_predict=emit_wide2.launch_predict, launch_step=emit_wide2.launch_step, launch_run=emit_wide3.launch_run,
+        kernels=lambda sp_: emit_wide2.kernels(sp_) + "\n" + emit_wide3.kernels(sp_, with_run=not use_run2) + "\n" +
+                            (emit_run2.kernels(sp_) + "\n" if use_run2 else "") + emit_wide2.maha_kernels(sp_),
+        launch_predict=emit_wide2.launch_predict, launch_step=emit_wide2.launch_step,
+        launch_run=emit_run2.launch_run if use_run2 else emit_wide3.launch_run,
         launch_maha=emit_wide2.launch_maha)
   else:
     fam_mod = types.SimpleNamespace(

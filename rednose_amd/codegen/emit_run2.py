@@ -34,6 +34,7 @@ tests/test_emit_host.py runs the kernel on the host with a thread per lane of bo
 Reference: EKF_sym.predict_and_update_batch's loop body, ekf_sym.py:473-538, over a schedule; ekf_c.c:8-121.
 """
 from rednose_amd.codegen import emit_wide3 as w3
+from rednose_amd.codegen.emit_common import term, sum_terms
 
 LDS_BUDGET = 40960      # bytes per workgroup for four workgroups per CU (160 KB)
 
@@ -62,7 +63,7 @@ def lds_bytes(spec):
   _, _, FPW = w3.layout(spec)
   lay, _, _ = w3._tables(spec, Run2Layout)      # pylint: disable=protected-access
   zmax = max(k.zdim for k in spec.kinds)
-  return 8 * (FPW * E * E + 2 + FPW * zmax * E + FPW * lay.SLOT) + 16
+  return 8 * (FPW * E * E + 2 + FPW * zmax * E + FPW * lay.SLOT + E + (E & 1)) + 16
 
 
 def applicable(spec):
@@ -72,19 +73,173 @@ def applicable(spec):
   zmax = max(k.zdim for k in spec.kinds)
   plain = all(k.He_sym is None and k.ea_sym is None for k in spec.kinds)
   from rednose_amd.codegen import tuning
-  return GL == 8 and plain and spec.N == 0 and FPW * zmax <= 64 and lds_bytes(spec) <= LDS_BUDGET and not tuning.current().wide_timeline
+  return GL == 8 and plain and spec.N == 0 and FPW * zmax <= 64 and lds_bytes(spec) <= LDS_BUDGET
+
+
+JB = 2            # columns per block of the rank-Z passes (emit_wide3 runs 4 with a 512-register budget; here the budget is 256)
+CH = 8            # entries of a row of A = P F^T formed per block of predict's first half
+
+
+def _ind(lines, n=2):
+  pad = " " * n
+  return [pad + x for x in lines]
+
+
+def _tl(ph, base="tlb"):
+  """Debug stamp (tuning knob wide_timeline; tools/timeline.py run2): slot `base` + ph of the workgroup's timeline, lane 0 of the calling wavefront."""
+  from rednose_amd.codegen import tuning
+  if not tuning.current().wide_timeline:
+    return []
+  return [f"if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) {{ const int ti_ = {base} + {ph}; g_tl[(blockIdx.x * 64 + ti_) * 2] = __builtin_readcyclecounter(); "
+          "g_tl[(blockIdx.x * 64 + ti_) * 2 + 1] = wall_clock64(); }"]
+
+
+def _tl_on():
+  from rednose_amd.codegen import tuning
+  return bool(tuning.current().wide_timeline)
+
+
+def predict_fn(spec):
+  """emit_wide3.predict_fn's algebra (one transposition through the LDS image, P = P^T), ONE body for both kinds of process
+  noise -- the lane's diagonal entries of Q are register operands, the rows of a non-diagonal Q are added from HBM / L2 afterwards
+  (`qdiag` false: rare) -- and in blocks of CH entries closed by a fence, so that the broadcast reads of F's entries stay
+  inside their block: two inlined alternatives of this function, or one whose coefficient reads hipcc may hoist, do not fit 256
+  registers beside the 132 of the rows."""
+  E = spec.dim_err
+  GL, R, _ = w3.layout(spec)
+  lay, Fs, _ = w3._tables(spec, Run2Layout)      # pylint: disable=protected-access
+  b = [f"const double dt = sl[{lay.OFF_DT}];"]
+  for s_ in range(R):
+    for c0 in range(0, E, CH):
+      cols = list(range(c0, min(c0 + CH, E)))
+      b.append("{")
+      b.append(f"  double a[{len(cols)}];")
+      for i in cols:
+        b.append(f"  a[{i - c0}] = {sum_terms(term(cf, f'row{s_}[{k}]') for k, cf in Fs.row_nz(i))};")
+      b += [f"  if (ok{s_}) {{", "#pragma unroll", f"    for (int i = 0; i < {len(cols)}; i++) sP[rr{s_} * {E} + {c0} + i] = a[i];", "  }"]
+      b.append("}")
+      b.append("rn::wave_lds_sync();")
+  for s_ in range(R):
+    b.append(f"int rd{s_} = rc{s_};")
+    b.append(f'asm volatile("" : "+v"(rd{s_}));      // the diagonal selects below are computed here: as loop invariants they are {min(GL, E - GL * s_)} SGPR pairs per slot, across the whole step loop')
+    b.append(f"const double dq{s_} = dt * sQd[rd{s_}];      // diag(Q) is the same for every filter: {E} doubles of LDS instead of {R} registers per lane across the step loop")
+    # column of A = row of B, fetched per block of outputs (only the entries that block's rows of F touch): the whole column at once is
+    # 44 registers that stay live through the slot
+    for c0 in range(0, E, CH):
+      outs = list(range(c0, min(c0 + CH, E)))
+      need = sorted({m for j in outs for m, _ in Fs.row_nz(j)})
+      b.append("{")
+      for m in need:
+        b.append(f"  const double a_{m} = sP[{m} * {E} + rc{s_}];")
+      for j in outs:
+        diag = f" + (rd{s_} == {j} ? dq{s_} : 0.0)" if GL * s_ <= j < GL * (s_ + 1) else ""
+        b.append(f"  row{s_}[{j}] = {sum_terms(term(cf, f'a_{m}') for m, cf in Fs.row_nz(j))}{diag};")
+      b.append("}")
+      b.append("rn::wave_lds_sync();")
+  b.append("rn::wave_lds_sync();      // the image is free again")
+  b.append("if (!qdiag) {")
+  for s_ in range(R):
+    for c0 in range(0, E, CH):      # (in blocks: 66 loads in flight at once are 132 registers)
+      for j in range(c0, min(c0 + CH, E)):
+        b.append(f"  {{ const double q_ = gQ[rc{s_} * {E} + {j}]; row{s_}[{j}] += dt * ((rc{s_} == {j}) ? 0.0 : q_); }}")
+      b.append("  rn::wave_lds_sync();")
+  b.append("}")
+  rows = ", ".join(f"double (&row{s_})[{E}]" for s_ in range(R))
+  idx = ", ".join(f"const int rr{s_}, const int rc{s_}, const bool ok{s_}" for s_ in range(R))
+  head = f"__device__ __forceinline__ void predict_rows_r2({rows}, double* sP, const double* sQd, const double* __restrict__ gQ, const bool qdiag, const double* sl, {idx}) {{"
+  return "\n".join([head] + _ind(b) + ["}"])
+
+
+def update_fn(spec):
+  """emit_wide3.update_fn's Joseph-form update for ALL kinds in one body: the kind-specific parts -- the three sparse products with
+  He = H H_mod -- sit in three small switches, everything else (S, its factor, the gate, the gain, both rank-Z passes) exists once,
+  at the model's largest observation dimension ZM: a kind with fewer rows is padded with zero rows of He and an identity block of
+  R, which adds exact zeros to the sums of the unpadded form.  (Eight inlined update bodies in one switch, as in k_run, cost hipcc
+  ~200 spilled registers at a 256-register budget although each body alone fits: the row set is live across the switch.)
+  dx and the flags leave for the slot as soon as the gain exists, followed by the workgroup barrier the scalar wavefront waits at;
+  a second barrier (`he_release`) after the Joseph coefficients tells it that He and y are dead."""
+  E = spec.dim_err
+  _, R, _ = w3.layout(spec)
+  lay, _, Hss = w3._tables(spec, Run2Layout)      # pylint: disable=protected-access
+  ZM = lay.zmax
+  b = ["(void)sP;"]
+  for s_ in range(R):
+    b.append(f"double kk{s_}[{ZM}] = {{{', '.join('0.0' for _ in range(ZM))}}};")
+  b += ["int zk = 0;", "double thr = 0.0;", "bool gate_on = false;"]
+  # G^T = P He^T, row-local (P = P^T): the lane that owns row j has column j of G
+  b.append("switch (kind) {")
+  for k in spec.kinds:
+    Hs, Z = Hss[k.kind], k.zdim
+    ln = [f"kk{s_}[{zi}] = {sum_terms(term(cf, f'row{s_}[{c}]') for c, cf in Hs.row_nz(zi))};" for s_ in range(R) for zi in range(Z)]
+    ln.append(f"zk = {Z};" + (f" thr = {k.maha_thresh!r}; gate_on = true;" if k.maha_test else ""))
+    b.append(f"  case {k.kind}: {{ " + " ".join(ln) + " break; }")
+  b += ["  default: break;", "}"]
+  for s_ in range(R):
+    b.append(f"if (ok{s_}) {{ " + " ".join(f"sG[{zi} * {E} + rr{s_}] = kk{s_}[{zi}];" for zi in range(ZM)) + " }")
+  b.append("rn::wave_lds_sync();")
+  b += _tl(3)
+  ident = ", ".join("1.0" if i // ZM == i % ZM else "0.0" for i in range(ZM * ZM))
+  b.append(f"double HPH[{ZM * ZM}] = {{{', '.join('0.0' for _ in range(ZM * ZM))}}}, Rl[{ZM * ZM}] = {{{ident}}}, S[{ZM * ZM}], L[{ZM * ZM}], iL[{ZM}];")
+  b.append("switch (kind) {")
+  for k in spec.kinds:
+    Hs, Z = Hss[k.kind], k.zdim
+    ln = [f"HPH[{zi * ZM + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))};" for zi in range(Z) for w in range(Z)]
+    ln += [f"Rl[{zi * ZM + w}] = gR[{zi * Z + w}];" for zi in range(Z) for w in range(Z)]
+    b.append(f"  case {k.kind}: {{ " + " ".join(ln) + " break; }")
+  b += ["  default: break;", "}"]
+  b += ["#pragma unroll", f"for (int i = 0; i < {ZM * ZM}; i++) S[i] = HPH[i] + Rl[i];", f"rn::spd_factor<{ZM}>(S, L, iL);", "int gated = 0;",
+        f"const double yv[{ZM}] = {{{', '.join(f'zk > {i} ? sl[{lay.OFF_Y + i}] : 0.0' for i in range(ZM))}}};"]
+  if any(k.maha_test for k in spec.kinds):
+    b += ["if (gate_on) {", f"  double v[{ZM}] = {{{', '.join(f'yv[{i}]' for i in range(ZM))}}};", f"  rn::spd_forward<{ZM}>(L, iL, v);",
+          "  const double d2 = " + " + ".join(f"v[{i}]*v[{i}]*iL[{i}]" for i in range(ZM)) + ";", "  if (d2 > thr) {", "    gated = 1;",
+          "#pragma unroll", f"    for (int i = 0; i < {ZM * ZM}; i++) {{ Rl[i] = 1.0e16 * Rl[i]; S[i] = HPH[i] + Rl[i]; }}",
+          f"    rn::spd_factor<{ZM}>(S, L, iL);", "  }", "}"]
+  else:
+    b.append("(void)thr; (void)gate_on;")
+  for s_ in range(R):
+    b.append(f"rn::spd_solve<{ZM}>(L, iL, kk{s_});                       // K[row][:]")
+    b.append(f"const double dx{s_} = " + " + ".join(f"kk{s_}[{zi}]*yv[{zi}]" for zi in range(ZM)) + ";")
+  for s_ in range(R):
+    b.append(f"if (ok{s_}) {{ sw[{lay.OFF_DX} + rr{s_}] = dx{s_};" + (f" if (rr{s_} == 0) sw[{lay.OFF_FL}] = (double)gated;" if s_ == 0 else "") + " }")
+  b += _tl(4)
+  b.append("rn::wg_barrier();      // B3: dx, flags -> the scalar wavefront")
+  b += _tl(5)
+  b += w3._rank_pass(E, ZM, R, "sG", "-=", "kk", JB=JB)      # pylint: disable=protected-access
+  b += _tl(6)
+  for s_ in range(R):
+    b.append(f"double cc{s_}[{ZM}] = {{{', '.join('0.0' for _ in range(ZM))}}};")
+  b.append("switch (kind) {")
+  for k in spec.kinds:
+    Hs, Z = Hss[k.kind], k.zdim
+    ln = [f"cc{s_}[{zi}] = {sum_terms(term(cf, f'row{s_}[{j}]') for j, cf in Hs.row_nz(zi))};" for s_ in range(R) for zi in range(Z)]
+    b.append(f"  case {k.kind}: {{ " + " ".join(ln) + " break; }")
+  b += ["  default: break;", "}"]
+  for s_ in range(R):
+    b.append(f"double Dm{s_}[{ZM}];")
+    for zi in range(ZM):
+      kr = " + ".join(f"kk{s_}[{w}]*Rl[{w * ZM + zi}]" for w in range(ZM))
+      b.append(f"Dm{s_}[{zi}] = ({kr}) - (cc{s_}[{zi}]);")
+  b.append("if (he_release) rn::wg_barrier();      // B4: He, y are dead -- the scalar wavefront may evaluate the next step's observation")
+  b += _tl(7)
+  b.append("rn::wave_lds_sync();      // every lane has taken G: the buffer takes K^T")
+  for s_ in range(R):
+    b.append(f"if (ok{s_}) {{ " + " ".join(f"sG[{zi} * {E} + rr{s_}] = kk{s_}[{zi}];" for zi in range(ZM)) + " }")
+  b.append("rn::wave_lds_sync();")
+  b += w3._rank_pass(E, ZM, R, "sG", "+=", "Dm", JB=JB)      # pylint: disable=protected-access
+  b.append("rn::wave_lds_sync();      // the broadcast buffer is free again")
+  rows = ", ".join(f"double (&row{s_})[{E}]" for s_ in range(R))
+  idx = ", ".join(f"const int rr{s_}, const int rc{s_}, const bool ok{s_}" for s_ in range(R))
+  head = (f"__device__ __forceinline__ void update_rows_r2(const int kind, {rows}, const double* __restrict__ gR, double* sP, "
+          f"double* sG, const double* sl, double* sw, {idx}, const bool he_release{', const int tlb' if _tl_on() else ''}) {{")
+  return "\n".join([head] + _ind(b) + ["}"])
 
 
 def kernels(spec):
-  """Scalar phase functions against Run2Layout (suffix _r2, x as a register array), the matrix functions of emit_wide3 against it, k_run2."""
+  """Scalar phase functions against Run2Layout (suffix _r2, x as a register array), the matrix functions, k_run2."""
   from rednose_amd.codegen import emit_wide2 as w2
   scal_text, lay = w2.device_functions(spec, lay_cls=Run2Layout, sfx="_r2", xreg=True)
-  out = [f"constexpr int SLOT_R2 = {lay.SLOT};   // two-wavefront fused run: doubles per scalar slot", "", scal_text, "",
-         w3.predict_fn(spec, lay_cls=Run2Layout, sfx="_r2"), w3.predict_fn(spec, qdiag=True, lay_cls=Run2Layout, sfx="_r2")]
-  for k in spec.kinds:
-    out.append(w3.update_fn(spec, k, lay_cls=Run2Layout, sfx="_r2", two_wave=True))
-  out.append(run_kernel(spec))
-  return "\n".join(out)
+  return "\n".join([f"constexpr int SLOT_R2 = {lay.SLOT};   // two-wavefront fused run: doubles per scalar slot", "", scal_text, "",
+                    predict_fn(spec), update_fn(spec), run_kernel(spec)])
 
 
 def run_kernel(spec):
@@ -98,21 +253,23 @@ def run_kernel(spec):
   idx = ", ".join(f"rr{s}, rc{s}, ok{s}" for s in range(R))
   nlc = chr(10)
   scal_cases = nlc.join(f"          case {k.kind}: scal_obs_{k.kind}_r2(xr, sl, sl + {lay.OFF_Y}); break;" for k in spec.kinds)
-  # every case works on its own opaque copies of the slot / buffer addresses: identical loads in all cases (y, R, the rows of G) would
-  # otherwise be hoisted in front of the switch and live across it -- each kind alone fits 256 registers, all of them together spilled
-  mat_cases = nlc.join(f"            case {k.kind}: {{ double* slk = sl; double* sGk = s_G + gg * {zmax * E}; const double* gRk = gR + t * {zmax * zmax}; "
-                       'asm volatile("" : "+v"(slk), "+v"(sGk), "+s"(gRk)); '
-                       f"update_{k.kind}_rows_r2({rows}, gRk, sP, sGk, slk, slk, {idx}, he_release); done = true; break; }}"
-                       for k in spec.kinds)
+  known = " || ".join(f"kind == {k.kind}" for k in spec.kinds)
   img = nlc.join(f"        if (ok{s}) {{\n#pragma unroll\n          for (int j = 0; j < {E}; j++) sP[rr{s} * {E} + j] = row{s}[j];\n        }}" for s in range(R))
   id0_guard = "true" if not spec.identity_at_dt0() else "dt != 0.0"
   id0_next = "true" if not spec.identity_at_dt0() else "dtn != 0.0"
   nt_trace = "true" if tuning.current().nt_trace else "false"
-  qd_decl = nlc.join(f"  const double qd{s} = gQ[((c + {GL * s}) < {E} ? (c + {GL * s}) : 0) * {E + 1}];" for s in range(R))
-  qd_args = ", ".join(f"qd{s}" for s in range(R))
+  prio = f"    __builtin_amdgcn_s_setprio({int(tuning.current().run2_prio)});      // a chain of dependent instructions: whenever one is ready it goes first\n" if tuning.current().run2_prio else ""
   decl_rows = nlc.join(f"      double row{s}[{E}];" for s in range(R))
-  decl_idx = nlc.join(f"      const int rr{s} = c + {GL * s}; const bool ok{s} = live && rr{s} < {E}; const int rc{s} = rr{s} < {E} ? rr{s} : 0;" for s in range(R))
+  # row indices from an opaque copy of the lane's position, per scope: as loop invariants they (and every LDS address derived from them)
+  # would hold a dozen registers across the step loop
+  def decl_idx_at(ind):
+    return nlc.join([ind + "int cq = c;", ind + 'asm volatile("" : "+v"(cq));'] +
+                    [ind + f"const int rr{s} = cq + {GL * s}; const bool ok{s} = live && rr{s} < {E}; const int rc{s} = rr{s} < {E} ? rr{s} : 0;" for s in range(R)])
   load_rows = nlc.join(f"#pragma unroll\n      for (int j = 0; j < {E}; j++) row{s}[j] = 0.5 * (sP[rc{s} * {E} + j] + sP[j * {E} + rc{s}]);" for s in range(R))
+  def TL(ph, ind="        "):
+    return "".join(ind + x + nlc for x in _tl(ph))
+  tlb_decl = "        const int tlb = (int)(t % 3) * 20;\n" if _tl_on() else ""
+  tl_arg = ", tlb" if _tl_on() else ""
   stage_x = f"""if (c == 0 && live) {{
 #pragma unroll
           for (int i = 0; i < {D}; i++) sl[{lay.OFF_XS} + i] = xr[i];
@@ -128,6 +285,7 @@ __global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double
   __shared__ __attribute__((aligned(16))) double s_P[FPWR * {EE} + 2];      // one image of P per filter
   __shared__ __attribute__((aligned(16))) double s_G[FPWR * {zmax * E}];     // G, then K^T
   __shared__ __attribute__((aligned(16))) double s_sl[FPWR * SLOT_R2];
+  __shared__ double s_qd[{E + (E & 1)}];                                     // diag(Q)
   __shared__ int s_bad;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -139,7 +297,8 @@ __global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double
     int qoff = 0;
     for (int i = lane; i < {EE}; i += 64) qoff |= (i / {E} != i % {E}) && (gQ[i] != 0.0);
     const bool qdiag = !__any(qoff);
-{qd_decl}
+    if (lane < {E}) s_qd[lane] = gQ[lane * {E + 1}];
+    rn::wave_lds_sync();
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
       const int64_t base = tile * FPWR;
       const int cnt = (n - base) < FPWR ? (int)(n - base) : FPWR;
@@ -147,44 +306,34 @@ __global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double
       const bool live = g < cnt;
       double* sP = s_P + gg * {EE};
       double* sl = s_sl + gg * SLOT_R2;
-{decl_idx}
       int lb = lane;
       asm volatile("" : "+v"(lb));
       rn::copy_g2l<FPWR * {EE}>(gP + base * {EE}, cnt * {EE}, s_P, lb);
       rn::wave_lds_sync();
 {decl_rows}
+      {{
+{decl_idx_at("        ")}
 {load_rows}
+      }}
       rn::wave_lds_sync();
       rn::wg_barrier();                                   // B1 of step 0
       for (int64_t t = 0; t < T; t++) {{
         const int kind = kinds[t];
         const double dt = dts[t];
         const bool do_pred = {id0_guard};
-        bool he_release = false;                          // B4: the next step has no predict, its h / He go under this step's tail
+{decl_idx_at("        ")}
+{tlb_decl}{TL(0)}        bool he_release = false;                          // B4: the next step has no predict, its h / He go under this step's tail
         if (t + 1 < T) {{ const double dtn = dts[t + 1]; he_release = !({id0_next}); }}
-        if (do_pred) {{
-          if (qdiag) {{
-            predict_rows_qd_r2({rows}, sP, {qd_args}, sl, {idx});
-          }} else {{
-            int qz = 0;
-            asm volatile("" : "+v"(qz));
-            predict_rows_r2({rows}, sP, gQ + qz, sl, {idx});
-          }}
-        }}
-        rn::wg_barrier();                                 // B2
-        const int bad = __builtin_amdgcn_readfirstlane(s_bad);
-        bool done = false;
-        if (!bad) {{
-          switch (kind) {{
-{mat_cases}
-            default: break;
-          }}
-        }}
-        if (!done) {{
+        if (do_pred) predict_rows_r2({rows}, sP, s_qd, gQ, qdiag, sl, {idx});
+{TL(1)}        rn::wg_barrier();                                 // B2
+{TL(2)}        const int bad = __builtin_amdgcn_readfirstlane(s_bad);
+        if (!bad && ({known})) {{
+          update_rows_r2(kind, {rows}, gR + t * {zmax * zmax}, sP, s_G + gg * {zmax * E}, sl, sl, {idx}, he_release{tl_arg});
+        }} else {{
           rn::wg_barrier();                               // B3
           if (he_release) rn::wg_barrier();               // B4
         }}
-        if (tP != nullptr) {{
+{TL(8)}        if (tP != nullptr) {{
           int lz = lane;
           asm volatile("" : "+v"(lz));
 {img}
@@ -192,9 +341,12 @@ __global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double
           rn::copy_l2g<FPWR * {EE}, {nt_trace}>(tP + (t * n + base) * {EE}, cnt * {EE}, s_P, lz);
           rn::wave_lds_sync();
         }}
-        rn::wg_barrier();                                 // B1 of step t + 1
+{TL(9)}        rn::wg_barrier();                                 // B1 of step t + 1
       }}
+      {{
+{decl_idx_at("        ")}
 {img}
+      }}
       rn::wave_lds_sync();
       int le = lane;
       asm volatile("" : "+v"(le));
@@ -203,7 +355,7 @@ __global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double
     }}
   }} else {{
     // ================================ scalar wavefront ================================
-    const int zf = lane / {zmax}, zc = lane % {zmax};      // observation entry this lane carries between HBM and the slots
+{prio}    const int zf = lane / {zmax}, zc = lane % {zmax};      // observation entry this lane carries between HBM and the slots
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
       const int64_t base = tile * FPWR;
       const int cnt = (n - base) < FPWR ? (int)(n - base) : FPWR;
@@ -231,7 +383,7 @@ __global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double
       }}
       rn::wg_barrier();                                   // B1 of step 0
       for (int64_t t = 0; t < T; t++) {{
-        double zn = 0.0;                                  // next step's observation, in flight during this step
+{tlb_decl}{TL(10)}        double zn = 0.0;                                  // next step's observation, in flight during this step
         if (t + 1 < T && zlive) zn = gz[((t + 1) * n + base) * {zmax} + lane];
         const int kind = kinds[t];
         if (!obs_done) {{
@@ -246,14 +398,14 @@ __global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double
           if (lane == 0) s_bad = bad;
         }}
         rn::wave_lds_sync();
-        rn::wg_barrier();                                 // B2
-        rn::wg_barrier();                                 // B3: dx and the gate flag are in the slot
-        if (c == 0 && live) {{
+{TL(11)}        rn::wg_barrier();                                 // B2
+{TL(12)}        rn::wg_barrier();                                 // B3: dx and the gate flag are in the slot
+{TL(13)}        if (c == 0 && live) {{
           int fl = bad;
           if (!bad) fl = scal_inject_r2(sl, xr, norm_quats) | (int)sl[{lay.OFF_FL}];
           if (flags != nullptr) flags[t * n + base + g] = (uint8_t)fl;
         }}
-        if (zlive) gz[(t * n + base) * {zmax} + lane] = *slz;          // y (the observation itself after an unknown kind)
+{TL(14)}        if (zlive) gz[(t * n + base) * {zmax} + lane] = *slz;          // y (the observation itself after an unknown kind)
         rn::wave_lds_sync();
         if (tx != nullptr) {{
           {stage_x}
@@ -264,7 +416,7 @@ __global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double
         }}
         if (zlive) *slz = zn;
         rn::wave_lds_sync();
-        obs_done = false;
+{TL(15)}        obs_done = false;
         if (t + 1 < T) {{
           const double dtn = dts[t + 1];
           const bool pn = {id0_next};
@@ -273,8 +425,9 @@ __global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double
             else scal_keep_r2(xr, sl, norm_quats);
           }}
           rn::wave_lds_sync();
-          if (!pn) {{
+{TL(16, "          ")}          if (!pn) {{
             rn::wg_barrier();                             // B4: He of step t is dead
+{TL(17, "            ")}
             const int kn = kinds[t + 1];
             bad = 0;
             if (c == 0 && live) {{
@@ -289,7 +442,7 @@ __global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double
             obs_done = true;
           }}
         }}
-        rn::wg_barrier();                                 // B1 of step t + 1
+{TL(19)}        rn::wg_barrier();                                 // B1 of step t + 1
       }}
       {stage_x}
       int le = lane;

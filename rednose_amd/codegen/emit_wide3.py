@@ -32,7 +32,6 @@ import sympy as sp
 
 from rednose_amd.codegen.emit_common import term, sum_terms
 
-RUN2_JB = int(__import__('os').environ.get('RUN2_JB', '2'))      # columns per block of the rank-Z passes under emit_run2's 256-register budget
 EADIM = 3        # extra-argument dimension of feature-track kinds, hard-coded in the reference (ekf_sym.py:151)
 
 
@@ -142,7 +141,7 @@ def _tables(spec, lay_cls=None):
   return lay, Fs, Hs
 
 
-def predict_fn(spec, qdiag=False, lay_cls=None, sfx=""):
+def predict_fn(spec, qdiag=False):
   """Matrix part of predict on register rows; F's non-trivial entries are broadcast reads of the filter's slot.
 
   P' = F P F^T + dt Q with ONE transposition through LDS: rows of A = P F^T are row-local; under P = P^T the columns of A are the
@@ -157,7 +156,7 @@ def predict_fn(spec, qdiag=False, lay_cls=None, sfx=""):
   middle of a step (profiles/r3a: 11.6 us per step with the trace against 8.7 without)."""
   E = spec.dim_err
   GL, R, _ = layout(spec)
-  lay, Fs, _ = _tables(spec, lay_cls)
+  lay, Fs, _ = _tables(spec)
   b = [f"const double dt = sl[{lay.OFF_DT}];"]
   # rows of A, whole rows at a time: 16-byte LDS stores of a lane's contiguous row (entry-wise 8-byte stores at a row stride
   # collide on banks)
@@ -201,22 +200,19 @@ def predict_fn(spec, qdiag=False, lay_cls=None, sfx=""):
   idx = ", ".join(f"const int rr{s}, const int rc{s}, const bool ok{s}" for s in range(R))
   if qdiag:
     qarg = ", ".join(f"const double qd{s}" for s in range(R))
-    head = (f"__device__ __forceinline__ void predict_rows_qd{sfx}({rows}, double* sP, {qarg}, const double* sl, {idx}{_tl_arg()}) {{")
+    head = (f"__device__ __forceinline__ void predict_rows_qd({rows}, double* sP, {qarg}, const double* sl, {idx}{_tl_arg()}) {{")
   else:
-    head = (f"__device__ __forceinline__ void predict_rows{sfx}({rows}, double* sP, const double* __restrict__ gQ, const double* sl, {idx}{_tl_arg()}) {{")
+    head = (f"__device__ __forceinline__ void predict_rows({rows}, double* sP, const double* __restrict__ gQ, const double* sl, {idx}{_tl_arg()}) {{")
   return "\n".join([head] + _ind(b) + ["}"])
 
 
-def update_fn(spec, k, lay_cls=None, sfx="", two_wave=False):
+def update_fn(spec, k):
   """Matrix part of the update of kind k on register rows.  y, the non-trivial entries of He = H H_mod and, for feature-track
   kinds, the Householder reflectors and the projected noise are read from the filter's slot (phase 1 put them there); dx and
-  the gate / rank flags go back to it.
-  two_wave (emit_run2): dx and the flags leave for the slot as soon as the gain exists, followed by the workgroup barrier the
-  scalar wavefront waits at -- it injects the error state and evaluates the next step's scalars while this wavefront runs the two
-  rank-Z passes; a second barrier (`he_release`) after the Joseph coefficients tells it that He and y are dead."""
+  the gate / rank flags go back to it."""
   E, Zf = spec.dim_err, k.zdim
   _, R, _ = layout(spec)
-  lay, _, Hss = _tables(spec, lay_cls)
+  lay, _, Hss = _tables(spec)
   Hs = Hss[k.kind]
   feat = k.He_sym is not None
   Z = Zf - EADIM if feat else Zf
@@ -264,14 +260,9 @@ def update_fn(spec, k, lay_cls=None, sfx="", two_wave=False):
     if feat:     # the reference's numpy path ignores a measurement whose null-space projection failed (ekf_sym.py:589-591)
       b += ["if (rank_deficient != 0.0) {", "#pragma unroll", f"  for (int i = 0; i < {Z}; i++) kk{s}[i] = 0.0;", "}"]
     b.append(f"const double dx{s} = " + " + ".join(f"kk{s}[{zi}]*sl[{(lay.OFF_YP if feat else lay.OFF_Y) + zi}]" for zi in range(Z)) + ";")
-  fl = "(double)gated + rank_deficient" if feat else "(double)gated"
-  if two_wave:
-    for s in range(R):
-      b.append(f"if (ok{s}) {{ sw[{lay.OFF_DX} + rr{s}] = dx{s};" + (f" if (rr{s} == 0) sw[{lay.OFF_FL}] = {fl};" if s == 0 else "") + " }")
-    b.append("rn::wg_barrier();      // dx, flags -> the scalar wavefront")
   # B = P - K G: every broadcast row of G feeds all R row slots
   b += _tl(12)
-  b += _rank_pass(E, Z, R, "sG", "-=", "kk", JB=RUN2_JB if two_wave else None)
+  b += _rank_pass(E, Z, R, "sG", "-=", "kk")
   b += _tl(13)
   for s in range(R):
     if feat:
@@ -282,30 +273,33 @@ def update_fn(spec, k, lay_cls=None, sfx="", two_wave=False):
       c = f"Cf{s}[{EADIM + zi}]" if feat else sum_terms(term(cf, f"row{s}[{j}]") for j, cf in Hs.row_nz(zi))
       kr = " + ".join(f"kk{s}[{w}]*Rl[{w * Z + zi}]" for w in range(Z))
       b.append(f"Dm{s}[{zi}] = " + ("rank_deficient != 0.0 ? 0.0 : " if feat else "") + f"({kr}) - ({c});")
-  if two_wave:
-    b.append("if (he_release) rn::wg_barrier();      // He, y are dead: the scalar wavefront may evaluate the next step's observation")
   b.append("rn::wave_lds_sync();      // every lane has taken G (and y): the buffer takes K^T, the slot takes dx and the flags")
+  fl = "(double)gated + rank_deficient" if feat else "(double)gated"
   for s in range(R):
-    b.append(f"if (ok{s}) {{ " + " ".join(f"sG[{zi} * {E} + rr{s}] = kk{s}[{zi}];" for zi in range(Z)) +
-             ("" if two_wave else f" sw[{lay.OFF_DX} + rr{s}] = dx{s};" + (f" if (rr{s} == 0) sw[{lay.OFF_FL}] = {fl};" if s == 0 else "")) + " }")
+    b.append(f"if (ok{s}) {{ " + " ".join(f"sG[{zi} * {E} + rr{s}] = kk{s}[{zi}];" for zi in range(Z)) + f" sw[{lay.OFF_DX} + rr{s}] = dx{s};" +
+             (f" if (rr{s} == 0) sw[{lay.OFF_FL}] = {fl};" if s == 0 else "") + " }")
   b.append("rn::wave_lds_sync();")
   b += _tl(14)
-  b += _rank_pass(E, Z, R, "sG", "+=", "Dm", JB=RUN2_JB if two_wave else None)
+  b += _rank_pass(E, Z, R, "sG", "+=", "Dm")
   b += _tl(15)
   b.append("rn::wave_lds_sync();      // the broadcast buffer is free again")
   rows = ", ".join(f"double (&row{s})[{E}]" for s in range(R))
   idx = ", ".join(f"const int rr{s}, const int rc{s}, const bool ok{s}" for s in range(R))
-  head = (f"__device__ __forceinline__ void update_{k.kind}_rows{sfx}({rows}, const double* __restrict__ gR, double* sP, "
-          f"double* sG, const double* sl, double* sw, {idx}{', const bool he_release' if two_wave else ''}{_tl_arg()}) {{")
+  head = (f"__device__ __forceinline__ void update_{k.kind}_rows({rows}, const double* __restrict__ gR, double* sP, "
+          f"double* sG, const double* sl, double* sw, {idx}{_tl_arg()}) {{")
   return "\n".join([head] + _ind(b) + ["}"])
 
 
-def kernels(spec):
+def kernels(spec, with_run=True):
   """Matrix-phase device functions + the fused multi-step kernel (the phase-1 / phase-3 functions are emit_wide2's, which must
-  precede this text in the generated file)."""
+  precede this text in the generated file).  with_run=False: only the layout constants -- the model's fused run is emit_run2's k_run2
+  (the smoother emitters use these constants and emit their own functions)."""
   from rednose_amd.codegen import emit_wide2 as w2
   GL, R, FPW = layout(spec)
   scal_text, lay = w2.device_functions(spec, lay_cls=RunLayout, sfx="_r")
+  if not with_run:
+    return "\n".join([f"constexpr int GLR = {GL};    // fused run: lanes per filter", f"constexpr int RPL = {R};    // rows of P per lane",
+                      f"constexpr int FPWR = {FPW};   // filters per wavefront", f"constexpr int SLOT_R = {lay.SLOT};   // doubles per scalar slot of the single-wavefront layout", ""])
   out = [f"constexpr int GLR = {GL};    // fused run: lanes per filter", f"constexpr int RPL = {R};    // rows of P per lane",
          f"constexpr int FPWR = {FPW};   // filters per wavefront", f"constexpr int SLOT_R = {lay.SLOT};   // fused run: doubles per scalar slot",
          "", scal_text, "", predict_fn(spec), predict_fn(spec, qdiag=True)]

@@ -79,6 +79,8 @@ def gen_code(folder, name, f_sym, dt_sym, x_sym, obs_eqs, dim_x, dim_err, eskf_p
         usage, bad = fall_back("no_rts4", "the register-broadcast smoother spills under its two-wavefronts-per-SIMD budget: the fused run's layout instead")
       if "k_rts3" in bad:
         usage, bad = fall_back("no_rts3", "the smoother in the fused run's layout spills registers: lane-group smoother instead")
+      if "k_run2" in bad:
+        usage, bad = fall_back("no_run2", "the two-wavefront fused run spills under its 256-register budget: the single-wavefront k_run instead")
       if "k_run" in bad and usage["k_run"]["scratch"] > 0 and rn_emit.family(spec, tuple(fallbacks)) == "wide":
         # whatever the state count: a lone wavefront pays about a microsecond per scratch access, and the rows of P live in registers
         # for the whole schedule.  BatchedEKF.run() then walks the schedule with the step-granular entry points.

@@ -822,24 +822,47 @@ inline int host_readfirstlane(int v) {  // every lane is active wherever the ker
 """
 
 
-def _wide_run_kernel_host_library(tmp_path, spec):
-  from rednose_amd.codegen import emit_wide3, tuning
+def _two_wave(text):
+  """The single-wavefront host prelude / grid runner for a workgroup of TWO wavefronts (k_run2): 128 threads, rn::wave_lds_sync() and the
+  wavefront-wide votes / exchanges rendezvous the caller's own wavefront, rn::wg_barrier() all 128."""
+  text = text.replace("static pthread_barrier_t g_bar;", "static pthread_barrier_t g_wbar[2], g_wg;")
+  text = text.replace("pthread_barrier_wait(&g_bar)", "pthread_barrier_wait(&g_wbar[threadIdx.x >> 6])")
+  text = text.replace("static int g_xchg[64];", "static int g_xchg[128];").replace("static int g_vote[64];", "static int g_vote[128];")
+  text = text.replace("const int r = g_xchg[l];", "const int r = g_xchg[(threadIdx.x & ~63) + l];").replace("const int r = g_xchg[0];", "const int r = g_xchg[threadIdx.x & ~63];")
+  text = text.replace("for (int i = 0; i < 64; i++) r |= g_vote[i];", "for (int i = 0; i < 64; i++) r |= g_vote[(threadIdx.x & ~63) + i];")
+  text = text.replace("inline void async_wait() {}", "inline void async_wait() {}\ninline void wg_barrier() { pthread_barrier_wait(&g_wg); }")
+  text = text.replace("pthread_barrier_init(&g_bar, nullptr, 64);", "pthread_barrier_init(&g_wbar[0], nullptr, 64); pthread_barrier_init(&g_wbar[1], nullptr, 64); pthread_barrier_init(&g_wg, nullptr, 128);")
+  text = text.replace("pthread_barrier_destroy(&g_bar);", "pthread_barrier_destroy(&g_wbar[0]); pthread_barrier_destroy(&g_wbar[1]); pthread_barrier_destroy(&g_wg);")
+  text = text.replace("pthread_t th[64];", "pthread_t th[128];").replace("Arg args[64];", "Arg args[128];").replace("for (int l = 0; l < 64; l++)", "for (int l = 0; l < 128; l++)")
+  assert "&g_bar" not in text and " g_bar" not in text
+  return text
+
+
+def _wide_run_kernel_host_library(tmp_path, spec, variant="k_run"):
+  from rednose_amd.codegen import emit_run2, emit_wide3, tuning
   hdr = open(HDR, encoding="utf-8").read()
   helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "sincos_fast", "normalize_quat"))
   with tuning.using_model(spec):
-    text = emit_wide3.kernels(spec)
-    _, _, FPW = emit_wide3.layout(spec)
+    GL, R, FPW = emit_wide3.layout(spec)
+    if variant == "k_run2":
+      assert emit_run2.applicable(spec)
+      text = f"constexpr int GLR = {GL}; constexpr int RPL = {R}; constexpr int FPWR = {FPW};\n" + emit_run2.kernels(spec)
+    else:
+      text = emit_wide3.kernels(spec)
   text = re.sub(r'asm volatile\("" : "\+v"\((\w+)\)( :: "memory")?\);', ";", text)
   text = text.replace("__builtin_amdgcn_sched_barrier", "rn::sched_barrier_")
   text = re.sub(r"(__device__ \w+ (?:void|int) scal_\w+\(.*?\n}\n)", lambda m: m.group(1).replace("rn::wave_lds_sync();", ";"), text, flags=re.S)
   entry = """
 extern "C" __attribute__((visibility("default"))) void host_wide_run(int grid, double* x, double* P, const double* Q, const int32_t* kinds, const double* dts,
     int64_t T, double* z, const double* R, int64_t n, int norm_quats, uint8_t* flags, double* tx, double* tP) {
-  run_grid(grid, [&] { k_run(x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, tx, tP, nullptr, nullptr); });
-}"""
+  run_grid(grid, [&] { KERNEL(x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, tx, tP, nullptr, nullptr); });
+}""".replace("KERNEL", variant)
   prelude = _KERNEL_PRELUDE.replace("inline void pin(double&) {}", "inline void pin(double&) {}\n" + _WIDE_COPIES).replace("namespace rn {", _WAVE_VOTES + "namespace rn {", 1)
-  src = "\n".join([prelude, helpers, "}  // namespace rn", text, _RUN_GRID, entry])
-  cpp, lib = tmp_path / f"{spec.name}_wide_run_host.cpp", tmp_path / f"lib{spec.name}_wide_run_host.so"
+  grid_text = _RUN_GRID
+  if variant == "k_run2":
+    prelude, grid_text = _two_wave(prelude), _two_wave(_RUN_GRID)
+  src = "\n".join([prelude, helpers, "}  // namespace rn", text, grid_text, entry])
+  cpp, lib = tmp_path / f"{spec.name}_{variant}_host.cpp", tmp_path / f"lib{spec.name}_{variant}_host.so"
   cpp.write_text(src, encoding="utf-8")
   res = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fno-gnu-unique", "-fvisibility=hidden", "-Wno-unknown-pragmas", "-Wno-attributes",
                         str(cpp), "-o", str(lib)], capture_output=True, text=True)
@@ -847,9 +870,11 @@ extern "C" __attribute__((visibility("default"))) void host_wide_run(int grid, d
   return ctypes.CDLL(str(lib)), FPW
 
 
-@pytest.mark.parametrize("name", ["kinematic9", "rand24", "live_maha"])
-def test_lane_group_fused_run_kernel_on_the_host(tmp_path, name):
-  """k_run of the lane-group family, filtered trace and flags included, against the oracle's batch_run: a ragged last tile, fewer
+@pytest.mark.parametrize("name,variant", [("kinematic9", "k_run"), ("rand24", "k_run"), ("live_maha", "k_run"),
+                                          ("kinematic9", "k_run2"), ("rand17", "k_run2"), ("live_maha", "k_run2")])
+def test_lane_group_fused_run_kernel_on_the_host(tmp_path, name, variant):
+  """k_run of the lane-group family (and k_run2, its two-wavefront form: emit_run2.py -- a thread per lane of BOTH wavefronts, the
+  workgroup barriers as barriers over all 128), filtered trace and flags included, against the oracle's batch_run: a ragged last tile, fewer
   workgroups than tiles, a schedule mixing every non-feature kind with dt = 0 steps, gated observations, an unknown kind (flag 8,
   observation passes through).  The input covariances are ASYMMETRIC: the fused run is specified on (P + P^T) / 2
   (include/rednose_amd_filter.h), which is what the oracle is given."""
@@ -859,7 +884,7 @@ def test_lane_group_fused_run_kernel_on_the_host(tmp_path, name):
   mdl = dict(mdl)
   mdl["name"] = name
   spec = build_spec(**mdl, **kw)
-  lib, FPW = _wide_run_kernel_host_library(tmp_path, spec)
+  lib, FPW = _wide_run_kernel_host_library(tmp_path, spec, variant)
   o = OracleLib(name)
   D, E = spec.dim_x, spec.dim_err
   kinds = [k for k in spec.kinds if k.He_sym is None and k.ea_sym is None]

@@ -49,7 +49,13 @@ def main():
     text = re.sub(r"case (\d+): scal_obs_\d+_r2\(.*?\); break;", r"case \1: break;", text)
   for kd in drop:
     if kd.startswith("k"):
-      text = re.sub(r"case %s: \{ double\* slk.*?done = true; break; \}" % kd[1:], "", text)
+      text = re.sub(r"case %s: update_%s_rows_r2\(.*?\); done = true; break;" % (kd[1:], kd[1:]), "", text)
+  if "genq" in drop:      # (experiment) only the diagonal-Q predict
+    text = re.sub(r"\} else \{\n\s*int qz = 0;\n.*?\n.*?predict_rows_r2\(.*?\);\n\s*\}", "}", text, flags=re.S)
+  if "ubar" in drop:      # (experiment) no barriers inside the update functions
+    text = text.replace("rn::wg_barrier();      // dx, flags -> the scalar wavefront", "").replace("if (he_release) rn::wg_barrier();      // He, y", "// He, y")
+  if "trace" in drop:
+    text = text.replace("if (tP != nullptr) {", "if (false) {")
   fn = os.path.join(out, f"{name}_run2.hip")
   with open(fn, "w", encoding="utf-8") as f:
     f.write(text)

@@ -145,6 +145,20 @@ def run():
   assert getattr(f._lib, "live_debug_timeline")(ctypes.cast(buf, ctypes.c_void_p)) == 0
   a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 64, 2).astype(np.float64)[:min(256, (n + 7) // 8)]
   wall = a[:, :60, 1].reshape(-1, 3, 20) / 100.0
+  if len(sys.argv) > 4 and sys.argv[4] == "run2":      # k_run2: matrix wavefront stamps 0-9, scalar wavefront stamps 10-19, both against the matrix wavefront's step start
+    nm = {0: "M  step start (after B1)", 1: "M  predict done", 2: "M  after B2", 3: "M  G in the buffer", 4: "M  S, gate, K, dx done (before B3)", 5: "M  after B3",
+          6: "M  P - K G done", 7: "M  Joseph coefficients (+B4)", 8: "M  + D K^T done", 9: "M  trace out (before B1)",
+          10: " S step start (after B1)", 11: " S h / He done (before B2)", 12: " S after B2", 13: " S after B3", 14: " S injection, flags", 15: " S y / x trace out, next z in",
+          16: " S f / F of the next step", 17: " S after B4", 19: " S before B1"}
+    for s_ in range(3):
+      t = T - 3 + s_
+      rel = wall[:, t % 3, :] - wall[:, t % 3, :1]
+      dtv = ts[t] - (ts[t - 1] if t else 0.0)
+      print(f"  step {t}: kind {kinds[t]} dt {dtv:.2f}")
+      rows = sorted(((rel[:, i].mean(), i) for i in nm if np.all(wall[:, t % 3, i] > 0)))
+      for m, i in rows:
+        print(f"    {nm[i]:44s} {m:8.2f} us   min {rel[:, i].min():7.2f} max {rel[:, i].max():7.2f}")
+    return
   names = {0: "step start", 1: "scalars of predict (f, F)", 8: "  predict: rows of A = P F^T -> image", 9: "  predict: columns of A read, rows of P' formed",
            2: "predict, covariance (end)", 3: "scalars of the kind (h, He)", 10: "  update: G -> buffer", 11: "  update: S, Cholesky, gate",
            12: "  update: K rows solved", 13: "  update: P - K G", 14: "  update: Joseph coefficients, K^T -> buffer",
