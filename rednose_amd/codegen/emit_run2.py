@@ -20,7 +20,7 @@ They meet at workgroup barriers (s_waitcnt lgkmcnt(0) + s_barrier: LDS only -- a
   B3  dx, flags in the slot
       scalar: x <- x (+) dx, flags / y / x trace out, next z in, f / F of step t + 1
                                               | matrix: P -= K G, Joseph coefficients
-  B4  (only if step t + 1 has no predict) He is dead
+  F4  (a flag in LDS, only if step t + 1 has no predict: the matrix wavefront sets it and goes on, the scalar one waits for it) He is dead
       scalar: h, He, y of step t + 1  (*)     | matrix: P += D K^T, rows -> image -> trace
   (*) once per step: before B1 when the step has no predict (the matrix wavefront is still in the tail of the step before),
       after it otherwise (under the predict).
@@ -39,17 +39,34 @@ from rednose_amd.codegen.emit_common import term, sum_terms
 LDS_BUDGET = 40960      # bytes per workgroup for four workgroups per CU (160 KB)
 
 
+FPG = 8           # filters per workgroup (tile): the scalar wavefront serves them with one lane each, lanes 0, 8, .. 56
+
+
+def layout2(spec):
+  """-> (GL lanes per filter, R rows of P per lane, FPW filters per matrix wavefront, ND matrix wavefronts per workgroup).
+  Up to 16 error states: emit_wide3's 8 lanes x 2 rows, one matrix wavefront for the tile's 8 filters.  17 .. 22: TWO matrix
+  wavefronts of 4 filters each, 16 lanes x 2 rows -- 88 row registers instead of 132, so that three wavefronts per SIMD fit
+  (<= 168 registers each): a matrix wavefront is bound by the issue cadence of a wavefront that is (nearly) alone on its SIMD, and
+  two of them per SIMD overlap each other's latencies (profiles/tuning_notes.md: timeline of the one-matrix-wavefront form)."""
+  from rednose_amd.codegen import tuning
+  E = spec.dim_err
+  if E > 16 and tuning.current().run2_nd == 2:
+    return 16, -(-E // 16), 4, 2
+  return 8, -(-E // 8), 8, 1
+
+
 class Run2Layout:
-  """Per-filter slot (doubles): [F | dx | staged x] [He] [z / y] [dt] [flags].  No x: it lives in the scalar wavefront."""
+  """Per-filter slot (doubles): [x] [F | dx] [He] [z / y] [dt] [flags].  F and He cannot share a region as in emit_wide3.RunLayout
+  (both are live between B1 and B2); the room comes from the G / K^T buffer, which lives in the filter's covariance image here."""
 
   def __init__(self, spec, f_vars, he_vars_by_kind):
     D, E = spec.dim_x, spec.dim_err
     self.zmax = max(k.zdim for k in spec.kinds)
     self.nf = len(f_vars)
     self.nh = max([len(v) for v in he_vars_by_kind.values()] + [0])
-    self.OFF_X = None
-    self.OFF_F = self.OFF_DX = self.OFF_XS = 0
-    self.OFF_HE = max(self.nf, E, D)
+    self.OFF_X = 0
+    self.OFF_F = self.OFF_DX = D
+    self.OFF_HE = D + max(self.nf, E)
     self.OFF_Y = self.OFF_HE + self.nh
     self.OFF_DT = self.OFF_Y + self.zmax
     self.OFF_FL = self.OFF_DT + 1
@@ -60,24 +77,25 @@ class Run2Layout:
 
 def lds_bytes(spec):
   E = spec.dim_err
-  _, _, FPW = w3.layout(spec)
+  FPW = FPG
   lay, _, _ = w3._tables(spec, Run2Layout)      # pylint: disable=protected-access
   zmax = max(k.zdim for k in spec.kinds)
-  return 8 * (FPW * E * E + 2 + FPW * zmax * E + FPW * lay.SLOT + E + (E & 1)) + 16
+  return 8 * (FPW * E * E + 2 + FPW * lay.SLOT + E + (E & 1)) + 16
 
 
 def applicable(spec):
   """Models of the 8-lanes-per-filter layout (<= 22 error states) without feature-track kinds, extra arguments or a window shift,
   whose workgroup fits a quarter of a CU's LDS."""
   GL, _, FPW = w3.layout(spec)
+  FPW = FPG
   zmax = max(k.zdim for k in spec.kinds)
   plain = all(k.He_sym is None and k.ea_sym is None for k in spec.kinds)
   from rednose_amd.codegen import tuning
-  return GL == 8 and plain and spec.N == 0 and FPW * zmax <= 64 and lds_bytes(spec) <= LDS_BUDGET
+  return GL == 8 and plain and spec.N == 0 and FPW * zmax <= 64 and zmax <= spec.dim_err and lds_bytes(spec) <= LDS_BUDGET
 
 
-JB = 2            # columns per block of the rank-Z passes (emit_wide3 runs 4 with a 512-register budget; here the budget is 256)
-CH = 8            # entries of a row of A = P F^T formed per block of predict's first half
+JB = int(__import__('os').environ.get('RUN2_JB', '4'))            # columns per block of the rank-Z passes (emit_wide3 runs 4 with a 512-register budget; here the budget is 256)
+CH = int(__import__('os').environ.get('RUN2_CH', '8'))            # entries of a row of A = P F^T formed per block (and row slot) of predict
 
 
 def _ind(lines, n=2):
@@ -90,7 +108,7 @@ def _tl(ph, base="tlb"):
   from rednose_amd.codegen import tuning
   if not tuning.current().wide_timeline:
     return []
-  return [f"if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) {{ const int ti_ = {base} + {ph}; g_tl[(blockIdx.x * 64 + ti_) * 2] = __builtin_readcyclecounter(); "
+  return [f"if ((threadIdx.x == 0 || threadIdx.x == blockDim.x - 64) && blockIdx.x < 256) {{ const int ti_ = {base} + {ph}; g_tl[(blockIdx.x * 64 + ti_) * 2] = __builtin_readcyclecounter(); "
           "g_tl[(blockIdx.x * 64 + ti_) * 2 + 1] = wall_clock64(); }"]
 
 
@@ -106,36 +124,60 @@ def predict_fn(spec):
   inside their block: two inlined alternatives of this function, or one whose coefficient reads hipcc may hoist, do not fit 256
   registers beside the 132 of the rows."""
   E = spec.dim_err
-  GL, R, _ = w3.layout(spec)
+  GL, R, _, _ = layout2(spec)
   lay, Fs, _ = w3._tables(spec, Run2Layout)      # pylint: disable=protected-access
   b = [f"const double dt = sl[{lay.OFF_DT}];"]
-  for s_ in range(R):
-    for c0 in range(0, E, CH):
-      cols = list(range(c0, min(c0 + CH, E)))
-      b.append("{")
-      b.append(f"  double a[{len(cols)}];")
-      for i in cols:
-        b.append(f"  a[{i - c0}] = {sum_terms(term(cf, f'row{s_}[{k}]') for k, cf in Fs.row_nz(i))};")
-      b += [f"  if (ok{s_}) {{", "#pragma unroll", f"    for (int i = 0; i < {len(cols)}; i++) sP[rr{s_} * {E} + {c0} + i] = a[i];", "  }"]
-      b.append("}")
-      b.append("rn::wave_lds_sync();")
+  def shared(rows_of_f, blk):
+    """Declarations of the slot-resident entries of F that the rows `rows_of_f` touch (one broadcast read each, used by every row slot),
+    and the map entry text -> register name."""
+    names, decl = {}, []
+    for i in rows_of_f:
+      for _, cf in Fs.row_nz(i):
+        if cf is not None and cf[0] != 'one' and str(cf[1]).startswith("sl[") and cf[1] not in names:
+          names[cf[1]] = f"f{blk}_{len(names)}"
+          decl.append(f"  const double {names[cf[1]]} = {cf[1]};")
+    return names, decl
+
+  def tm(cf, operand, names):
+    if cf is not None and cf[0] != 'one' and cf[1] in names:
+      cf = (cf[0], names[cf[1]])
+    return term(cf, operand)
+  # first half: rows of A = P F^T, CH entries of all R row slots per block (one read of each entry of F per block, R * CH independent sums)
+  for c0 in range(0, E, CH):
+    cols = list(range(c0, min(c0 + CH, E)))
+    names, decl = shared(cols, f"a{c0}")
+    b.append("{")
+    b += decl
+    for s_ in range(R):
+      b.append(f"  double a{s_}[{len(cols)}];")
+    for i in cols:
+      for s_ in range(R):
+        b.append(f"  a{s_}[{i - c0}] = {sum_terms(tm(cf, f'row{s_}[{k}]', names) for k, cf in Fs.row_nz(i))};")
+    for s_ in range(R):
+      b += [f"  if (ok{s_}) {{", "#pragma unroll", f"    for (int i = 0; i < {len(cols)}; i++) sP[rr{s_} * {E} + {c0} + i] = a{s_}[i];", "  }"]
+    b.append("}")
+    b.append("rn::wave_lds_sync();")
   for s_ in range(R):
     b.append(f"int rd{s_} = rc{s_};")
     b.append(f'asm volatile("" : "+v"(rd{s_}));      // the diagonal selects below are computed here: as loop invariants they are {min(GL, E - GL * s_)} SGPR pairs per slot, across the whole step loop')
     b.append(f"const double dq{s_} = dt * sQd[rd{s_}];      // diag(Q) is the same for every filter: {E} doubles of LDS instead of {R} registers per lane across the step loop")
-    # column of A = row of B, fetched per block of outputs (only the entries that block's rows of F touch): the whole column at once is
-    # 44 registers that stay live through the slot
-    for c0 in range(0, E, CH):
-      outs = list(range(c0, min(c0 + CH, E)))
-      need = sorted({m for j in outs for m, _ in Fs.row_nz(j)})
-      b.append("{")
+  # second half: column of A = row of B, fetched per block of outputs (only the entries that block's rows of F touch: the whole column at
+  # once is 44 registers per slot), again all row slots per block
+  for c0 in range(0, E, CH):
+    outs = list(range(c0, min(c0 + CH, E)))
+    need = sorted({m for j in outs for m, _ in Fs.row_nz(j)})
+    names, decl = shared(outs, f"b{c0}")
+    b.append("{")
+    b += decl
+    for s_ in range(R):
       for m in need:
-        b.append(f"  const double a_{m} = sP[{m} * {E} + rc{s_}];")
-      for j in outs:
+        b.append(f"  const double a{s_}_{m} = sP[{m} * {E} + rc{s_}];")
+    for j in outs:
+      for s_ in range(R):
         diag = f" + (rd{s_} == {j} ? dq{s_} : 0.0)" if GL * s_ <= j < GL * (s_ + 1) else ""
-        b.append(f"  row{s_}[{j}] = {sum_terms(term(cf, f'a_{m}') for m, cf in Fs.row_nz(j))}{diag};")
-      b.append("}")
-      b.append("rn::wave_lds_sync();")
+        b.append(f"  row{s_}[{j}] = {sum_terms(tm(cf, f'a{s_}_{m}', names) for m, cf in Fs.row_nz(j))}{diag};")
+    b.append("}")
+    b.append("rn::wave_lds_sync();")
   b.append("rn::wave_lds_sync();      // the image is free again")
   b.append("if (!qdiag) {")
   for s_ in range(R):
@@ -157,9 +199,10 @@ def update_fn(spec):
   R, which adds exact zeros to the sums of the unpadded form.  (Eight inlined update bodies in one switch, as in k_run, cost hipcc
   ~200 spilled registers at a 256-register budget although each body alone fits: the row set is live across the switch.)
   dx and the flags leave for the slot as soon as the gain exists, followed by the workgroup barrier the scalar wavefront waits at;
-  a second barrier (`he_release`) after the Joseph coefficients tells it that He and y are dead."""
+  a flag (`he_release`) after the Joseph coefficients tells it that He and y are dead."""
   E = spec.dim_err
-  _, R, _ = w3.layout(spec)
+  _, R, _, ND = layout2(spec)
+  tight = ND > 1      # the 168-register budget of three wavefronts per SIMD: fences around every row of He, G^T re-read after the factor
   lay, _, Hss = w3._tables(spec, Run2Layout)      # pylint: disable=protected-access
   ZM = lay.zmax
   b = ["(void)sP;"]
@@ -170,7 +213,9 @@ def update_fn(spec):
   b.append("switch (kind) {")
   for k in spec.kinds:
     Hs, Z = Hss[k.kind], k.zdim
-    ln = [f"kk{s_}[{zi}] = {sum_terms(term(cf, f'row{s_}[{c}]') for c, cf in Hs.row_nz(zi))};" for s_ in range(R) for zi in range(Z)]
+    # (a fence per row of He: its entries are broadcast reads of the slot, and hipcc would fetch all of them -- 35 for live's accelerometer -- first)
+    ln = [f"kk{s_}[{zi}] = {sum_terms(term(cf, f'row{s_}[{c}]') for c, cf in Hs.row_nz(zi))};" + (" rn::wave_lds_sync();" if tight and len(Hs.row_nz(zi)) > 4 else "")
+          for zi in range(Z) for s_ in range(R)]
     ln.append(f"zk = {Z};" + (f" thr = {k.maha_thresh!r}; gate_on = true;" if k.maha_test else ""))
     b.append(f"  case {k.kind}: {{ " + " ".join(ln) + " break; }")
   b += ["  default: break;", "}"]
@@ -183,7 +228,8 @@ def update_fn(spec):
   b.append("switch (kind) {")
   for k in spec.kinds:
     Hs, Z = Hss[k.kind], k.zdim
-    ln = [f"HPH[{zi * ZM + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))};" for zi in range(Z) for w in range(Z)]
+    ln = [f"HPH[{zi * ZM + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))};" + (" rn::wave_lds_sync();" if tight and len(Hs.row_nz(w)) > 4 else "")
+          for w in range(Z) for zi in range(Z)]
     ln += [f"Rl[{zi * ZM + w}] = gR[{zi * Z + w}];" for zi in range(Z) for w in range(Z)]
     b.append(f"  case {k.kind}: {{ " + " ".join(ln) + " break; }")
   b += ["  default: break;", "}"]
@@ -196,6 +242,8 @@ def update_fn(spec):
           f"    rn::spd_factor<{ZM}>(S, L, iL);", "  }", "}"]
   else:
     b.append("(void)thr; (void)gate_on;")
+  for s_ in range(R if tight else 0):      # (the lane's entries of G^T come back from the buffer: held in registers through the factor and the gate they are 2 R ZM registers too many)
+    b.append(" ".join(f"kk{s_}[{zi}] = sG[{zi} * {E} + rc{s_}];" for zi in range(ZM)))
   for s_ in range(R):
     b.append(f"rn::spd_solve<{ZM}>(L, iL, kk{s_});                       // K[row][:]")
     b.append(f"const double dx{s_} = " + " + ".join(f"kk{s_}[{zi}]*yv[{zi}]" for zi in range(ZM)) + ";")
@@ -211,7 +259,8 @@ def update_fn(spec):
   b.append("switch (kind) {")
   for k in spec.kinds:
     Hs, Z = Hss[k.kind], k.zdim
-    ln = [f"cc{s_}[{zi}] = {sum_terms(term(cf, f'row{s_}[{j}]') for j, cf in Hs.row_nz(zi))};" for s_ in range(R) for zi in range(Z)]
+    ln = [f"cc{s_}[{zi}] = {sum_terms(term(cf, f'row{s_}[{j}]') for j, cf in Hs.row_nz(zi))};" + (" rn::wave_lds_sync();" if tight and len(Hs.row_nz(zi)) > 4 else "")
+          for zi in range(Z) for s_ in range(R)]
     b.append(f"  case {k.kind}: {{ " + " ".join(ln) + " break; }")
   b += ["  default: break;", "}"]
   for s_ in range(R):
@@ -219,7 +268,9 @@ def update_fn(spec):
     for zi in range(ZM):
       kr = " + ".join(f"kk{s_}[{w}]*Rl[{w * ZM + zi}]" for w in range(ZM))
       b.append(f"Dm{s_}[{zi}] = ({kr}) - (cc{s_}[{zi}]);")
-  b.append("if (he_release) rn::wg_barrier();      // B4: He, y are dead -- the scalar wavefront may evaluate the next step's observation")
+  b.append("rn::wave_lds_sync();")
+  b.append("if (he_release > 0) rn::flag_set(he_flag, he_release);      // He, y are dead: the scalar wavefront may evaluate the next step's observation.  A FLAG, not a barrier --")
+  b.append("                                                             // this wavefront needs nothing from the other one here and would wait ~1 us for its injection / trace stores")
   b += _tl(7)
   b.append("rn::wave_lds_sync();      // every lane has taken G: the buffer takes K^T")
   for s_ in range(R):
@@ -230,14 +281,14 @@ def update_fn(spec):
   rows = ", ".join(f"double (&row{s_})[{E}]" for s_ in range(R))
   idx = ", ".join(f"const int rr{s_}, const int rc{s_}, const bool ok{s_}" for s_ in range(R))
   head = (f"__device__ __forceinline__ void update_rows_r2(const int kind, {rows}, const double* __restrict__ gR, double* sP, "
-          f"double* sG, const double* sl, double* sw, {idx}, const bool he_release{', const int tlb' if _tl_on() else ''}) {{")
+          f"double* sG, const double* sl, double* sw, {idx}, const int he_release, int* he_flag{', const int tlb' if _tl_on() else ''}) {{")
   return "\n".join([head] + _ind(b) + ["}"])
 
 
 def kernels(spec):
   """Scalar phase functions against Run2Layout (suffix _r2, x as a register array), the matrix functions, k_run2."""
   from rednose_amd.codegen import emit_wide2 as w2
-  scal_text, lay = w2.device_functions(spec, lay_cls=Run2Layout, sfx="_r2", xreg=True)
+  scal_text, lay = w2.device_functions(spec, lay_cls=Run2Layout, sfx="_r2")
   return "\n".join([f"constexpr int SLOT_R2 = {lay.SLOT};   // two-wavefront fused run: doubles per scalar slot", "", scal_text, "",
                     predict_fn(spec), update_fn(spec), run_kernel(spec)])
 
@@ -246,19 +297,20 @@ def run_kernel(spec):
   from rednose_amd.codegen import tuning
   D, E = spec.dim_x, spec.dim_err
   EE = E * E
-  GL, R, FPW = w3.layout(spec)
+  GL, R, FPW, ND = layout2(spec)
   lay, _, _ = w3._tables(spec, Run2Layout)      # pylint: disable=protected-access
   zmax = max(k.zdim for k in spec.kinds)
   rows = ", ".join(f"row{s}" for s in range(R))
   idx = ", ".join(f"rr{s}, rc{s}, ok{s}" for s in range(R))
   nlc = chr(10)
-  scal_cases = nlc.join(f"          case {k.kind}: scal_obs_{k.kind}_r2(xr, sl, sl + {lay.OFF_Y}); break;" for k in spec.kinds)
+  scal_cases = nlc.join(f"          case {k.kind}: scal_obs_{k.kind}_r2(sl, sl + {lay.OFF_Y}); break;" for k in spec.kinds)
   known = " || ".join(f"kind == {k.kind}" for k in spec.kinds)
   img = nlc.join(f"        if (ok{s}) {{\n#pragma unroll\n          for (int j = 0; j < {E}; j++) sP[rr{s} * {E} + j] = row{s}[j];\n        }}" for s in range(R))
   id0_guard = "true" if not spec.identity_at_dt0() else "dt != 0.0"
   id0_next = "true" if not spec.identity_at_dt0() else "dtn != 0.0"
   nt_trace = "true" if tuning.current().nt_trace else "false"
   prio = f"    __builtin_amdgcn_s_setprio({int(tuning.current().run2_prio)});      // a chain of dependent instructions: whenever one is ready it goes first\n" if tuning.current().run2_prio else ""
+  s_lanes = f"    const int g = lane / {64 // FPG};\n    const int c = lane % {64 // FPG};"
   decl_rows = nlc.join(f"      double row{s}[{E}];" for s in range(R))
   # row indices from an opaque copy of the lane's position, per scope: as loop invariants they (and every LDS address derived from them)
   # would hold a dozen registers across the step loop
@@ -270,45 +322,46 @@ def run_kernel(spec):
     return "".join(ind + x + nlc for x in _tl(ph))
   tlb_decl = "        const int tlb = (int)(t % 3) * 20;\n" if _tl_on() else ""
   tl_arg = ", tlb" if _tl_on() else ""
-  stage_x = f"""if (c == 0 && live) {{
-#pragma unroll
-          for (int i = 0; i < {D}; i++) sl[{lay.OFF_XS} + i] = xr[i];
-        }}
-        rn::wave_lds_sync();"""
   return f"""
-// ---- fused multi-step run, matrix wavefront + scalar wavefront per tile of {FPW} filters (emit_run2.py): same interface as k_run ----
-__global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double* __restrict__ gP, const double* __restrict__ gQ,
+// ---- fused multi-step run, {ND} matrix wavefront(s) + a scalar wavefront per tile of {FPG} filters (emit_run2.py): same interface as k_run ----
+constexpr int R2_FPG = {FPG};      // filters per workgroup
+constexpr int R2_FPW = {FPW};      // filters per matrix wavefront
+constexpr int R2_GL = {GL};       // lanes per filter in a matrix wavefront
+constexpr int R2_THREADS = {64 * (ND + 1)};
+__global__ __launch_bounds__({64 * (ND + 1)}, {ND + 1}) void k_run2(double* __restrict__ gx, double* __restrict__ gP, const double* __restrict__ gQ,
     const int32_t* __restrict__ kinds, const double* __restrict__ dts, const int64_t T, double* __restrict__ gz,
     const double* __restrict__ gR, const int64_t n, const int norm_quats, uint8_t* __restrict__ flags,
     double* __restrict__ tx, double* __restrict__ tP, const double* __restrict__ gea, const int32_t* __restrict__ augs) {{
   (void)gea; (void)augs;
-  __shared__ __attribute__((aligned(16))) double s_P[FPWR * {EE} + 2];      // one image of P per filter
-  __shared__ __attribute__((aligned(16))) double s_G[FPWR * {zmax * E}];     // G, then K^T
-  __shared__ __attribute__((aligned(16))) double s_sl[FPWR * SLOT_R2];
+  __shared__ __attribute__((aligned(16))) double s_P[R2_FPG * {EE} + 2];      // one image of P per filter; its first {zmax} rows are the G / K^T buffer of the update (which never touches the image)
+  __shared__ __attribute__((aligned(16))) double s_sl[R2_FPG * SLOT_R2];
   __shared__ double s_qd[{E + (E & 1)}];                                     // diag(Q)
   __shared__ int s_bad;
+  __shared__ int s_he;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int g = lane / GLR;
-  const int c = lane % GLR;
-  const int64_t tiles = (n + FPWR - 1) / FPWR;
-  if (wave == 0) {{
-    // ================================ matrix wavefront ================================
+  const int64_t tiles = (n + R2_FPG - 1) / R2_FPG;
+  if (wave < {ND}) {{
+    // ================================ matrix wavefront(s): filters wave * R2_FPW .. of the tile ================================
+    const int g = wave * R2_FPW + lane / R2_GL;
+    const int c = lane % R2_GL;
     int qoff = 0;
     for (int i = lane; i < {EE}; i += 64) qoff |= (i / {E} != i % {E}) && (gQ[i] != 0.0);
     const bool qdiag = !__any(qoff);
-    if (lane < {E}) s_qd[lane] = gQ[lane * {E + 1}];
+    if (wave == 0 && lane < {E}) s_qd[lane] = gQ[lane * {E + 1}];
     rn::wave_lds_sync();
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
-      const int64_t base = tile * FPWR;
-      const int cnt = (n - base) < FPWR ? (int)(n - base) : FPWR;
+      const int64_t base = tile * R2_FPG;
+      const int cnt = (n - base) < R2_FPG ? (int)(n - base) : R2_FPG;
       const int gg = g < cnt ? g : 0;
       const bool live = g < cnt;
+      const int cntw = cnt - wave * R2_FPW < 0 ? 0 : (cnt - wave * R2_FPW > R2_FPW ? R2_FPW : cnt - wave * R2_FPW);      // this wavefront's filters
       double* sP = s_P + gg * {EE};
       double* sl = s_sl + gg * SLOT_R2;
+      double* sPw = s_P + wave * (R2_FPW * {EE});
       int lb = lane;
       asm volatile("" : "+v"(lb));
-      rn::copy_g2l<FPWR * {EE}>(gP + base * {EE}, cnt * {EE}, s_P, lb);
+      rn::copy_g2l<R2_FPW * {EE}>(gP + (base + wave * R2_FPW) * {EE}, cntw * {EE}, sPw, lb);
       rn::wave_lds_sync();
 {decl_rows}
       {{
@@ -322,23 +375,23 @@ __global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double
         const double dt = dts[t];
         const bool do_pred = {id0_guard};
 {decl_idx_at("        ")}
-{tlb_decl}{TL(0)}        bool he_release = false;                          // B4: the next step has no predict, its h / He go under this step's tail
-        if (t + 1 < T) {{ const double dtn = dts[t + 1]; he_release = !({id0_next}); }}
+{tlb_decl}{TL(0)}        int he_release = 0;                               // > 0: the next step has no predict, its h / He go under this step's tail -- the value the flag takes when He is dead
+        if (t + 1 < T) {{ const double dtn = dts[t + 1]; if (!({id0_next})) he_release = (int)t + 1; }}
         if (do_pred) predict_rows_r2({rows}, sP, s_qd, gQ, qdiag, sl, {idx});
 {TL(1)}        rn::wg_barrier();                                 // B2
 {TL(2)}        const int bad = __builtin_amdgcn_readfirstlane(s_bad);
         if (!bad && ({known})) {{
-          update_rows_r2(kind, {rows}, gR + t * {zmax * zmax}, sP, s_G + gg * {zmax * E}, sl, sl, {idx}, he_release{tl_arg});
+          update_rows_r2(kind, {rows}, gR + t * {zmax * zmax}, sP, sP, sl, sl, {idx}, he_release, &s_he{tl_arg});
         }} else {{
           rn::wg_barrier();                               // B3
-          if (he_release) rn::wg_barrier();               // B4
+          if (he_release > 0) rn::flag_set(&s_he, he_release);
         }}
 {TL(8)}        if (tP != nullptr) {{
           int lz = lane;
           asm volatile("" : "+v"(lz));
 {img}
           rn::wave_lds_sync();
-          rn::copy_l2g<FPWR * {EE}, {nt_trace}>(tP + (t * n + base) * {EE}, cnt * {EE}, s_P, lz);
+          rn::copy_l2g<R2_FPW * {EE}, {nt_trace}>(tP + (t * n + base + wave * R2_FPW) * {EE}, cntw * {EE}, sPw, lz);
           rn::wave_lds_sync();
         }}
 {TL(9)}        rn::wg_barrier();                                 // B1 of step t + 1
@@ -350,25 +403,27 @@ __global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double
       rn::wave_lds_sync();
       int le = lane;
       asm volatile("" : "+v"(le));
-      rn::copy_l2g<FPWR * {EE}>(gP + base * {EE}, cnt * {EE}, s_P, le);
+      rn::copy_l2g<R2_FPW * {EE}>(gP + (base + wave * R2_FPW) * {EE}, cntw * {EE}, sPw, le);
       rn::wave_lds_sync();
     }}
   }} else {{
-    // ================================ scalar wavefront ================================
-{prio}    const int zf = lane / {zmax}, zc = lane % {zmax};      // observation entry this lane carries between HBM and the slots
+    // ================================ scalar wavefront: one lane per filter ================================
+{prio}{s_lanes}
+    const int zf = lane / {zmax}, zc = lane % {zmax};      // observation entry this lane carries between HBM and the slots
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
-      const int64_t base = tile * FPWR;
-      const int cnt = (n - base) < FPWR ? (int)(n - base) : FPWR;
+      const int64_t base = tile * R2_FPG;
+      const int cnt = (n - base) < R2_FPG ? (int)(n - base) : R2_FPG;
       const int gg = g < cnt ? g : 0;
       const bool live = g < cnt;
       const bool zlive = zf < cnt;
       double* sl = s_sl + gg * SLOT_R2;
       double* slz = s_sl + (zlive ? zf : 0) * SLOT_R2 + {lay.OFF_Y} + zc;
-      double xr[{D}];
-#pragma unroll
-      for (int i = 0; i < {D}; i++) xr[i] = gx[(base + gg) * {D} + i];
+      int l0 = lane;
+      asm volatile("" : "+v"(l0));
+      for (int i = l0; i < cnt * {D}; i += 64) s_sl[(i / {D}) * SLOT_R2 + {lay.OFF_X} + i % {D}] = gx[base * {D} + i];
       if (zlive) *slz = gz[base * {zmax} + lane];
       rn::wave_lds_sync();
+      if (lane == 0) s_he = 0;
       int bad = 0;
       bool obs_done = false;
       if (T > 0) {{
@@ -376,8 +431,8 @@ __global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double
         const double dtn = dt0;
         const bool p0 = {id0_next};
         if (c == 0 && live) {{
-          if (p0) scal_predict_r2(xr, dt0, sl, norm_quats);
-          else scal_keep_r2(xr, sl, norm_quats);
+          if (p0) scal_predict_r2(sl + {lay.OFF_X}, dt0, sl, norm_quats);
+          else scal_keep_r2(sl + {lay.OFF_X}, sl, norm_quats);
         }}
         rn::wave_lds_sync();
       }}
@@ -402,16 +457,15 @@ __global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double
 {TL(12)}        rn::wg_barrier();                                 // B3: dx and the gate flag are in the slot
 {TL(13)}        if (c == 0 && live) {{
           int fl = bad;
-          if (!bad) fl = scal_inject_r2(sl, xr, norm_quats) | (int)sl[{lay.OFF_FL}];
+          if (!bad) fl = scal_inject_r2(sl, sl + {lay.OFF_X}, norm_quats) | (int)sl[{lay.OFF_FL}];
           if (flags != nullptr) flags[t * n + base + g] = (uint8_t)fl;
         }}
 {TL(14)}        if (zlive) gz[(t * n + base) * {zmax} + lane] = *slz;          // y (the observation itself after an unknown kind)
         rn::wave_lds_sync();
         if (tx != nullptr) {{
-          {stage_x}
           int lz = lane;
           asm volatile("" : "+v"(lz));
-          for (int i = lz; i < cnt * {D}; i += 64) tx[(t * n + base) * {D} + i] = s_sl[(i / {D}) * SLOT_R2 + {lay.OFF_XS} + i % {D}];
+          for (int i = lz; i < cnt * {D}; i += 64) tx[(t * n + base) * {D} + i] = s_sl[(i / {D}) * SLOT_R2 + {lay.OFF_X} + i % {D}];
           rn::wave_lds_sync();
         }}
         if (zlive) *slz = zn;
@@ -421,12 +475,12 @@ __global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double
           const double dtn = dts[t + 1];
           const bool pn = {id0_next};
           if (c == 0 && live) {{
-            if (pn) scal_predict_r2(xr, dtn, sl, norm_quats);
-            else scal_keep_r2(xr, sl, norm_quats);
+            if (pn) scal_predict_r2(sl + {lay.OFF_X}, dtn, sl, norm_quats);
+            else scal_keep_r2(sl + {lay.OFF_X}, sl, norm_quats);
           }}
           rn::wave_lds_sync();
 {TL(16, "          ")}          if (!pn) {{
-            rn::wg_barrier();                             // B4: He of step t is dead
+            rn::flag_wait(&s_he, (int)t + 1);             // He of step t is dead (set by the matrix wavefront after its Joseph coefficients)
 {TL(17, "            ")}
             const int kn = kinds[t + 1];
             bad = 0;
@@ -444,10 +498,9 @@ __global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double
         }}
 {TL(19)}        rn::wg_barrier();                                 // B1 of step t + 1
       }}
-      {stage_x}
       int le = lane;
       asm volatile("" : "+v"(le));
-      for (int i = le; i < cnt * {D}; i += 64) gx[base * {D} + i] = s_sl[(i / {D}) * SLOT_R2 + {lay.OFF_XS} + i % {D}];
+      for (int i = le; i < cnt * {D}; i += 64) gx[base * {D} + i] = s_sl[(i / {D}) * SLOT_R2 + {lay.OFF_X} + i % {D}];
       rn::wave_lds_sync();
     }}
   }}
@@ -456,6 +509,6 @@ __global__ __launch_bounds__(128, 2) void k_run2(double* __restrict__ gx, double
 
 
 def launch_run():
-  return """  const int64_t tiles = (n + FPWR - 1) / FPWR;
-  hipLaunchKernelGGL(k_run2, dim3(rn::grid_for_tiles(tiles)), dim3(128), 0, (hipStream_t)stream,
+  return """  const int64_t tiles = (n + R2_FPG - 1) / R2_FPG;
+  hipLaunchKernelGGL(k_run2, dim3(rn::grid_for_tiles(tiles)), dim3(R2_THREADS), 0, (hipStream_t)stream,
                      x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P, ea, augment);"""

@@ -100,6 +100,18 @@ __device__ __forceinline__ void wg_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// One-way hand-off between two wavefronts of a workgroup through a word of LDS: the producer's earlier LDS accesses are performed before
+// the flag's store (the LDS serves a wavefront's instructions in order), the consumer polls.  Both wavefronts are resident (same
+// workgroup), so the wait cannot deadlock.
+__device__ __forceinline__ void flag_set(int* flag, int v) {
+  wave_lds_sync();
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void flag_wait(int* flag, int v) {
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != v) __builtin_amdgcn_s_sleep(2);
+  wave_lds_sync();
+}
+
 // Forces `v` to exist in registers at this point of the instruction stream (an empty volatile asm that "modifies" it):
 // arithmetic producing v cannot sink below, arithmetic consuming it cannot rise above.  No instruction is emitted.
 __device__ __forceinline__ void pin(double& v) { asm volatile("" : "+v"(v)); }
@@ -243,16 +255,48 @@ __device__ __forceinline__ void copy_g2l(const double* __restrict__ g, int nd, d
 template <int MAXD, bool NT = false>
 __device__ __forceinline__ void copy_l2g(double* __restrict__ g, int nd, const double* lds, int lane) {
   typedef double v2d_ __attribute__((ext_vector_type(2)));
-  constexpr int IT = (MAXD / 2 + WAVE - 1) / WAVE;
+  constexpr int NV = MAXD / 2;
+  constexpr int IT = (NV + WAVE - 1) / WAVE;
+  constexpr int FULL = NV / WAVE;            // iterations in which every lane has an element of a full buffer
+  constexpr int BATCH = 8;                   // LDS reads in flight before the first store of a batch (32 registers)
   const int nv = nd >> 1;
   v2d_* __restrict__ g2 = reinterpret_cast<v2d_*>(g);
   const v2d_* l2 = reinterpret_cast<const v2d_*>(lds);
+  if (nd == MAXD) {
+    // A full buffer (every tile but a ragged last one): no per-element predicate, BATCH reads issued before their stores.  The guarded
+    // loop below compiles to compare - exec mask - ds_read - s_waitcnt lgkmcnt(0) - store per KiB, i.e. one exposed LDS latency per
+    // iteration: 1.9 us for the 31 KiB of a fused-run trace step (profiles/tuning_notes.md, round 5).
 #pragma unroll
-  for (int i = 0; i < IT; i++) {
-    const int idx = lane + i * WAVE;
-    if (idx < nv) {
-      if constexpr (NT) __builtin_nontemporal_store(l2[idx], g2 + idx);
-      else g2[idx] = l2[idx];
+    for (int b = 0; b < FULL; b += BATCH) {
+      v2d_ v[BATCH];
+#pragma unroll
+      for (int i = 0; i < BATCH; i++) {
+        if (b + i < FULL) v[i] = l2[lane + (b + i) * WAVE];
+      }
+#pragma unroll
+      for (int i = 0; i < BATCH; i++) {
+        if (b + i < FULL) {
+          if constexpr (NT) __builtin_nontemporal_store(v[i], g2 + lane + (b + i) * WAVE);
+          else g2[lane + (b + i) * WAVE] = v[i];
+        }
+      }
+      wave_lds_sync();
+    }
+    if constexpr (FULL < IT) {
+      const int idx = lane + FULL * WAVE;
+      if (idx < NV) {
+        if constexpr (NT) __builtin_nontemporal_store(l2[idx], g2 + idx);
+        else g2[idx] = l2[idx];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < IT; i++) {
+      const int idx = lane + i * WAVE;
+      if (idx < nv) {
+        if constexpr (NT) __builtin_nontemporal_store(l2[idx], g2 + idx);
+        else g2[idx] = l2[idx];
+      }
     }
   }
   if ((nd & 1) && lane == 0) g[nd - 1] = lds[nd - 1];

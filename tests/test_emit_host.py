@@ -477,6 +477,7 @@ _KERNEL_PRELUDE = r"""
 #include <cstdint>
 #include <cstring>
 #include <pthread.h>
+#include <sched.h>
 #define __device__
 #define __forceinline__ inline
 #define __global__
@@ -822,18 +823,22 @@ inline int host_readfirstlane(int v) {  // every lane is active wherever the ker
 """
 
 
-def _two_wave(text):
-  """The single-wavefront host prelude / grid runner for a workgroup of TWO wavefronts (k_run2): 128 threads, rn::wave_lds_sync() and the
-  wavefront-wide votes / exchanges rendezvous the caller's own wavefront, rn::wg_barrier() all 128."""
-  text = text.replace("static pthread_barrier_t g_bar;", "static pthread_barrier_t g_wbar[2], g_wg;")
+def _two_wave(text, nw=2):
+  """The single-wavefront host prelude / grid runner for a workgroup of `nw` wavefronts (k_run2): 64 nw threads, rn::wave_lds_sync() and the
+  wavefront-wide votes / exchanges rendezvous the caller's own wavefront, rn::wg_barrier() all of them."""
+  text = text.replace("static pthread_barrier_t g_bar;", "static pthread_barrier_t g_wbar[4], g_wg;").replace("struct Dim3 { int x; };\nstatic thread_local Dim3 threadIdx, blockIdx, gridDim;",
+                                                                                                             "struct Dim3 { int x; };\nstatic thread_local Dim3 threadIdx, blockIdx, gridDim, blockDim;")
   text = text.replace("pthread_barrier_wait(&g_bar)", "pthread_barrier_wait(&g_wbar[threadIdx.x >> 6])")
-  text = text.replace("static int g_xchg[64];", "static int g_xchg[128];").replace("static int g_vote[64];", "static int g_vote[128];")
+  text = text.replace("static int g_xchg[64];", "static int g_xchg[256];").replace("static int g_vote[64];", "static int g_vote[256];")
   text = text.replace("const int r = g_xchg[l];", "const int r = g_xchg[(threadIdx.x & ~63) + l];").replace("const int r = g_xchg[0];", "const int r = g_xchg[threadIdx.x & ~63];")
   text = text.replace("for (int i = 0; i < 64; i++) r |= g_vote[i];", "for (int i = 0; i < 64; i++) r |= g_vote[(threadIdx.x & ~63) + i];")
-  text = text.replace("inline void async_wait() {}", "inline void async_wait() {}\ninline void wg_barrier() { pthread_barrier_wait(&g_wg); }")
-  text = text.replace("pthread_barrier_init(&g_bar, nullptr, 64);", "pthread_barrier_init(&g_wbar[0], nullptr, 64); pthread_barrier_init(&g_wbar[1], nullptr, 64); pthread_barrier_init(&g_wg, nullptr, 128);")
-  text = text.replace("pthread_barrier_destroy(&g_bar);", "pthread_barrier_destroy(&g_wbar[0]); pthread_barrier_destroy(&g_wbar[1]); pthread_barrier_destroy(&g_wg);")
-  text = text.replace("pthread_t th[64];", "pthread_t th[128];").replace("Arg args[64];", "Arg args[128];").replace("for (int l = 0; l < 64; l++)", "for (int l = 0; l < 128; l++)")
+  text = text.replace("inline void async_wait() {}", "inline void async_wait() {}\ninline void wg_barrier() { pthread_barrier_wait(&g_wg); }\n"
+                      "inline void flag_set(int* f, int v) { pthread_barrier_wait(&g_wbar[threadIdx.x >> 6]); if ((threadIdx.x & 63) == 0) __atomic_store_n(f, v, __ATOMIC_RELEASE); }\n"
+                      "inline void flag_wait(int* f, int v) { while (__atomic_load_n(f, __ATOMIC_ACQUIRE) != v) sched_yield(); }")
+  text = text.replace("pthread_barrier_init(&g_bar, nullptr, 64);", f"for (int w = 0; w < {nw}; w++) pthread_barrier_init(&g_wbar[w], nullptr, 64); pthread_barrier_init(&g_wg, nullptr, {64 * nw});")
+  text = text.replace("pthread_barrier_destroy(&g_bar);", f"for (int w = 0; w < {nw}; w++) pthread_barrier_destroy(&g_wbar[w]); pthread_barrier_destroy(&g_wg);")
+  text = text.replace("pthread_t th[64];", "pthread_t th[256];").replace("Arg args[64];", "Arg args[256];").replace("for (int l = 0; l < 64; l++)", f"for (int l = 0; l < {64 * nw}; l++)")
+  text = text.replace("threadIdx.x = a.lane;", f"threadIdx.x = a.lane; blockDim.x = {64 * nw};")
   assert "&g_bar" not in text and " g_bar" not in text
   return text
 
@@ -844,9 +849,11 @@ def _wide_run_kernel_host_library(tmp_path, spec, variant="k_run"):
   helpers = "\n".join(_function_text(hdr, f) for f in ("spd_factor", "spd_forward", "spd_solve", "ldu_factor", "ldu_forward", "ldu_forward_t", "ldu_solve", "rsqrt_pow", "sincos_fast", "normalize_quat"))
   with tuning.using_model(spec):
     GL, R, FPW = emit_wide3.layout(spec)
+    nw = 1
     if variant == "k_run2":
       assert emit_run2.applicable(spec)
-      text = f"constexpr int GLR = {GL}; constexpr int RPL = {R}; constexpr int FPWR = {FPW};\n" + emit_run2.kernels(spec)
+      nw = emit_run2.layout2(spec)[3] + 1
+      text = f"constexpr int GLR = {GL}; constexpr int RPL = {R}; constexpr int FPWR = {FPW};\n" + re.sub(r"__builtin_amdgcn_s_setprio\(\d+\);", ";", emit_run2.kernels(spec))
     else:
       text = emit_wide3.kernels(spec)
   text = re.sub(r'asm volatile\("" : "\+v"\((\w+)\)( :: "memory")?\);', ";", text)
@@ -860,7 +867,7 @@ extern "C" __attribute__((visibility("default"))) void host_wide_run(int grid, d
   prelude = _KERNEL_PRELUDE.replace("inline void pin(double&) {}", "inline void pin(double&) {}\n" + _WIDE_COPIES).replace("namespace rn {", _WAVE_VOTES + "namespace rn {", 1)
   grid_text = _RUN_GRID
   if variant == "k_run2":
-    prelude, grid_text = _two_wave(prelude), _two_wave(_RUN_GRID)
+    prelude, grid_text = _two_wave(prelude, nw), _two_wave(_RUN_GRID, nw)
   src = "\n".join([prelude, helpers, "}  // namespace rn", text, grid_text, entry])
   cpp, lib = tmp_path / f"{spec.name}_{variant}_host.cpp", tmp_path / f"lib{spec.name}_{variant}_host.so"
   cpp.write_text(src, encoding="utf-8")

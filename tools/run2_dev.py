@@ -17,7 +17,7 @@ from rednose_amd.helpers import TEMPLATE_DIR
 
 def unit_text(spec):
   D, E, M = spec.dim_x, spec.dim_err, spec.dim_main_err
-  GL, R, FPW = emit_wide3.layout(spec)
+  GL, R, FPW = emit_wide3.layout(spec)      # (the smoothers' constants; k_run2 has its own)
   src = ['#include "ekf_hip_rt.h"', SINCOS_FAST, "", "namespace {", f"constexpr int DIM = {D};", f"constexpr int EDIM = {E};", f"constexpr int MEDIM = {M};",
          f"constexpr int GLR = {GL};", f"constexpr int RPL = {R};", f"constexpr int FPWR = {FPW};", ""]
   for var in spec.global_vars:
