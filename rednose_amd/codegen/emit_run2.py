@@ -37,6 +37,7 @@ from rednose_amd.codegen import emit_wide3 as w3
 from rednose_amd.codegen.emit_common import term, sum_terms
 
 LDS_BUDGET = 40960      # bytes per workgroup for four workgroups per CU (160 KB)
+MIN_E = 13              # smallest number of error states served (measured, see applicable())
 
 
 FPG = 8           # filters per workgroup (tile): the scalar wavefront serves them with one lane each, lanes 0, 8, .. 56
@@ -84,14 +85,18 @@ def lds_bytes(spec):
 
 
 def applicable(spec):
-  """Models of the 8-lanes-per-filter layout (<= 22 error states) without feature-track kinds, extra arguments or a window shift,
+  """Models of the 8-lanes-per-filter layout with 13 .. 22 error states, without feature-track kinds, extra arguments or a window shift,
   whose workgroup fits a quarter of a CU's LDS."""
   GL, _, FPW = w3.layout(spec)
   FPW = FPG
   zmax = max(k.zdim for k in spec.kinds)
   plain = all(k.He_sym is None and k.ea_sym is None for k in spec.kinds)
   from rednose_amd.codegen import tuning
-  return GL == 8 and plain and spec.N == 0 and FPW * zmax <= 64 and zmax <= spec.dim_err and lds_bytes(spec) <= LDS_BUDGET
+  # below 13 error states k_run already has several wavefronts per SIMD and the second wavefront only adds barriers: kinematic9 (E = 9) 7.02 ms
+  # with k_run against 8.04 with k_run2, rand13 21.3 against 18.2, rand17 34.9 against 31.0 (tools/ab_run, 32 768 filters x 1 000 steps;
+  # profiles/r5_run2_small_models_ab.txt)
+  return (GL == 8 and spec.dim_err >= MIN_E and plain and spec.N == 0 and FPW * zmax <= 64 and zmax <= spec.dim_err
+          and lds_bytes(spec) <= LDS_BUDGET)
 
 
 JB = int(__import__('os').environ.get('RUN2_JB', '4'))            # columns per block of the rank-Z passes (emit_wide3 runs 4 with a 512-register budget; here the budget is 256)

@@ -878,7 +878,7 @@ extern "C" __attribute__((visibility("default"))) void host_wide_run(int grid, d
 
 
 @pytest.mark.parametrize("name,variant", [("kinematic9", "k_run"), ("rand24", "k_run"), ("live_maha", "k_run"),
-                                          ("kinematic9", "k_run2"), ("rand17", "k_run2"), ("live_maha", "k_run2")])
+                                          ("rand13", "k_run2"), ("rand17", "k_run2"), ("live_maha", "k_run2")])
 def test_lane_group_fused_run_kernel_on_the_host(tmp_path, name, variant):
   """k_run of the lane-group family (and k_run2, its two-wavefront form: emit_run2.py -- a thread per lane of BOTH wavefronts, the
   workgroup barriers as barriers over all 128), filtered trace and flags included, against the oracle's batch_run: a ragged last tile, fewer

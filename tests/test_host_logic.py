@@ -385,3 +385,33 @@ def test_register_broadcast_smoother_is_chosen_where_it_applies_and_falls_back()
   assert "k_rts_group<RtsModel>" in textg and "void k_rts3(" not in textg
   assert not emit_rts4.applicable(build_spec(**Kinematic9Kalman.model()))        # odd number of error states
   assert not emit_rts4.applicable(build_spec(**R.Random24Kalman.model()))        # four 24 x 24 images do not fit 20 KB
+
+
+def test_two_wavefront_fused_run_is_chosen_where_it_applies_and_falls_back():
+  """emit_run2.applicable: lane-group models of the 8-lanes-per-filter layout with 13 .. 22 error states (below, k_run is the faster one) without feature-track kinds, extra arguments
+  or a window shift; the library then carries k_run2 INSTEAD of k_run (same batch_run entry point), the fallback `no_run2` (gen_code takes it
+  when k_run2 does not fit 256 registers without scratch) and the knob run2=0 emit k_run again."""
+  import examples.random_kf as R
+  from examples.kinematic9_kf import Kinematic9Kalman
+  from rednose_amd.codegen import emit, emit_run2, tuning
+  from rednose_amd.codegen.spec import build_spec
+  s9 = build_spec(**R.Random13Kalman.model())
+  assert emit_run2.applicable(s9) and emit_run2.layout2(s9) == (8, 2, 8, 1) and emit_run2.lds_bytes(s9) <= emit_run2.LDS_BUDGET
+  _, text = emit.emit(s9)
+  assert "void k_run2(" in text and "void k_run(" not in text and "hipLaunchKernelGGL(k_run2," in text and "dim3(R2_THREADS)" in text
+  assert text.count("rn::wg_barrier();") >= 4 and "rn::flag_set(" in text and "rn::flag_wait(" in text
+  assert "__syncthreads" not in text      # (its release fence would wait for the trace stores in flight)
+  # one update body for all kinds: the per-kind parts are switches inside it
+  assert text.count("void update_rows_r2(") == 1 and text.count("void predict_rows_r2(") == 1
+  _, text1 = emit.emit(s9, fallbacks=("no_run2",))
+  assert "void k_run(" in text1 and "void k_run2(" not in text1 and "hipLaunchKernelGGL(k_run," in text1
+  os.environ["RN_TUNE"] = "run2=0"
+  try:
+    _, text0 = emit.emit(s9)
+  finally:
+    del os.environ["RN_TUNE"]
+  assert "void k_run(" in text0 and "void k_run2(" not in text0
+  assert not emit_run2.applicable(build_spec(**R.Random24Kalman.model()))        # 16 lanes per filter
+  assert not emit_run2.applicable(build_spec(**Kinematic9Kalman.model()))        # 9 error states: k_run measured faster
+  from examples.feature_kf import FeatureKalman
+  assert not emit_run2.applicable(build_spec(**FeatureKalman.model()))           # feature-track kinds, window shift
