@@ -31,6 +31,11 @@ for rep in range(3):
   e[0].record()
   f.run(ts, kinds, zc, Rs, flags=True, out=(tx, tP))
   e[1].record()
+  if os.environ.get("RN_C4_GAP_MS"):      # (experiment: idle time between the two passes -- is the backward pass's time a function of what ran just before it?)
+    import time
+    torch.cuda.synchronize()
+    time.sleep(float(os.environ["RN_C4_GAP_MS"]) * 1e-3)
+    e[1].record()
   f._rts_on(tx, tP, ts, n, None)      # pylint: disable=protected-access
   e[2].record()
   torch.cuda.synchronize()
