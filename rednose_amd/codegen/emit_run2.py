@@ -7,9 +7,10 @@ registers parked in AGPRs around them (profiles/tuning_notes.md).  LDS (an E x E
 CU, one per SIMD: nothing else can issue while a chain waits.
 
 Here a workgroup is TWO wavefronts on the same eight filters and the same LDS block:
-  * wavefront 0 (matrix) keeps the rows of P in registers and runs emit_wide3's predict_rows / update_*_rows, nothing else;
-  * wavefront 1 (scalar) keeps x in registers (one lane per filter) and runs the scalar phase functions, the observation /
-    residual / flag / state-trace traffic, and the error injection.
+  * wavefront 0 (matrix) keeps the rows of P in registers and runs the covariance algebra (predict_rows_r2 / update_rows_r2 below:
+    emit_wide3's sums in emit_wide3's order, ONE body each for all kinds of process noise / observation), nothing else;
+  * wavefront 1 (scalar) runs emit_wide2's scalar phase functions (one lane per filter) against the filters' slots, the
+    observation / residual / flag / state-trace traffic, and the error injection.
 They meet at workgroup barriers (s_waitcnt lgkmcnt(0) + s_barrier: LDS only -- a full fence would drain the matrix wavefront's
 32 KB of trace stores at every barrier), per step t:
 
@@ -25,10 +26,12 @@ They meet at workgroup barriers (s_waitcnt lgkmcnt(0) + s_barrier: LDS only -- a
   (*) once per step: before B1 when the step has no predict (the matrix wavefront is still in the tail of the step before),
       after it otherwise (under the predict).
 
-The slot cannot overlay F and He any more (both are live between B1 and B2); x leaves the slot for the scalar wavefront's
-registers instead (the state trace and the final store stage it through the F region, which is dead then), so eight filters'
-slots, images and G / K^T buffers stay under 40 KB: four workgroups = eight wavefronts per CU, two per SIMD, at <= 256 registers.
-Arithmetic, order of operations and results are k_run's (same device functions against another slot layout): the parity tests
+The slot cannot overlay F and He any more (both are live between B1 and B2); the room comes from the G / K^T buffer, which is the
+first rows of the filter's covariance image here (the update never touches the image): eight filters' slots and images stay under
+40 KB -- four workgroups = eight wavefronts per CU, two per SIMD, at <= 256 registers (what that took from the generator: DESIGN.md
+section 10).  Served: 13 .. 22 error states without feature-track kinds (applicable()); `k_run` stays the fused run of every other
+lane-group model and the fallback (`no_run2`).  Measured: profiles/tuning_notes.md, profiles/r5_run2_*.txt.
+Arithmetic, order of operations and results are k_run's (same scalar functions against another slot layout): the parity tests
 of the fused run apply unchanged (tests/test_gpu_run.py, test_gpu_random.py, test_gpu_fullsize.py, test_gpu_asymmetric.py) and
 tests/test_emit_host.py runs the kernel on the host with a thread per lane of both wavefronts.
 Reference: EKF_sym.predict_and_update_batch's loop body, ekf_sym.py:473-538, over a schedule; ekf_c.c:8-121.
