@@ -47,15 +47,11 @@ FPG = 8           # filters per workgroup (tile): the scalar wavefront serves th
 
 
 def layout2(spec):
-  """-> (GL lanes per filter, R rows of P per lane, FPW filters per matrix wavefront, ND matrix wavefronts per workgroup).
-  Up to 16 error states: emit_wide3's 8 lanes x 2 rows, one matrix wavefront for the tile's 8 filters.  17 .. 22: TWO matrix
-  wavefronts of 4 filters each, 16 lanes x 2 rows -- 88 row registers instead of 132, so that three wavefronts per SIMD fit
-  (<= 168 registers each): a matrix wavefront is bound by the issue cadence of a wavefront that is (nearly) alone on its SIMD, and
-  two of them per SIMD overlap each other's latencies (profiles/tuning_notes.md: timeline of the one-matrix-wavefront form)."""
-  from rednose_amd.codegen import tuning
+  """-> (GL lanes per filter, R rows of P per lane, FPW filters per matrix wavefront, ND matrix wavefronts per workgroup): emit_wide3's
+  8 lanes x R rows, one matrix wavefront for the tile's 8 filters.  (Two matrix wavefronts of 4 filters each, 16 lanes x 2 rows, three
+  wavefronts per SIMD at 167 registers, were built and measured: 32.5 ms per config-4 chunk against 20.5 -- the SIMD's fp64 pipe is shared,
+  two matrix wavefronts on it take twice as long each.  profiles/tuning_notes.md; the kernel text keeps the wavefront index general.)"""
   E = spec.dim_err
-  if E > 16 and tuning.current().run2_nd == 2:
-    return 16, -(-E // 16), 4, 2
   return 8, -(-E // 8), 8, 1
 
 
@@ -102,8 +98,8 @@ def applicable(spec):
           and lds_bytes(spec) <= LDS_BUDGET)
 
 
-JB = int(__import__('os').environ.get('RUN2_JB', '4'))            # columns per block of the rank-Z passes (emit_wide3 runs 4 with a 512-register budget; here the budget is 256)
-CH = int(__import__('os').environ.get('RUN2_CH', '8'))            # entries of a row of A = P F^T formed per block (and row slot) of predict
+JB = 4            # columns per block of the rank-Z passes (2: 19.0 ms per config-4 chunk, 4: 18.7; emit_wide3 also runs 4)
+CH = 8            # entries of a row of A = P F^T formed per block (and row slot) of predict (4: 19.0 ms, 8: 18.8)
 
 
 def _ind(lines, n=2):
@@ -209,8 +205,7 @@ def update_fn(spec):
   dx and the flags leave for the slot as soon as the gain exists, followed by the workgroup barrier the scalar wavefront waits at;
   a flag (`he_release`) after the Joseph coefficients tells it that He and y are dead."""
   E = spec.dim_err
-  _, R, _, ND = layout2(spec)
-  tight = ND > 1      # the 168-register budget of three wavefronts per SIMD: fences around every row of He, G^T re-read after the factor
+  _, R, _, _ = layout2(spec)
   lay, _, Hss = w3._tables(spec, Run2Layout)      # pylint: disable=protected-access
   ZM = lay.zmax
   b = ["(void)sP;"]
@@ -221,8 +216,7 @@ def update_fn(spec):
   b.append("switch (kind) {")
   for k in spec.kinds:
     Hs, Z = Hss[k.kind], k.zdim
-    # (a fence per row of He: its entries are broadcast reads of the slot, and hipcc would fetch all of them -- 35 for live's accelerometer -- first)
-    ln = [f"kk{s_}[{zi}] = {sum_terms(term(cf, f'row{s_}[{c}]') for c, cf in Hs.row_nz(zi))};" + (" rn::wave_lds_sync();" if tight and len(Hs.row_nz(zi)) > 4 else "")
+    ln = [f"kk{s_}[{zi}] = {sum_terms(term(cf, f'row{s_}[{c}]') for c, cf in Hs.row_nz(zi))};"
           for zi in range(Z) for s_ in range(R)]
     ln.append(f"zk = {Z};" + (f" thr = {k.maha_thresh!r}; gate_on = true;" if k.maha_test else ""))
     b.append(f"  case {k.kind}: {{ " + " ".join(ln) + " break; }")
@@ -236,7 +230,7 @@ def update_fn(spec):
   b.append("switch (kind) {")
   for k in spec.kinds:
     Hs, Z = Hss[k.kind], k.zdim
-    ln = [f"HPH[{zi * ZM + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))};" + (" rn::wave_lds_sync();" if tight and len(Hs.row_nz(w)) > 4 else "")
+    ln = [f"HPH[{zi * ZM + w}] = {sum_terms(term(cf, f'sG[{zi} * {E} + {j}]') for j, cf in Hs.row_nz(w))};"
           for w in range(Z) for zi in range(Z)]
     ln += [f"Rl[{zi * ZM + w}] = gR[{zi * Z + w}];" for zi in range(Z) for w in range(Z)]
     b.append(f"  case {k.kind}: {{ " + " ".join(ln) + " break; }")
@@ -250,8 +244,6 @@ def update_fn(spec):
           f"    rn::spd_factor<{ZM}>(S, L, iL);", "  }", "}"]
   else:
     b.append("(void)thr; (void)gate_on;")
-  for s_ in range(R if tight else 0):      # (the lane's entries of G^T come back from the buffer: held in registers through the factor and the gate they are 2 R ZM registers too many)
-    b.append(" ".join(f"kk{s_}[{zi}] = sG[{zi} * {E} + rc{s_}];" for zi in range(ZM)))
   for s_ in range(R):
     b.append(f"rn::spd_solve<{ZM}>(L, iL, kk{s_});                       // K[row][:]")
     b.append(f"const double dx{s_} = " + " + ".join(f"kk{s_}[{zi}]*yv[{zi}]" for zi in range(ZM)) + ";")
@@ -267,7 +259,7 @@ def update_fn(spec):
   b.append("switch (kind) {")
   for k in spec.kinds:
     Hs, Z = Hss[k.kind], k.zdim
-    ln = [f"cc{s_}[{zi}] = {sum_terms(term(cf, f'row{s_}[{j}]') for j, cf in Hs.row_nz(zi))};" + (" rn::wave_lds_sync();" if tight and len(Hs.row_nz(zi)) > 4 else "")
+    ln = [f"cc{s_}[{zi}] = {sum_terms(term(cf, f'row{s_}[{j}]') for j, cf in Hs.row_nz(zi))};"
           for zi in range(Z) for s_ in range(R)]
     b.append(f"  case {k.kind}: {{ " + " ".join(ln) + " break; }")
   b += ["  default: break;", "}"]

@@ -17,7 +17,6 @@ variants do not overwrite generated/).  What each alternative measured: profiles
   run_block    steps per block of the lane-per-filter fused run without trace (0 = auto by model size, -1 = that kernel is not emitted)
   exact_math   1 = IEEE division / square root and ocml sin / cos in place of the fast primitives (reference build for the accuracy tests; full sin / cos range)
   run2         1 = fused run of lane-group models up to 22 error states as TWO wavefronts per tile, matrix + scalar (emit_run2), 0 = k_run (emit_wide3)
-  run2_nd      2 = two matrix wavefronts of 4 filters (16 lanes x 2 rows) per tile for 17 .. 22 error states (three wavefronts per SIMD), 1 = one of 8 filters (8 lanes x 3 rows)
   run2_prio    s_setprio level of emit_run2's scalar wavefront (its chain of dependent instructions issues ahead of the co-resident matrix wavefront's FMAs); 0 = none
   rts4         1 = smoother of lane-group models with register-broadcast operands (emit_rts4: 16 lanes x 2 rows, 4 filters per wavefront, two wavefronts per SIMD), 0 = rts3
   rts3         1 = smoother of lane-group models in the fused run's layout (emit_rts3: 8 filters per wavefront), 0 = rn::k_rts_group
@@ -40,7 +39,6 @@ class Tuning:
   run_block: int = 0
   rts3: int = 1
   run2_prio: int = 0              # (measured: 20.5-20.9 ms per config-4 chunk at 3 against 20.4 at 0 -- the scalar wavefront is not on the critical path)
-  run2_nd: int = 1               # (measured: 32.5 ms per config-4 chunk at 2 against 20.5-24.0 at 1 -- the SIMD's fp64 issue is shared, two matrix wavefronts per SIMD take twice as long each)
   run2: int = 1              # fused run with a scalar wavefront beside the matrix wavefront (emit_run2: two wavefronts per SIMD); 0 = emit_wide3's k_run
   rts4: int = 1              # smoother with every cross-lane operand by row_newbcast, two wavefronts per SIMD (emit_rts4: even E, 8 .. 22 error states); 0 = emit_rts3
   exact_math: int = 0        # 1 = IEEE division / sqrt and the library's sin / cos instead of the hardware-seed + Newton primitives and rn::sincos_fast (a reference build for tests: tests/test_gpu_live.py)

@@ -880,6 +880,10 @@ extern "C" __attribute__((visibility("default"))) void host_wide_run(int grid, d
 @pytest.mark.parametrize("name,variant", [("kinematic9", "k_run"), ("rand24", "k_run"), ("live_maha", "k_run"),
                                           ("rand13", "k_run2"), ("rand17", "k_run2"), ("live_maha", "k_run2")])
 def test_lane_group_fused_run_kernel_on_the_host(tmp_path, name, variant):
+  _fused_run_host_case(tmp_path, name, variant)
+
+
+def _fused_run_host_case(tmp_path, name, variant):
   """k_run of the lane-group family (and k_run2, its two-wavefront form: emit_run2.py -- a thread per lane of BOTH wavefronts, the
   workgroup barriers as barriers over all 128), filtered trace and flags included, against the oracle's batch_run: a ragged last tile, fewer
   workgroups than tiles, a schedule mixing every non-feature kind with dt = 0 steps, gated observations, an unknown kind (flag 8,
