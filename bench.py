@@ -51,13 +51,23 @@ FP64_VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9     # 256 CUs x 4 SIMDs x 16 fp64 lane
 #                                               (78.6 TFLOP/s vector fp64 counts an FMA as two)
 
 
-def hbm_roofline(bytes_per_launch, launch_s, kernel, traffic=None, **more):
+def hbm_roofline(bytes_per_launch, launch_s, kernel, traffic=None, wall_s=None, traffic_source=None, **more):
+  """`frac` prices the algorithmic bytes against the launch duration the HIP events measured; `frac_wall` (when `wall_s`, the host's
+  wall clock per step over the same region, is given) against what a caller's clock sees -- event interval + whatever the queue left idle.
+  `traffic` is a PMC counter figure per launch; `traffic_source` says where it was read from (it is not re-measured in this run)."""
   a = bytes_per_launch / launch_s / 1e9
-  return dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS, traffic=traffic, kernel=kernel,
-              algorithmic_bytes_per_launch=bytes_per_launch, launch_us=launch_s * 1e6, **more)
+  out = dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS, traffic=traffic, kernel=kernel,
+             algorithmic_bytes_per_launch=bytes_per_launch, launch_us=launch_s * 1e6, **more)
+  if traffic is not None:
+    out["traffic_source"] = traffic_source
+  if wall_s is not None:
+    out["frac_wall"] = bytes_per_launch / wall_s / 1e9 / HBM_PEAK_GBS
+    out["wall_us"] = wall_s * 1e6
+  return out
 
 
 TRAFFIC_CARRIED = {}      # section label -> note, for counters taken on an earlier build of the library that is being timed
+TRAFFIC_SOURCE = {}       # section label -> where its counter figure came from (file, section, digest of the library it was taken on)
 
 
 def measured_traffic(label, lib_name, gen):
@@ -78,7 +88,15 @@ def measured_traffic(label, lib_name, gen):
     if now not in rec.get("carried_to", []):
       return None
     TRAFFIC_CARRIED[label] = f"counters taken on build {rec['lib_digest'][:12]} of lib{lib_name}.so; since then: {rec.get('carried_note', '?')}"
+  TRAFFIC_SOURCE[label] = (f"profiles/pmc_traffic.json[{label}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiles/collect.sh on "
+                           f"lib{lib_name}.so digest {rec['lib_digest'][:12]} (an earlier GPU call; not re-measured in this run)")
   return rec["hbm_bytes_per_launch"]
+
+
+def traffic_kw(label, lib_name, gen, scale=1.0):
+  """`traffic` / `traffic_source` keyword arguments of hbm_roofline for one section of profiles/pmc_traffic.json."""
+  per = measured_traffic(label, lib_name, gen)
+  return dict(traffic=None) if per is None else dict(traffic=per * scale, traffic_source=TRAFFIC_SOURCE.get(label))
 
 
 def fp64_valu_instructions(lib, kernel="k_run", unroll=1):
@@ -483,11 +501,21 @@ def config4_extra(torch, dev, rank, nb=16384, T=2100, chunk=8192):
       finite = finite and bool(torch.isfinite(xs[0]).all()) and bool(torch.isfinite(Ps[0]).all()) and bool(torch.isfinite(xs[-1]).all())
     assert finite, "config 4: non-finite smoothed estimate"
     res = dict(fwd_ms=fwd, bwd_ms=bwd, gated=float(np.mean(gated)))
+  # The backward pass again on ONE chunk with every step advancing time (ts = 0.01 k): no step takes the identity-gain path of k_rts4
+  # (dt == 0: Ck = I, emit_rts4.py), every step pays the factorisation, the substitutions and both products -- the cost of the full
+  # step stays visible next to the stream's figure, in which 1.1 of every 2.1 steps have dt = 0.  The trace is the last chunk's
+  # smoothed one (valid states and covariances; the pass runs in place on it).
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  f._rts_on(tx, tP, 0.01 * np.arange(T), chunk, None)      # pylint: disable=protected-access
+  e1.record()
+  torch.cuda.synchronize()
+  full_ms = e0.elapsed_time(e1)
+  assert bool(torch.isfinite(tP[0]).all()) and bool(torch.isfinite(tx[0]).all()), "config 4 (all steps dt > 0): non-finite smoothed estimate"
   del tx, tP
   def chunk_traffic(label):
     """PMC traffic of the 8 192 x 2 100 chunk launch (profiles/pmc_workload.py), times the chunks swept here (sum over launches, like the bytes)."""
-    per = measured_traffic(label, "live_maha", gen) if (chunk == 8192 and T == 2100) else None
-    return None if per is None else per * (nb / chunk)
+    return traffic_kw(label, "live_maha", gen, scale=nb / chunk) if (chunk == 8192 and T == 2100) else dict(traffic=None)
 
   try:          # the smoother kernel this library was built with (emit_rts4's k_rts4, its fallbacks: emit_rts3's k_rts3, the lane-group rn::k_rts_group)
     with open(os.path.join(gen, "live_maha.kernels.txt"), encoding="utf-8") as fh:
@@ -498,15 +526,37 @@ def config4_extra(torch, dev, rank, nb=16384, T=2100, chunk=8192):
     rts_kernel, run_kernel = "k_rts*", "k_run*"
   fwd_bytes = nb * T * 8.0 * ((23 + 484) + 2 * 3) + nb * T           # filtered trace written, z read, y written, flags
   bwd_bytes = nb * (T - 1) * 8.0 * 2 * (23 + 484)                     # filtered pair read, smoothed pair written
+  # fp64 work of a FULL backward step, counted on the algorithm (E = 22): L D L^T E^3 / 6, two triangular solves with E right-hand sides E^3,
+  # T = Ck D E^3, U = T Ck^T on the lower blocks E^3 / 2 -> 28.4 k FMAs per filter-step; a dt = 0 step of the stream takes the identity-gain
+  # path (one subtraction and one addition per entry of P: not counted).  Priced against the vector fp64 issue rate like the fused runs.
+  E_ = 22
+  fma_full = E_ ** 3 * (1 / 6 + 1 + 1 + 1 / 2)
+  dts = np.diff(ts)
+  try:
+    with open(os.path.join(gen, "live_maha.hip"), encoding="utf-8") as fh:
+      id0 = "if (dt == 0.0 && !first)" in fh.read()      # this build's k_rts4 has the identity-gain path (tuning knob rts_dt0, emit_rts4.dt0_path)
+  except OSError:
+    id0 = False
+  full_steps_frac = float(np.mean(dts[:-1] != 0.0)) if id0 else 1.0      # (the newest step always takes the full path)
+  bwd_rate = nb * (T - 1) / (res["bwd_ms"] * 1e-3)
+  full_rate = chunk * (T - 1) / (full_ms * 1e-3)
+  rb = hbm_roofline(bwd_bytes, res["bwd_ms"] * 1e-3, rts_kernel, **chunk_traffic("config4_backward"))
+  rb.update(fp64_fma_per_full_step=fma_full, full_steps_fraction=full_steps_frac, fp64_frac=fma_full * full_steps_frac * bwd_rate / FP64_VALU_LANE_OPS,
+            fp64_note="algorithmic FMAs of the steps that take the full path (dt != 0) x steps/s / 39.3 T fp64 lane-instructions/s; the kernel issues ~1.5 x that "
+                      "(11 of 16 DPP lanes busy, scalar phase on one lane per filter)")
+  rfull = hbm_roofline(chunk * (T - 1) * 8.0 * 2 * (23 + 484), full_ms * 1e-3, rts_kernel + " (every step dt > 0: full solve on all steps)", traffic=None)
+  rfull.update(fp64_frac=fma_full * full_rate / FP64_VALU_LANE_OPS, steps_per_s=full_rate, chunk_filters=chunk)
   return {"batch": nb, "T": T, "chunk_filters": chunk,
           "forward_steps_per_s": nb * T / (res["fwd_ms"] * 1e-3), "backward_steps_per_s": nb * (T - 1) / (res["bwd_ms"] * 1e-3),
           "combined_steps_per_s": nb * T / ((res["fwd_ms"] + res["bwd_ms"]) * 1e-3),
           "forward_ms": res["fwd_ms"], "backward_ms": res["bwd_ms"], "gated_fraction_of_gnss": res["gated"],
           "trace_bytes_per_chunk": int(T * chunk * (23 + 484) * 8),
-          "roofline_forward": hbm_roofline(fwd_bytes, res["fwd_ms"] * 1e-3, f"{run_kernel} (trace + gate flags)", traffic=chunk_traffic("config4_forward")),
-          "roofline_backward": hbm_roofline(bwd_bytes, res["bwd_ms"] * 1e-3, rts_kernel, traffic=chunk_traffic("config4_backward")),
+          "roofline_forward": hbm_roofline(fwd_bytes, res["fwd_ms"] * 1e-3, f"{run_kernel} (trace + gate flags)", **chunk_traffic("config4_forward")),
+          "roofline_backward": rb,
+          "roofline_backward_dt_gt0": rfull,
           "note": "forward = fused batch_run writing the filtered trace + gate flags; backward = batch_rts recomputing the predicted pairs; "
-                  "bytes: forward 4 104 B + 1 flag per filter-step, backward 8 112 B per filter-step"}
+                  "bytes: forward 4 104 B + 1 flag per filter-step, backward 8 112 B per filter-step (both paths of k_rts4 read the filtered pair and "
+                  "write the smoothed pair); roofline_backward_dt_gt0 = the same kernel on one chunk whose steps all advance time"}
 
 
 def msckf_extra(torch, dev):
@@ -531,7 +581,7 @@ def msckf_extra(torch, dev):
   msf = e0.elapsed_time(e1) / Kf
   bf = 8.0 * (2 * (36 + 36 * 36) + 6 + 3 + 3)
   return {"batch": nf, "steps": Kf, "value": nf / (msf * 1e-3), "unit": "steps/s",
-          "roofline": hbm_roofline(bf * nf, msf * 1e-3, "k_step_2<true>", traffic=measured_traffic(f"feature36_b{nf}", FK.name, genf)),
+          "roofline": hbm_roofline(bf * nf, msf * 1e-3, "k_step_2<true>", **traffic_kw(f"feature36_b{nf}", FK.name, genf)),
           "note": "fused predict + feature-track update (Z = 6 projected to 3), one filter per wavefront, per-filter landmarks"}
 
 
@@ -687,14 +737,14 @@ def main():
       ls = o["dev_ms"] * 1e-3 / oK
       rec = {"batch": on, "steps": oK, "value": on * oK / o["wall"], "unit": "steps/s", "kinds": o["kinds"],
              "algorithmic_bytes_per_filter_step": o["bytes_per_step"],
-             "roofline": hbm_roofline(o["bytes_per_step"] * on, ls, kernel, traffic=measured_traffic(f"{'kinematic6' if key == 'kinematic6_1M' else (key or om)}_b{on}", o["M"].name, o["gen"]),
-                                      launch_us_median=o["launch_us_median"])}
+             "roofline": hbm_roofline(o["bytes_per_step"] * on, ls, kernel, **traffic_kw(f"{'kinematic6' if key == 'kinematic6_1M' else (key or om)}_b{on}", o["M"].name, o["gen"]),
+                                      wall_s=o["wall"] / oK, launch_us_median=o["launch_us_median"])}
       if note:
         rec["note"] = note
       extra[key or om] = rec
     stepwise("live", 16384, 420, 42, "k_step_{4,10,12}<true> (IMU + GNSS stream mix)")
     stepwise("live", 16384, 200, 20, "k_step_4<true>", key="live_dt_gt0", only_kind=4,
-             note="every launch advances time: the launch that runs the covariance predict (in the stream, 2 of 2.1 launches have dt = 0)")
+             note="every launch advances time: the launch that runs the covariance predict (in the stream, 1.1 of every 2.1 launches have dt = 0)")
     stepwise("kinematic", 65536, 500, 50, "k_step_1<true>",
              note="2-state model, 112 B per filter-step: one launch per step is bounded by launch latency; see kinematic_fused")
     stepwise("kinematic6", 1 << 20, 200, 20, "k_step_1<true>", key="kinematic6_1M")
@@ -729,8 +779,9 @@ def main():
                              f"batch {n} on rank 0, shared R, scalar dt", "batch_per_gpu": n,
                  "steady_state": f"device warmed to steady state before the timed region: {r['steady']['launches']} extra untimed launches (<= {STEADY_CAP_S} s), see untimed_launches / cold_launch_us / steady_state_warmup",
                  "global_batch": int(round(steps_total / K)), "parallelism": f"batch-sharded x{world}, no data-path collective"},
-      "roofline": hbm_roofline(r["bytes_per_step"] * n, launch_s, kern, traffic=measured_traffic(f"{M.name}_b{n}", M.name, r["gen"]),
-                               launch_us_median=r["launch_us_median"], launch_us_median_groups=r["launch_us_groups"]),
+      # frac: HIP events over the K timed launches; frac_wall: the same bytes against ms_per_step (host wall clock, max over ranks)
+      "roofline": hbm_roofline(r["bytes_per_step"] * n, launch_s, kern, **traffic_kw(f"{M.name}_b{n}", M.name, r["gen"]),
+                               wall_s=wall_max / K, launch_us_median=r["launch_us_median"], launch_us_median_groups=r["launch_us_groups"]),
       "steady_state_warmup": r["steady"],
     }
     if r.get("group_us"):

@@ -62,6 +62,14 @@ def compile_filter(folder, name, extra_flags=(), verbose=False):
   if res.returncode != 0:
     raise RuntimeError(f"hipcc failed for {src}:\n{res.stderr[-6000:]}")
   usage = kernel_resources(res.stderr)
+  if any("k_rts4" in k for k in usage):      # inline-assembly DPP operands: hipcc's hazard pass does not see them (dpp_hazards)
+    dis = disassemble(lib)
+    hz = dpp_hazards(dis) if dis is not None else []
+    for k in usage:
+      if "k_rts4" in k:
+        usage[k]["dpp_hazards"] = len(hz)
+    if hz and verbose:
+      print(f"note: k_rts4 has {len(hz)} DPP read-after-write hazard(s), first: {hz[0]}")
   with open(os.path.join(folder, f"{name}.kernels.txt"), "w", encoding="utf-8") as f:
     f.write("# per-kernel resources reported by hipcc (-Rpass-analysis=kernel-resource-usage) for lib%s.so\n" % name)
     f.write("%-60s %6s %6s %8s %8s %7s %6s\n" % ("kernel", "vgprs", "agprs", "scratch", "lds", "spills", "occ"))
@@ -75,9 +83,78 @@ def compile_filter(folder, name, extra_flags=(), verbose=False):
   return lib
 
 
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def disassemble(lib):
+  """Disassembly (llvm-objdump -d) of the gfx950 code object inside a HIP shared library, or None when the LLVM tools are absent."""
+  import tempfile
+  objdump = os.path.join(LLVM_BIN, "llvm-objdump")
+  if not os.path.exists(objdump):
+    return None
+  with tempfile.TemporaryDirectory() as d:
+    fb, co = os.path.join(d, "lib.hipfb"), os.path.join(d, "lib.co")
+    subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", lib, fb], check=True, capture_output=True)
+    subprocess.run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fb}",
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True, capture_output=True)
+    return subprocess.run([objdump, "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+
+
+def _vgprs(operand):
+  """VGPR numbers an assembly operand names: v7, -v7, |v7|, v[6:7] (anything else: none)."""
+  m = re.fullmatch(r"[-|]*v(\d+)\|?", operand)
+  if m:
+    return {int(m.group(1))}
+  m = re.fullmatch(r"[-|]*v\[(\d+):(\d+)\]\|?", operand)
+  if m:
+    return set(range(int(m.group(1)), int(m.group(2)) + 1))
+  return set()
+
+
+def dpp_hazards(disassembly, kernel="k_rts4", wait_states=2):
+  """DPP read-after-VALU-write hazards of one kernel: a list of (address, instruction, offending earlier instruction).
+
+  On gfx9 a VALU instruction that reads a VGPR through DPP (its src0) needs TWO wait states after the VALU instruction that wrote
+  that VGPR (LLVM GCNHazardRecognizer::checkDPPHazards, DppVgprWaitStates = 2); every instruction issued in between is one wait
+  state, `s_nop N` is N + 1.  hipcc inserts them for code it generates but not inside inline assembly, and emit_rts4's
+  RN4_FMAC / RN4_FNMAC carry none (only RN4_BC has its `s_nop 1`): whether the DPP source of a `v_fmac_f64_dpp` was produced by
+  the instruction in front of it is up to hipcc's scheduling of THIS model's expressions.  compile_filter runs this check on
+  every library with k_rts4 and gen_code falls back to the smoother without DPP (`no_rts4`) when it finds anything;
+  tests/test_abi.py runs it over the shipped models.  The walk is linear over the kernel's text (a branch target starts with
+  the history of the instruction printed before it, which is the fall-through predecessor; a hazard across a taken branch
+  would need the writer to be the last VALU instruction before an s_cbranch -- the branch itself is then one wait state and at
+  least one more instruction stands between it and any DPP read in the code emit_rts4 prints)."""
+  out, cur, hist = [], None, []
+  for line in disassembly.split("\n"):
+    m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+    if m:
+      cur, hist = m.group(1), []
+      continue
+    if cur is None or kernel not in cur:
+      continue
+    m = re.match(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", line)
+    if not m:
+      continue
+    op, args, addr = m.group(1), m.group(2), m.group(3)
+    ops = [a.strip() for a in args.split(",")] if args else []
+    if op.endswith("_dpp") or " row_newbcast:" in args or " quad_perm:" in args or " row_shr:" in args or " row_shl:" in args or " row_bcast:" in args:
+      src0 = _vgprs(ops[1].split(" ")[0]) if len(ops) > 1 else set()
+      for back, (w_op, w_args, w_regs) in enumerate(reversed(hist[-wait_states:])):
+        if w_regs & src0:
+          out.append((addr, f"{op} {args}", f"{w_op} {w_args} ({back} wait state(s) before)"))
+    if op == "s_nop":
+      hist += [("s_nop", "", set())] * (int(args, 0) + 1)
+    elif op.startswith("v_") and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):      # a VALU write of a VGPR (compares / lane reads write SGPRs)
+      hist.append((op, args, _vgprs(ops[0].split(" ")[0]) if ops else set()))
+    else:
+      hist.append((op, args, set()))
+    del hist[:-8]
+  return out
+
+
 def spilled_kernels(usage, prefixes=("k_step", "k_run", "k_predict", "k_rts", "k_maha")):
-  """Names of shipped kernels that use scratch memory or spilled registers."""
-  return [k for k, u in usage.items() if k.startswith(prefixes) and (u["scratch"] > 0 or u["vgpr_spill"] > 0)]
+  """Names of shipped kernels that use scratch memory or spilled registers, or (k_rts4) read a DPP source too soon after it was written."""
+  return [k for k, u in usage.items() if k.startswith(prefixes) and (u["scratch"] > 0 or u["vgpr_spill"] > 0 or u.get("dpp_hazards", 0) > 0)]
 
 
 def kernel_resources(remarks):

@@ -55,6 +55,12 @@ MACROS = r"""
 #define RN4_FNMAC(acc, src, coef, L) asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:" #L " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(coef))
 // (s_nop 1: a DPP read of a register the previous vector instruction wrote wants two wait states; inline asm is opaque to hipcc's hazard pass)
 #define RN4_BC(dst, src, L)          asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:" #L " row_mask:0xf bank_mask:0xf" : "=v"(dst) : "v"(src))
+// RN4_FMAC / RN4_FNMAC carry no wait states (two per instruction would cost the products a third of their issue rate).  Their DPP sources are
+// register rows that ordinary C statements wrote (the rows of Pk1_k, the factor's scaled columns): hipcc may sink such a statement to right in
+// front of its first reader.  So at the head of every phase that reads a row set through DPP the rows are pinned (rn::pin: the writers cannot sink
+// below) and RN4_SETTLE() puts the two wait states between them and the phase -- volatile asm statements keep their order.  What remains possible is
+// a register copy hipcc's allocator places in front of a reader: rednose_amd.build.dpp_hazards checks every built k_rts4 for that.
+#define RN4_SETTLE()                 asm volatile("s_nop 1")
 #endif
 """
 
@@ -71,6 +77,12 @@ def rows_per_lane(spec):
 def lds_bytes(spec, slot):
   D, E = spec.dim_x, spec.dim_err
   return 8 * (FPW * E * E + 2 + FPW * slot + 2 * (FPW * D + 2) + FPW * E + 2 + E + 2 * FPW * (GL - -(-E // rows_per_lane(spec))) + 2)
+
+
+def dt0_path(spec):
+  """Steps with dt == 0 take the identity-gain path (see kernel()): only for models whose predict(dt = 0) is the identity symbolically."""
+  from rednose_amd.codegen import tuning
+  return bool(tuning.current().rts_dt0) and spec.identity_at_dt0()
 
 
 def applicable(spec):
@@ -124,6 +136,13 @@ def kernel(spec):
   def ncol(s):           # columns a row slot keeps of a SYMMETRIC matrix: up to its last row (block lower triangle)
     return last_row(s) + 1
 
+  def settle(name, ind="      "):
+    """the block-lower rows `name` are about to be read through DPP: see RN4_SETTLE"""
+    for s_ in S:
+      A("#pragma unroll")
+      A(f"{ind}for (int j = 0; j < {ncol(s_)}; j++) rn::pin({name}{s_}[j]);")
+    A(f"{ind}RN4_SETTLE();")
+
   def rows_decl(name, sym_=False):
     return " ".join(f"double {name}{s}[{ncol(s) if sym_ else E}];" for s in S)
 
@@ -157,8 +176,6 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   __shared__ __attribute__((aligned(16))) double s_dv[{FPW} * {E} + 2];          // inv_err(xk1_k, xk1_n), then Ck delta
   __shared__ __attribute__((aligned(16))) double s_trash[{E} + 2 * {FPW * (GL - RS)} + 2];      // where the idle lanes' row stores go (no predicated regions around LDS stores): overlapping rows, 16 bytes apart
   const int lane = threadIdx.x;
-  const int g = lane / {GL};
-  const int c = lane % {GL};
   int qoff = 0;
   for (int i = lane; i < {EE}; i += 64) qoff |= (i / {E} != i % {E}) && (gQ[i] != 0.0);
   const bool qdiag = !__any(qoff);      // a diagonal process noise (the usual case): its row entry is requested at the head of every step
@@ -166,6 +183,10 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {{
     const int64_t base = tile * {FPW};
     const int cnt = (n - base) < {FPW} ? (int)(n - base) : {FPW};
+    int lt = lane;      // opaque per tile: index arithmetic derived from it is not hoisted to the kernel's entry (where it was ~80 spilled registers)
+    asm volatile("" : "+v"(lt));
+    const int g = lt / {GL};
+    const int c = lt % {GL};
     const bool live = g < cnt;
     const int gg = live ? g : 0;
     const bool lead = live && c == 0;
@@ -174,8 +195,8 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
     double* sxk = s_xk + gg * {D};
     double* sxn = s_xn + gg * {D};
     double* sdv = s_dv + gg * {E};
-    int ct = c, lt = lane;      // opaque per tile: index arithmetic derived from them is not hoisted to the kernel's entry (where it was ~80 spilled registers)
-    asm volatile("" : "+v"(ct), "+v"(lt));""")
+    int ct = c;
+    asm volatile("" : "+v"(ct));""")
   for s in S:
     A(f"    const int rr{s} = ct + {RS * s}; const bool ok{s} = live && ct < {RS} && rr{s} < {E}; const int rc{s} = (ct < {RS} && rr{s} < {E}) ? rr{s} : 0;")
   A("    if (T == 1) {      // nothing to smooth, the single estimate's predicted pair is not available: the filtered pair passes through")
@@ -231,6 +252,102 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   A("      const double dt = dtc;")
   A("      rn::wave_lds_sync();")
   A("      RN_RTS_STAMP(1);")
+  if dt0_path(spec):
+    # ---- steps with dt == 0 of a model whose predict(dt = 0) is the identity (FilterSpec.identity_at_dt0: f(x, 0) == x, F(x, 0) == I symbolically, and
+    # dt Q = 0): the predicted pair of step k IS the filtered one, bit for bit -- what the full path computes there is Pk1_k = sym(Pk_k), A = Pk_k and
+    # Ck = Pk1_k^-1-solve of itself = I up to the rounding of the factorisation (|Ck - I| <= 2.3e-9 in the reference's own golden, np.linalg.solve).
+    # With Ck = I (ekf_sym.py:672-686):  xk_n = err(xk_k, inv_err(xk1_k, xk1_n))  -- NOT xk1_n: err o inv_err is not the identity for finite
+    # rotations --,  Pk_n = Pk_k + (Pk1_n - Pk1_k)  evaluated as written.  No factorisation, no substitutions, no products: the step is one read and
+    # one write of the covariance.  dt is a scalar of the launch (ts is shared by the batch): the branch is uniform.  The recursion's first step always
+    # takes the full path (it also produces the newest pair).  Tuning knob rts_dt0 = 0 keeps the full solve on every step.
+    A("      if (dt == 0.0 && !first) {")
+    A("        if (lead && (norm_quats & 2)) {")
+    A(f"          double xv[{D}];")
+    A("#pragma unroll")
+    A(f"          for (int i = 0; i < {D}; i++) xv[i] = sxn[i];")
+    A(f"         {quat}")
+    A("#pragma unroll")
+    A(f"          for (int i = 0; i < {D}; i++) sxn[i] = xv[i];")
+    A("        }")
+    A("        rn::wave_lds_sync();")
+    A("        int lo = lb;")
+    A('        asm volatile("" : "+v"(lo));')
+    A(f"        for (int i = lo; i < cnt * {D}; i += 64) xs[((k + 1) * n + base) * {D} + i] = s_xn[i];      // smoothed state of step k + 1 (after its renormalisation)")
+    A(f"        double xnext[{XT}];      // filtered state of the next (older) step")
+    A("#pragma unroll")
+    A(f"        for (int it = 0; it < {XT}; it++) {{ const int i = lo + 64 * it; xnext[it] = xf[((k > 0 ? k - 1 : 0) * n + base) * {D} + (i < cnt * {D} ? i : 0)]; }}")
+    A("        dtc = k > 0 ? ts[k] - ts[k - 1] : 0.0;")
+    A("        rn::wave_lds_sync();      // every lane has read xk1_n: the buffer takes xk_n")
+    A("        if (lead) {      // xk1_k = f(xk_k, 0) = xk_k [renormalised like the forward pass]; delta = inv_err(xk1_k, xk1_n); xk_n = err(xk_k, delta)")
+    A(f"          double xa[{D}], xv[{D}], x1n[{D}], xnew[{D}], delta[{E}];")
+    A("#pragma unroll")
+    A(f"          for (int i = 0; i < {D}; i++) {{ xa[i] = sxk[i]; xv[i] = xa[i]; x1n[i] = sxn[i]; }}")
+    A(f"          if (norm_quats & 1) {{{quat} }}")
+    A("          inv_err_fun(xv, x1n, delta);")
+    A("          err_fun(xa, delta, xnew);")
+    A("#pragma unroll")
+    A(f"          for (int i = 0; i < {D}; i++) sxn[i] = xnew[i];       // xk_n: becomes xk1_n of the next (older) step")
+    A("        }")
+    A("        rn::async_wait();")
+    A("        rn::wave_lds_sync();      // Pk_k has landed; the lead lanes have read xk_k: the buffer takes the next step's")
+    A("#pragma unroll")
+    A(f"        for (int it = 0; it < {XT}; it++) {{ const int i = lo + 64 * it; if (i < cnt * {D}) s_xk[i] = xnext[it]; }}")
+    # Covariance.  U = D = Pk1_n - Pk1_k with Pk1_k = the LOWER triangle of Pk_k mirrored (the contract of batch_rts); a lane holds D on the block
+    # lower triangle of its rows (in place of the carried rows); what a row needs of D beyond its slot's last row belongs to the lanes of the later
+    # slots, which put it where the row's own entries of that block were (the upper-right block of the image, read into registers first).  The sum
+    # Pk_k + U is then formed row by row in place, with the entries of Pk_k as stored (above the diagonal too).
+    for s in S:
+      lo_, hi_ = RS * s, min(E, RS * s + RS)
+      if lo_:
+        A("#pragma unroll")
+        A(f"        for (int j = 0; j < {lo_}; j++) ps{s}[j] -= sI[rq{s} * {E} + j];")
+      A("#pragma unroll")
+      A(f"        for (int j = {lo_}; j < {hi_}; j++) ps{s}[j] -= sI[{E} * max(rq{s}, j) + min(rq{s}, j)];")
+      A("        __builtin_amdgcn_sched_barrier(0);")
+    for s in S:
+      if ncol(s) < E:
+        A(f"        double pu{s}[{E - ncol(s)}];")
+        A("#pragma unroll")
+        A(f"        for (int j = {ncol(s)}; j < {E}; j++) pu{s}[j - {ncol(s)}] = sI[rq{s} * {E} + j];")
+    if R > 1:
+      A("        rn::wave_lds_sync();      // every lane has read what the exchange overwrites")
+      for s in S:
+        if RS * s:
+          A(f"        {{ double* swc = ok{s} ? sI + rq{s} : strash; const int st = ok{s} ? {E} : 0;      // column rq{s} of the rows above the slot (idle lanes: one trash entry)")
+          A("#pragma unroll")
+          A(f"          for (int j = 0; j < {RS * s}; j++) swc[j * st] = ps{s}[j]; }}")
+      A("        rn::wave_lds_sync();")
+    for s in S:
+      A("        {")
+      A(f"          double o_[{E}];")
+      A("#pragma unroll")
+      A(f"          for (int j = 0; j < {E}; j++) o_[j] = sI[rq{s} * {E} + j];")
+      A("#pragma unroll")
+      A(f"          for (int j = 0; j < {ncol(s)}; j++) o_[j] += ps{s}[j];      // Pk_n = Pk_k + U, U = D (Ck = I)")
+      if ncol(s) < E:
+        A("#pragma unroll")
+        A(f"          for (int j = {ncol(s)}; j < {E}; j++) o_[j] += pu{s}[j - {ncol(s)}];      // (the sum commutes: U arrived in the image, Pk_k waits in pu)")
+      A("#pragma unroll")
+      A(f"          for (int j = 0; j < {E}; j++) sw{s}[j] = o_[j];")
+      A("        }")
+      A("        __builtin_amdgcn_sched_barrier(0);")
+    A("        rn::wave_lds_sync();")
+    A("        {      // Pk_n leaves: one coalesced pass over the tile's records")
+    A("          typedef double rts4_d2 __attribute__((ext_vector_type(2)));")
+    A(f"          rts4_d2* __restrict__ out2 = reinterpret_cast<rts4_d2*>(Ps + (k * n + base) * {EE});")
+    A(f"          const int nv = cnt * {EE // 2};")
+    A("#pragma unroll")
+    A(f"          for (int it = 0; it < {IT}; it++) {{")
+    A("            const int idx = lo + 64 * it;")
+    A(f"            if ((cnt == {FPW} && it < {ITF}) || idx < nv) out2[idx] = *reinterpret_cast<const rts4_d2*>(s_I + 2 * idx);")
+    A("          }")
+    A("        }")
+    A('        asm volatile("" : ' + ", ".join(f'"+v"(rq{s})' for s in S) + ");")
+    lower_rows("ps", ind="        ", full=False)
+    A("        rn::wave_lds_sync();      // every lane has its rows: the image is free for the next step's burst")
+    A("        RN_RTS_STAMP(10);")
+    A("        continue;")
+    A("      }")
   A("      // ---- B. f(xk_k) [renormalised like the forward pass], non-zeros of Fk: once per filter -> slot ----")
   A("      if (lead) scal_predict_s4(sxk, dt, sl, norm_quats & 1);")
   A("      rn::async_wait();")
@@ -322,8 +439,9 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   A("      if (first) {")
   A("        // newest estimate := the predicted pair of the last step (passed in, or recomputed just now): ekf_sym.py:658-659")
   A("        if (live) {       // (two loops, not one select between a global and an LDS source: hipcc 7.2 trips over the generic pointer)")
-  A(f"          if (xl != nullptr) {{ for (int i = c; i < {D}; i += {GL}) sxn[i] = xl[(base + gg) * {D} + i]; }}")
-  A(f"          else {{ for (int i = c; i < {D}; i += {GL}) sxn[i] = sl[{lay.OFF_X} + i]; }}")
+  A(f"          const int cf = lb % {GL};      // (from the step's opaque lane index: addresses formed from c are hoisted to the kernel's entry and held in registers for this one step)")
+  A(f"          if (xl != nullptr) {{ for (int i = cf; i < {D}; i += {GL}) sxn[i] = xl[(base + lb / {GL}) * {D} + i]; }}")
+  A(f"          else {{ for (int i = cf; i < {D}; i += {GL}) sxn[i] = sl[{lay.OFF_X} + i]; }}")
   A("        }")
   A("        if (Pl == nullptr) {      // (a covariance that was passed in went into ps* before the loop)")
   A(f"          double* __restrict__ po = Ps + ((k + 1) * n + base + gg) * {EE};      // the recomputed Pk1_k leaves mirrored from the block lower triangle the lanes hold")
@@ -367,6 +485,7 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   def upd_slots(m):          # slots that hold a row >= m
     return [s for s in S if last_row(s) >= m]
 
+  settle("a")
   A("      double dj_0;")
   A(f"      RN4_BC(dj_0, a{slot_of(0)}[0], {lane_of(0)});")
   A("      double id_0 = rn::fast_recip(dj_0);")
@@ -394,6 +513,7 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
       for s in S:
         if last_row(s) > j + 1:
           A(f"      const double l{s}_{j + 1} = a{s}[{j + 1}] * id_{j + 1};")
+  settle("a")
   A("      RN_RTS_STAMP(6);")
   A("      // ---- F. Ck^T = Pk1_k^-1 M, one row slot at a time (its right-hand side = the lane's row of A, waiting in the image):")
   A("      // forward substitution with the unit factor, scaling by the reciprocal pivots, backward substitution, all in axpy form --")
@@ -415,6 +535,7 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
     A(f"        for (int j = 0; j < {E}; j++) sw{s}[j] = y[j];      // row of Ck (each lane overwrites the row it read; idle lanes: the trash row)")
     A("      }")
   A("      rn::wave_lds_sync();")
+  A("      RN4_SETTLE();      // (the rows of D were pinned where they were formed)")
   A("      RN_RTS_STAMP(7);")
   A("      // ---- H. T = Ck D, one row slot at a time: coefficients = the lane's row of Ck, operands = rows of D from their owners ----")
   A(f"      {rows_decl('t')}")
@@ -503,14 +624,14 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   if any(last_row(s) + 1 < E for s in S):
     A("      {      // upper-right blocks: U[r][j] = U[j][r] for the columns beyond a slot's last row")
     for s in S:
-      ncol = last_row(s) + 1
-      if ncol < E:
+      nc_ = last_row(s) + 1
+      if nc_ < E:
         A("        {")
-        A(f"          double m_[{E - ncol}];")
+        A(f"          double m_[{E - nc_}];")
         A("#pragma unroll")
-        A(f"          for (int j = {ncol}; j < {E}; j++) m_[j - {ncol}] = sI[j * {E} + rq{s}];")
+        A(f"          for (int j = {nc_}; j < {E}; j++) m_[j - {nc_}] = sI[j * {E} + rq{s}];")
         A("#pragma unroll")
-        A(f"          for (int j = {ncol}; j < {E}; j++) sw{s}[j] = m_[j - {ncol}];")
+        A(f"          for (int j = {nc_}; j < {E}; j++) sw{s}[j] = m_[j - {nc_}];")
         A("        }")
     A("      }")
     A("      rn::wave_lds_sync();")

@@ -124,6 +124,47 @@ def test_no_generated_library_touches_scratch_memory(gen_dir):
           assert int(parts[3]) == 0, f"{os.path.basename(fn)}: {parts[0]} uses {parts[3]} B of scratch per lane"
 
 
+@pytest.mark.parametrize("name", ["live", "live_maha", "rand8", "randz10"])
+def test_dpp_sources_respect_wait_states(name):
+  """k_rts4 takes cross-lane operands with inline-assembly `v_fmac_f64_dpp` / `v_mov_b64_dpp ... row_newbcast`.  A VGPR read through
+  DPP needs two wait states after the VALU instruction that wrote it; hipcc's hazard pass does not look inside inline assembly, so
+  whether an FMAC's DPP source was produced just in front of it is a property of each build.  rednose_amd.build.dpp_hazards walks
+  the disassembly of the shipped code object (compile_filter runs the same check and gen_code falls back to `no_rts4` on a hit);
+  the detector itself is checked on a synthetic listing and by asking for more wait states than the hardware needs."""
+  from examples import ensure_generated
+  from rednose_amd import build as rb
+  gen = ensure_generated([name])
+  with open(os.path.join(gen, f"{name}.kernels.txt"), encoding="utf-8") as f:
+    assert "k_rts4" in f.read(), f"{name}: expected the register-broadcast smoother in this library"
+  dis = rb.disassemble(os.path.join(gen, f"lib{name}.so"))
+  if dis is None:
+    pytest.skip("llvm-objdump not available")
+  n_dpp = sum(1 for ln in dis.split("\n") if "row_newbcast:" in ln)
+  assert n_dpp > 100, n_dpp
+  hz = rb.dpp_hazards(dis)
+  assert not hz, f"{name}: {len(hz)} DPP read-after-write hazards in k_rts4, first {hz[0]}"
+  assert rb.dpp_hazards(dis, wait_states=8), "detector found nothing even at 8 wait states: it is not reading this listing"
+
+
+def test_dpp_hazard_detector_on_a_synthetic_listing():
+  from rednose_amd import build as rb
+  head = "0000000000001000 <_ZN12_GLOBAL__N_16k_rts4EPKdS1_>:\n"
+  def ins(text, addr):
+    return f"\t{text}// {addr:012X}: 00000000\n"
+  dpp = "v_fmac_f64_dpp v[4:5], -v[2:3], v[90:91] row_newbcast:1 row_mask:0xf bank_mask:0xf"
+  bad0 = head + ins("v_fma_f64 v[2:3], v[6:7], v[8:9], v[2:3]", 0x1000) + ins(dpp, 0x1008)
+  bad1 = head + ins("v_mul_f64 v[2:3], v[6:7], v[8:9]", 0x1000) + ins("s_nop 0", 0x1008) + ins(dpp, 0x100c)
+  ok_nop = head + ins("v_mul_f64 v[2:3], v[6:7], v[8:9]", 0x1000) + ins("s_nop 1", 0x1008) + ins(dpp, 0x100c)
+  ok_two = head + ins("v_mul_f64 v[2:3], v[6:7], v[8:9]", 0x1000) + ins("v_add_f64 v[10:11], v[6:7], v[8:9]", 0x1008) + ins("ds_read_b64 v[20:21], v30", 0x1010) + ins(dpp, 0x1018)
+  ok_other = head + ins("v_mul_f64 v[90:91], v[6:7], v[8:9]", 0x1000) + ins(dpp, 0x1008)      # src1 / accumulator are ordinary reads
+  ok_load = head + ins("ds_read_b64 v[2:3], v30", 0x1000) + ins(dpp, 0x1008)                   # not a VALU write: s_waitcnt orders it
+  half = head + ins("v_mov_b32_e32 v3, v7", 0x1000) + ins(dpp, 0x1004)                          # one half of the pair is enough
+  assert len(rb.dpp_hazards(bad0)) == 1 and len(rb.dpp_hazards(bad1)) == 1 and len(rb.dpp_hazards(half)) == 1
+  assert not rb.dpp_hazards(ok_nop) and not rb.dpp_hazards(ok_two) and not rb.dpp_hazards(ok_other) and not rb.dpp_hazards(ok_load)
+  other_kernel = bad0.replace("k_rts4", "k_step")
+  assert not rb.dpp_hazards(other_kernel)
+
+
 def test_loader_backends(gen_dir):
   """load_code binds the same prototypes through either backend: cffi when importable (what the reference uses), ctypes
   otherwise or on request.  BatchedEKF always asks for ctypes (it passes ctypes pointers); a forced "cffi" without cffi

@@ -985,6 +985,7 @@ inline double host_row_bcast(double v, int L) {
 #define RN4_FMAC(acc, src, coef, L)  (acc) = std::fma(host_row_bcast((src), (L)), (coef), (acc))
 #define RN4_FNMAC(acc, src, coef, L) (acc) = std::fma(-host_row_bcast((src), (L)), (coef), (acc))
 #define RN4_BC(dst, src, L)          (dst) = host_row_bcast((src), (L))
+#define RN4_SETTLE()                 do { } while (0)
 #define RN_RTS_STAMP(i) do { } while (0)
 #define __builtin_amdgcn_s_setprio(x)
 using std::max; using std::min; using std::fma;

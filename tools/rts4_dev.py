@@ -64,7 +64,11 @@ def unit_text(spec):
   if (hipDeviceSynchronize() != hipSuccess) return 1;
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rn::g_rts_tl), sizeof(unsigned long long) * 256 * 16, 0, hipMemcpyDeviceToHost);
 }""")
-  return "\n".join(src)
+  text = "\n".join(src)
+  if "rn::sincos_fast(" in text:      # models with trigonometric terms: the helper emit() splices in (codegen/emit.py)
+    from rednose_amd.codegen.lower import SINCOS_FAST
+    text = text.replace('#include "ekf_hip_rts.h"\n', '#include "ekf_hip_rts.h"\n' + SINCOS_FAST, 1)
+  return text
 
 
 def main():
