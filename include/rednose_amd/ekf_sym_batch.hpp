@@ -17,7 +17,9 @@
 //     to their own times through the library's `_masked` entry points, a late observation rewinds, applies and fast-forwards only
 //     the filters it is late for, one that is too old is ignored for that filter alone;
 //   * no Eigen: state lives in HBM as x (N, D), P (N, E, E) row-major fp64; z is a DEVICE pointer (N, Z) that the
-//     kernel overwrites with the residual y; R is a host Z x Z matrix shared by the batch.
+//     kernel overwrites with the residual y; R is a host Z x Z matrix shared by the batch; a call carries one observation per
+//     filter or, like the reference's (:83-85,172-180), n of them: vectors of z / R / extra_args pointers, one predict, n updates,
+//     one checkpoint.
 // Errors throw std::runtime_error carrying {name}_last_error_string(); nothing aborts.
 #pragma once
 
@@ -144,7 +146,35 @@ class EKFSymBatch {
   // Python class implements it, ekf_sym.py:365-391,527-528).
   bool predict_and_update_batch(double t, int kind, double* z_dev, const double* R_host, uint8_t* flags_dev = nullptr,
                                 const double* ea_dev = nullptr, bool augment = false) {
+    return predict_and_update_batch(t, kind, std::vector<double*>{z_dev}, std::vector<const double*>{R_host}, flags_dev,
+                                    ea_dev ? std::vector<const double*>{ea_dev} : std::vector<const double*>{}, augment);
+  }
+
+  // n observations of one kind in ONE call, in the shape the reference takes them (ekf_sym.cc:83-85: a vector of z, a vector of R, a
+  // vector of extra_args): ONE predict to t, the n observations applied in order (ekf_sym.cc:172-180), ONE checkpoint (:191) --
+  // a late call rewinds over calls, not over observations.  z_devs[i]: (N, Z) device, in: z_i, out: y_i (Estimate.y, :183);
+  // R_hosts[i]: Z x Z row-major host, shared by the batch; ea_devs: empty, or one (N, kind_eadim) device pointer per observation;
+  // flags_dev: n x N bytes (observation i's flags at flags_dev + i * N) or nullptr.  Launches: one fused predict + update, then
+  // n - 1 batch_update_k -- the step-granular kernels, the reference's arithmetic on any P (BatchedEKF serves the same call with one
+  // batch_run launch where the library allows it).
+  // The reference's Estimate (ekf_sym.h:32-42) for the whole batch, as host copies: xk1 / Pk1 the predicted pair (after predict(t), before
+  // the first update), xk / Pk the filtered pair right after THIS call's observations (before any fast-forward, ekf_sym.cc:106-116); the
+  // residuals y stay where the observations were (z_devs).  Filled when a pointer to one is passed to predict_and_update_batch: the call
+  // then predicts and updates in separate launches (the predicted pair has to exist in memory) and copies 2 N (D + E^2) doubles to the host.
+  struct Estimate {
+    std::vector<double> xk1, xk, Pk1, Pk;
+    double t = NAN;
+    int kind = 0;
+  };
+
+  bool predict_and_update_batch(double t, int kind, const std::vector<double*>& z_devs, const std::vector<const double*>& R_hosts,
+                                uint8_t* flags_dev = nullptr, const std::vector<const double*>& ea_devs = {}, bool augment = false,
+                                Estimate* estimate = nullptr) {
     const int Z = zdim_.at(kind);
+    if (z_devs.empty() || z_devs.size() != R_hosts.size() || (!ea_devs.empty() && ea_devs.size() != z_devs.size()))
+      throw std::runtime_error("rednose_amd: predict_and_update_batch needs n >= 1 observations with one R (and, if any, one extra_args) each");   // ekf_sym.cc:159-160
+    if (z_devs.size() * (size_t)Z * Z > 64 * 64)
+      throw std::runtime_error("rednose_amd: too many observations in one call for the noise staging buffer");
     std::vector<Checkpoint> replay;
     if (!std::isnan(filter_time_) && t < filter_time_) {
       // late observation (ekf_sym.cc:87-94): too old for the ring or for max_rewind_age -> ignored
@@ -152,10 +182,25 @@ class EKFSymBatch {
       if (augment) throw std::runtime_error("rednose_amd: augment with a rewind is not supported (the reference asserts the same)");
       replay = rewind(t);
     }
-    step(t, kind, Z, z_dev, R_host, flags_dev, ea_dev);
+    step(t, kind, Z, z_devs, R_hosts, flags_dev, ea_devs, estimate);
+    if (estimate) {
+      estimate->t = t;
+      estimate->kind = kind;
+      synchronize();
+      estimate->xk = state();
+      estimate->Pk = covs();
+    }
     if (augment) this->augment();
-    for (auto& c : replay) {             // fast-forward through the observations that were overtaken (ekf_sym.cc:111-116)
-      step(c.obs_t, c.kind, zdim_.at(c.kind), c.z, c.R.data(), nullptr, c.has_ea ? c.ea : nullptr);
+    for (auto& c : replay) {             // fast-forward through the calls that were overtaken (ekf_sym.cc:111-116), each with all its observations
+      const int Zc = zdim_.at(c.kind);
+      std::vector<double*> zs;
+      std::vector<const double*> Rs, eas;
+      for (int i = 0; i < c.nobs; i++) {
+        zs.push_back(c.z + (size_t)i * obs_stride(Zc));
+        Rs.push_back(c.R.data() + (size_t)i * Zc * Zc);
+        if (c.has_ea) eas.push_back(c.ea + (size_t)i * obs_stride(c.ead));
+      }
+      step(c.obs_t, c.kind, Zc, zs, Rs, nullptr, eas);
       spare_.push_back(c);
     }
     return true;
@@ -292,11 +337,16 @@ class EKFSymBatch {
     double *x = nullptr, *P = nullptr; // device copies of the batch state
     double obs_t = NAN;
     int kind = 0;
-    double* z = nullptr;               // device copy of the observation (the kernel overwrites the caller's with the residual)
-    double* ea = nullptr;              // device buffer for a copy of the extra arguments
-    bool has_ea = false;               // ... which this observation had
-    std::vector<double> R;             // Z x Z, host
+    int nobs = 1;                      // observations of the call this checkpoint closes (ekf_sym.cc:191: one checkpoint per call)
+    double* z = nullptr;               // device copies of the observations, obs_stride(Z) doubles apart (the kernels overwrite the caller's with the residuals)
+    double* ea = nullptr;              // device copies of the extra arguments, obs_stride(ead) apart
+    size_t zcap = 0, eacap = 0;        // doubles allocated behind z / ea
+    bool has_ea = false;               // ... which these observations had
+    int ead = 0;
+    std::vector<double> R;             // nobs x Z x Z, host
   };
+  // distance between two observations' (N, w) blocks of a checkpoint: even, so that every block starts 16-byte aligned
+  size_t obs_stride(int w) const { return ((size_t)n_ * w + 1) & ~(size_t)1; }
 
   void release(Checkpoint& c) {
     (void)hipFree(c.x); (void)hipFree(c.P); (void)hipFree(c.z); (void)hipFree(c.ea);
@@ -308,27 +358,56 @@ class EKFSymBatch {
     Checkpoint c;
     hip(hipMalloc((void**)&c.x, sizeof(double) * n_ * D_), "hipMalloc ring x");
     hip(hipMalloc((void**)&c.P, sizeof(double) * n_ * E_ * E_), "hipMalloc ring P");
-    hip(hipMalloc((void**)&c.z, sizeof(double) * n_ * 64), "hipMalloc ring z");
-    hip(hipMalloc((void**)&c.ea, sizeof(double) * n_ * 4), "hipMalloc ring ea");
     return c;
   }
+  static void reserve(double** p, size_t* cap, size_t doubles) {
+    if (*cap >= doubles) return;
+    (void)hipFree(*p);
+    *p = nullptr;
+    hip(hipMalloc((void**)p, sizeof(double) * doubles), "hipMalloc ring observations");
+    *cap = doubles;
+  }
 
-  // predict + update + checkpoint (EKFSym::predict_and_update_batch's inner part, ekf_sym.cc:158-194)
-  void step(double t, int kind, int Z, double* z_dev, const double* R_host, uint8_t* flags_dev, const double* ea_dev) {
+  // predict + n updates + ONE checkpoint (EKFSym::predict_and_update_batch's inner part, ekf_sym.cc:158-194)
+  void step(double t, int kind, int Z, const std::vector<double*>& z_devs, const std::vector<const double*>& R_hosts, uint8_t* flags_dev,
+            const std::vector<const double*>& ea_devs, Estimate* estimate = nullptr) {
     Checkpoint c;
     const bool keep = rewind_to_keep_ > 0;
+    const int nobs = (int)z_devs.size();
+    const int ead = sym<int (*)(int)>("kind_eadim")(kind);
     if (keep) {
       c = slot();
-      c.obs_t = t; c.kind = kind; c.R.assign(R_host, R_host + Z * Z);
-      hip(hipMemcpyAsync(c.z, z_dev, sizeof(double) * n_ * Z, hipMemcpyDeviceToDevice, stream_), "ring z");
-      const int ead = sym<int (*)(int)>("kind_eadim")(kind);
-      c.has_ea = ea_dev != nullptr && ead > 0;
-      if (c.has_ea) hip(hipMemcpyAsync(c.ea, ea_dev, sizeof(double) * n_ * ead, hipMemcpyDeviceToDevice, stream_), "ring ea");
+      c.obs_t = t; c.kind = kind; c.nobs = nobs; c.ead = ead;
+      c.R.clear();
+      reserve(&c.z, &c.zcap, obs_stride(Z) * nobs);
+      c.has_ea = !ea_devs.empty() && ead > 0;
+      if (c.has_ea) reserve(&c.ea, &c.eacap, obs_stride(ead) * nobs);
+      for (int i = 0; i < nobs; i++) {
+        c.R.insert(c.R.end(), R_hosts[i], R_hosts[i] + Z * Z);
+        hip(hipMemcpyAsync(c.z + (size_t)i * obs_stride(Z), z_devs[i], sizeof(double) * n_ * Z, hipMemcpyDeviceToDevice, stream_), "ring z");
+        if (c.has_ea) hip(hipMemcpyAsync(c.ea + (size_t)i * obs_stride(ead), ea_devs[i], sizeof(double) * n_ * ead, hipMemcpyDeviceToDevice, stream_), "ring ea");
+      }
     }
     const double dt = advance(t);
-    hip(hipMemcpyAsync(R_, R_host, sizeof(double) * Z * Z, hipMemcpyHostToDevice, stream_), "copy R");
-    auto fn = sym<step_fn>("batch_predict_update_" + std::to_string(kind));
-    check(fn(x_, P_, Q_, nullptr, dt, z_dev, R_, 0, ea_dev, n_, norm_quats_, flags_dev, stream_), "batch_predict_update");
+    for (int i = 0; i < nobs; i++)
+      hip(hipMemcpyAsync(R_ + (size_t)i * Z * Z, R_hosts[i], sizeof(double) * Z * Z, hipMemcpyHostToDevice, stream_), "copy R");
+    int first_update = 1;
+    if (estimate) {            // the predicted pair has to exist in memory: predict alone, then every observation as an update
+      check(batch_predict_(x_, P_, Q_, nullptr, dt, n_, norm_quats_, stream_), "batch_predict");
+      synchronize();
+      estimate->xk1 = state();
+      estimate->Pk1 = covs();
+      first_update = 0;
+    } else {
+      auto fused = sym<step_fn>("batch_predict_update_" + std::to_string(kind));
+      check(fused(x_, P_, Q_, nullptr, dt, z_devs[0], R_, 0, ea_devs.empty() ? nullptr : ea_devs[0], n_, norm_quats_, flags_dev, stream_), "batch_predict_update");
+    }
+    if (nobs > first_update) {
+      auto upd = sym<update_fn>("batch_update_" + std::to_string(kind));
+      for (int i = first_update; i < nobs; i++)
+        check(upd(x_, P_, z_devs[i], R_ + (size_t)i * Z * Z, 0, ea_devs.empty() ? nullptr : ea_devs[i], n_, norm_quats_,
+                  flags_dev ? flags_dev + (size_t)i * n_ : nullptr, stream_), "batch_update");
+    }
     filter_time_ = t;
     if (keep) {
       hip(hipMemcpyAsync(c.x, x_, sizeof(double) * n_ * D_, hipMemcpyDeviceToDevice, stream_), "ring x");
@@ -496,6 +575,7 @@ class EKFSymBatch {
   using predict_fn = int (*)(double*, double*, const double*, const double*, double, int64_t, int, void*);
   using step_fn = int (*)(double*, double*, const double*, const double*, double, double*, const double*, int, const double*,
                           int64_t, int, uint8_t*, void*);
+  using update_fn = int (*)(double*, double*, double*, const double*, int, const double*, int64_t, int, uint8_t*, void*);
 
   template <class F>
   F sym(const std::string& suffix) const {

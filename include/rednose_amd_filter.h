@@ -119,6 +119,9 @@ extern "C" {
   int RN_FN(name, run_unroll)(void);                  /* steps per iteration of batch_run's loop (instruction accounting) */ \
   int RN_FN(name, has_batch_run)(void);               /* 0: the fused kernel of this model did not fit the register file -- batch_run \
                                                          returns 4 (unsupported); walk the schedule with batch_predict_update_k */ \
+  int RN_FN(name, predict_identity_at_dt0)(void);     /* 1: predict(dt = 0) is the identity on (x, P) for this model (f(x, 0) == x, F(x, 0) == I \
+                                                         symbolically): a batch_run step with dt = 0 is an update alone -- the n observations of one  \
+                                                         EKFSym::predict_and_update_batch call (ekf_sym.cc:172-180) can be one launch */ \
   /* T predict+update steps in ONE launch, x and P resident on chip between steps.  kinds (T) int32, dts (T),   \
    * R (T, zmax*zmax; the leading Z*Z entries of row t are that step's row-major R) and z (T, n, zmax; in: z,   \
    * out: y) are DEVICE arrays; the schedule is shared by all filters.  flags (T, n), trace_x (T, n, D) and      \

@@ -97,27 +97,32 @@ static void fullpiv_solve(double *S, double *B, double *X, int n, int m) {
  * Basis of the right null space of M (rows x cols, row-major) by Gaussian elimination with FULL pivoting -- what
  * Eigen's FullPivLU::kernel() computes for ekf_c.c:71 (A = Hea^T.fullPivLu().kernel()): with P M Q = L U and
  * U = [U1 U2] (U1 rank x rank upper triangular), the kernel vectors are Q [-U1^-1 U2 ; I].  ker is cols x (cols - rank),
- * row-major; returns the kernel dimension.  Rank threshold: |pivot| <= eps * max(rows, cols) * |largest pivot|
- * (Eigen's default).  Any basis gives the same x and P; only the projected residual y depends on the choice.
+ * row-major; returns the kernel dimension.  As in Eigen's FullPivLU: the pivot search walks the remaining corner column by column and
+ * keeps the FIRST maximum (its maxCoeff visitor; decides which of several equal entries becomes the pivot), the elimination runs through
+ * all min(rows, cols) steps unless the corner is exactly zero, and the rank is decided afterwards -- a pivot counts when
+ * |pivot| > eps * min(rows, cols) * |largest pivot met| (threshold() = epsilon * diagonalSize, m_maxpivot the running maximum).  Pivots are
+ * counted from the front (with full pivoting a small pivot is followed by smaller ones; Eigen's kernel() would also skip a small pivot in
+ * the middle).  Any basis gives the same x and P; only the projected residual y depends on the choice.
  */
 static int fullpiv_kernel(const double *M, int rows, int cols, double *ker) {
   double U[OR_MAXZ * OR_MAXZ];
   int colperm[OR_MAXZ];
   memcpy(U, M, sizeof(double) * (size_t)rows * cols);
   for (int j = 0; j < cols; j++) colperm[j] = j;
-  int rank = 0;
-  double maxpiv = 0.0;
+  int rank = 0, done = 0;
+  double maxpiv = 0.0, piv[OR_MAXZ];
   const int steps = rows < cols ? rows : cols;
   for (int k = 0; k < steps; k++) {
     int pr = k, pc = k;
     double best = 0.0;
-    for (int i = k; i < rows; i++)
-      for (int j = k; j < cols; j++) {
+    for (int j = k; j < cols; j++)
+      for (int i = k; i < rows; i++) {
         double a = fabs(U[i * cols + j]);
         if (a > best) { best = a; pr = i; pc = j; }
       }
-    if (k == 0) maxpiv = best;
-    if (best <= 2.220446049250313e-16 * (rows > cols ? rows : cols) * maxpiv) break;
+    if (best == 0.0) break;
+    piv[done++] = best;
+    if (best > maxpiv) maxpiv = best;
     if (pr != k) for (int j = 0; j < cols; j++) { double t = U[k * cols + j]; U[k * cols + j] = U[pr * cols + j]; U[pr * cols + j] = t; }
     if (pc != k) {
       for (int i = 0; i < rows; i++) { double t = U[i * cols + k]; U[i * cols + k] = U[i * cols + pc]; U[i * cols + pc] = t; }
@@ -127,8 +132,8 @@ static int fullpiv_kernel(const double *M, int rows, int cols, double *ker) {
       double l = U[i * cols + k] / U[k * cols + k];
       for (int j = k; j < cols; j++) U[i * cols + j] -= l * U[k * cols + j];
     }
-    rank++;
   }
+  while (rank < done && piv[rank] > 2.220446049250313e-16 * steps * maxpiv) rank++;
   const int nk = cols - rank;
   for (int c = 0; c < nk; c++) {
     double v[OR_MAXZ];

@@ -480,6 +480,102 @@ def perfilter_timelines():
   print("per-filter timelines: part A", NA, "x", T, "ignored", int(noneA.sum()), "; part B", NB, "x", TB, "observations", int((kB > 0).sum()))
 
 
+def multi_obs_goldens():
+  """n observations per call (the reference's predict_and_update_batch proper, ekf_sym.py:484-531 = ekf_sym.cc:158-194): ONE predict, n
+  sequential updates, ONE checkpoint, y a list of n.
+  Part A, `kinematic9`, per-filter logs: 8 instances of the reference class, each fed its own log of 36 calls -- own times, kinds
+  1 / 2 / 3 at random, n in {1, 2, 3} observations per call (position fixes: mostly 3) with a DIFFERENT noise matrix per observation,
+  ONE LATE multi-observation call per filter (rewind over 2-4 multi-observation checkpoints, then fast-forward through them).
+  Part B, `feature` (MSCKF), shared timeline: 4 instances with the same call times / kinds and their own observations: every third call
+  3 position fixes + window shift, the others 4 feature tracks (n = 4 landmarks as extra_args)."""
+  import importlib.util
+  rng = np.random.default_rng(77)
+  spec = importlib.util.spec_from_file_location("rn_amd_kinematic9_kf_m", os.path.join(REPO, "examples", "kinematic9_kf.py"))
+  mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+  K9, ANCHOR = mod.Kinematic9Kalman, mod.ANCHOR
+  NB, TB, NM = 8, 36, 3
+  tA = np.zeros((NB, TB)); kA = np.zeros((NB, TB), dtype=np.int32); nA = np.zeros((NB, TB), dtype=np.int32)
+  zA = np.zeros((NB, TB, NM, 3)); sA = np.ones((NB, TB, NM)); yA = np.zeros((NB, TB, NM, 3))
+  xA = np.empty((NB, TB, 9)); PA = np.empty((NB, TB, 9, 9)); x1A = np.empty((NB, TB, 9)); P1A = np.empty((NB, TB, 9, 9))
+  xkA = np.empty((NB, TB, 9)); PkA = np.empty((NB, TB, 9, 9)); lateA = np.zeros(NB, dtype=np.int32)
+  for i in range(NB):
+    f = ref_filter("kinematic9", K9.Q, K9.initial_x, np.diag(K9.initial_P_diag), 9, 9)
+    tr = np.array([0.5, 0.5, 0.5, 1.0, -0.5, 0.2, 0.3, 0.1, -0.2]) + rng.normal(size=9) * 0.05
+    times = np.cumsum(rng.uniform(0.01, 0.05, size=TB)) + rng.uniform(0, 0.3)
+    late_at = int(rng.integers(6, TB - 2))
+    back = int(rng.integers(2, 5))
+    times[late_at] = 0.5 * (times[late_at - back] + times[late_at - back + 1])
+    lateA[i] = late_at
+    for j in range(TB):
+      t = float(times[j])
+      k = int(rng.integers(1, 4))
+      n = 3 if (k == 1 and rng.random() < 0.7) else int(rng.integers(1, 4))
+      if j == late_at:
+        n = max(n, 2)                      # the late call carries several observations
+      p = tr[0:3] + t * tr[3:6] + 0.5 * t * t * tr[6:9]; v = tr[3:6] + t * tr[6:9]
+      Z = K9.obs_noise[k].shape[0]
+      zs, Rs = [], []
+      for m in range(n):
+        sc = float(rng.uniform(0.5, 2.0))
+        if k == 1:
+          z = p + rng.normal(size=3) * 0.1 * np.sqrt(sc)
+        elif k == 2:
+          z = np.array([np.linalg.norm(p - np.array(ANCHOR))]) + rng.normal(size=1) * 0.2 * np.sqrt(sc)
+        else:
+          z = v + rng.normal(size=3) * 0.3 * np.sqrt(sc)
+        zs.append(z); Rs.append(K9.obs_noise[k] * sc)
+        zA[i, j, m, :Z] = z; sA[i, j, m] = sc
+      ret = f.predict_and_update_batch(t, k, np.array(zs), np.array(Rs), [[]] * n)      # (the default [[]] serves ONE observation: ekf_sym.py:518 indexes extra_args[i])
+      assert ret is not None and len(ret[6]) == n
+      tA[i, j], kA[i, j], nA[i, j] = t, k, n
+      for m in range(n):
+        yA[i, j, m, :Z] = np.ravel(ret[6][m])
+      x1A[i, j], xkA[i, j], P1A[i, j], PkA[i, j] = ret[0], ret[1], ret[2], ret[3]
+      xA[i, j], PA[i, j] = f.state(), f.covs()
+  # ---- part B: MSCKF feature tracks, shared timeline
+  spec = importlib.util.spec_from_file_location("rn_amd_feature_kf_m", os.path.join(REPO, "examples", "feature_kf.py"))
+  fmod = importlib.util.module_from_spec(spec); spec.loader.exec_module(fmod)
+  FK = fmod.FeatureKalman
+  NF, TF, NT = 4, 24, 4
+  ZF = 2 * len(FK.observed)
+  D = FK.dim_state
+  landmarks = np.array([[2.0, 1.0, 8.0], [-1.5, 0.5, 6.0], [0.5, -1.0, 10.0], [3.0, 2.0, 12.0]])
+  tB = 0.05 * (1 + np.arange(TF)); kB = np.where(np.arange(TF) % 3 == 0, 1, 2).astype(np.int32); nB = np.where(kB == 1, 3, NT).astype(np.int32)
+  zB = np.zeros((NF, TF, NT, ZF)); eaB = np.zeros((NF, TF, NT, 3)); yB = np.zeros((NF, TF, NT, ZF))
+  xB = np.empty((NF, TF, D)); PB = np.empty((NF, TF, D, D)); x1B = np.empty((NF, TF, D)); P1B = np.empty((NF, TF, D, D))
+  for i in range(NF):
+    f = ref_filter(FK.name, FK.Q, FK.initial_x, np.diag(FK.initial_P_diag), fmod.DIM_MAIN, fmod.DIM_MAIN, **FK.filter_kwargs())
+    truth_p, truth_v = np.zeros(3), np.array([1.0, 0.5, 0.0]) + rng.normal(size=3) * 0.05
+    window = [np.zeros(3)] * FK.n_window
+    for j in range(TF):
+      truth_p = truth_p + 0.05 * truth_v
+      if kB[j] == 1:
+        zs = [truth_p + rng.normal(size=3) * 0.2 for _ in range(3)]
+        for m in range(3):
+          zB[i, j, m, :3] = zs[m]
+        ret = f.predict_and_update_batch(float(tB[j]), 1, np.array(zs), np.array([FK.obs_noise[1]] * 3), [[]] * 3, augment=True)
+        window = window[1:] + [truth_p.copy()]
+      else:
+        zs, eas = [], []
+        for m in range(NT):
+          ea = landmarks[m] + rng.normal(size=3) * 0.05
+          rays = [landmarks[m] - window[w] for w in FK.observed]
+          zs.append(np.concatenate([[r[0] / r[2], r[1] / r[2]] for r in rays]) + rng.normal(size=ZF) * 0.01)
+          eas.append(list(ea))
+          zB[i, j, m], eaB[i, j, m] = zs[m], ea
+        ret = f.predict_and_update_batch(float(tB[j]), 2, np.array(zs), np.array([np.eye(ZF) * 0.01**2] * NT), eas)
+      for m in range(int(nB[j])):
+        y = np.ravel(ret[6][m])
+        yB[i, j, m, :len(y)] = y
+      x1B[i, j], P1B[i, j] = ret[0], ret[2]
+      xB[i, j], PB[i, j] = f.state(), f.covs()
+  np.savez_compressed(os.path.join(GOLD, "multi_obs.npz"), A_t=tA, A_kind=kA, A_n=nA, A_z=zA, A_Rscale=sA, A_y=yA, A_x=xA, A_P=PA,
+                      A_xk_km1=x1A[:, ::6], A_Pk_km1=P1A[:, ::6], A_xk_k=xkA[:, ::6], A_Pk_k=PkA[:, ::6], A_late=lateA,
+                      B_t=tB, B_kind=kB, B_n=nB, B_z=zB, B_ea=eaB, B_y=yB, B_x=xB, B_P=PB, B_xk_km1=x1B[:, ::4], B_Pk_km1=P1B[:, ::4])
+  print("multi-observation calls: part A", NB, "x", TB, "calls,", int(nA.sum()), "observations, late calls at", lateA.tolist(),
+        "; part B", NF, "x", TF, "calls,", int(nB.sum()) * NF, "observations")
+
+
 if __name__ == "__main__":
   os.makedirs(GOLD, exist_ok=True)
   if len(sys.argv) > 1:          # python oracle/make_golden.py <function> ...: regenerate only those fixtures
@@ -498,5 +594,6 @@ if __name__ == "__main__":
   feature_goldens()
   feature_goldens(T=15, cls_name="WideFeatureKalman", out_name="feature36_stream.npz", n_upd=6)
   perfilter_timelines()
+  multi_obs_goldens()
   for fn in sorted(os.listdir(GOLD)):
     print(fn, os.path.getsize(os.path.join(GOLD, fn)))

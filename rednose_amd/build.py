@@ -49,6 +49,30 @@ def source_digest(*texts):
   return h.hexdigest()
 
 
+def build_python_binding(verbose=False):
+  """Compile rednose_amd/csrc/ekf_sym_batch_py.cpp -- the pybind11 binding of rednose_amd::EKFSymBatch, the analogue of the reference's Cython
+  module ekf_sym_pyx (rednose/helpers/ekf_sym_pyx.pyx, built there by SCons: rednose/SConscript) -- in-tree, next to the Python face that
+  imports it (rednose_amd/helpers/ekf_sym_pyx.py).  Host code only (the kernels live in the generated filter libraries the class dlopens);
+  hipcc because the header includes the HIP runtime API.  Skipped when the module is newer than its sources.  Returns the module's path."""
+  import sysconfig
+  import pybind11
+  here = os.path.dirname(os.path.abspath(__file__))
+  repo = os.path.dirname(here)
+  src = os.path.join(here, "csrc", "ekf_sym_batch_py.cpp")
+  hdr = os.path.join(repo, "include", "rednose_amd", "ekf_sym_batch.hpp")
+  out = os.path.join(here, "helpers", "_ekf_sym_batch" + sysconfig.get_config_var("EXT_SUFFIX"))
+  if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    return out
+  cmd = [find_hipcc(), "-O2", "-std=c++17", "-shared", "-fPIC", "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"],
+         "-I", os.path.join(repo, "include"), src, "-o", out, "-ldl"]
+  if verbose:
+    print(" ".join(cmd))
+  res = subprocess.run(cmd, capture_output=True, text=True)
+  if res.returncode != 0:
+    raise RuntimeError(f"hipcc failed for {src}:\n{res.stderr[-4000:]}")
+  return out
+
+
 def compile_filter(folder, name, extra_flags=(), verbose=False):
   src = os.path.join(folder, f"{name}.hip")
   lib = os.path.join(folder, f"lib{name}.so")

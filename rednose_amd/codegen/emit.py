@@ -28,13 +28,13 @@ SMALL_MAX_E = 7    # lane-per-filter register budget: x, P and the update's temp
 #   no_model_defaults  the per-model tuning defaults (two wavefronts per SIMD) spilled -> general structure
 #   rts_one_wave       the smoother spilled under the two-wavefronts-per-SIMD budget -> full register file
 #   no_rts             the smoother still touches scratch -> library without batch_rts (forward filter unaffected)
-#   no_rts4            the smoother with register-broadcast operands (emit_rts4, two wavefronts per SIMD) spilled -> emit_rts3
-#   no_rts3            the smoother in the fused run's layout (emit_rts3) spilled -> rn::k_rts_group
+#   no_rts4            the smoother with register-broadcast operands (emit_rts4, two wavefronts per SIMD) spilled, or one of its DPP reads follows
+#                      the write of its source too closely (build.dpp_hazards) -> rn::k_rts_group
 #   no_run_blk         the blocked fused run of a lane-per-filter model (emit_small.run_kernel_blk) spilled -> k_run serves untraced runs too
 #   no_run2            the fused run with a scalar wavefront beside the matrix wavefront (emit_run2, two wavefronts per SIMD) spilled -> k_run (emit_wide3)
 #   no_run             the fused multi-step run of a model above 32 error states touches scratch -> library without batch_run
 #                      (status ERR_UNSUPPORTED, the step-granular entry points cover such models)
-FALLBACKS = ("force_wide", "no_model_defaults", "no_rts4", "no_rts3", "rts_one_wave", "no_rts", "no_run2", "no_run", "no_run_blk")
+FALLBACKS = ("force_wide", "no_model_defaults", "no_rts4", "rts_one_wave", "no_rts", "no_run2", "no_run", "no_run_blk")
 _active = frozenset()      # fallbacks of the emit() call in progress
 
 
@@ -179,16 +179,14 @@ def _emit(spec):
 
   # ---- kernels ---------------------------------------------------------------------------------
   src.append(fam_mod.kernels(spec))
-  # smoother.  Lane-per-filter models: rn::k_rts (state and covariance of a filter in one lane's registers).  Lane-group
-  # models, MSCKF ones included (their main block is smoothed, ekf_sym.py:675-686): rn::k_rts_group.
+  # smoother.  Lane-per-filter models: rn::k_rts (state and covariance of a filter in one lane's registers).  Lane-group models: k_rts4
+  # (emit_rts4: 8 .. 22 error states) or rn::k_rts_group (MSCKF models -- their main block is smoothed, ekf_sym.py:675-686 --, larger models,
+  # and the fallback of k_rts4).
   group_rts = fam == "wide"
-  from rednose_amd.codegen import emit_rts3, emit_rts4
-  use_rts4 = (group_rts and emit_rts4.applicable(spec) and tuning.current().rts4 and "no_rts4" not in _active and "no_rts3" not in _active and "no_rts" not in _active)
-  use_rts3 = (not use_rts4 and group_rts and E <= 32 and emit_rts3.applicable(spec) and tuning.current().rts3 and "no_rts3" not in _active and "no_rts" not in _active)
+  from rednose_amd.codegen import emit_rts4
+  use_rts4 = (group_rts and emit_rts4.applicable(spec) and tuning.current().rts4 and "no_rts4" not in _active and "no_rts" not in _active)
   if use_rts4:
     src.append(emit_rts4.kernel(spec))
-  if use_rts3:
-    src.append(emit_rts3.kernel(spec))
   has_rts = (group_rts or (fam == "small" and spec.dim_main == spec.dim_x and spec.dim_main_err == spec.dim_err)) and "no_rts" not in _active
   if has_rts:
     quat = "".join(f" rn::normalize_quat<{D}>(x, {q});" for q in spec.quaternion_idxs)
@@ -208,6 +206,7 @@ def _emit(spec):
 struct RtsModel {{
   static constexpr int D = {D};
   static constexpr int E = {E};
+  static constexpr bool ID0 = {'true' if emit_rts4.dt0_path(spec) else 'false'};      // predict(dt = 0) is the identity: such steps take Ck = I (ekf_hip_rts.h)
   static __device__ __forceinline__ void f(const double* x, double dt, double* out) {{ f_fun(x, dt, out); }}
   static __device__ __forceinline__ void F(const double* x, double dt, double* out) {{ F_fun(x, dt, out); }}
   static __device__ __forceinline__ void err(const double* nom, const double* delta, double* out) {{ err_fun(nom, delta, out); }}
@@ -376,6 +375,11 @@ int {name}_batch_predict_update_{k.kind}{sfx}(double *x, double *P, const double
   # and callers walk a schedule with the step-granular entry points (BatchedEKF.run does)
   abi.append(f"int {name}_has_batch_run(void) {{ return {int(has_run)}; }}")
   hdr.append(f"int {name}_has_batch_run(void);")
+  # 1: predict(dt = 0) is the identity on (x, P) for this model, symbolically (FilterSpec.identity_at_dt0) -- a batch_run step with dt = 0 is
+  # then an update alone, which is how the orchestrators serve the n observations of ONE predict_and_update_batch call (the reference predicts
+  # once and updates n times, ekf_sym.cc:172-180) in one launch; 0: they issue batch_update_k launches instead
+  abi.append(f"int {name}_predict_identity_at_dt0(void) {{ return {int(spec.identity_at_dt0())}; }}")
+  hdr.append(f"int {name}_predict_identity_at_dt0(void);")
   abi.append(f"""int {name}_batch_run(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts, int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, double *trace_x, double *trace_P, const double *ea, const int32_t *augment, void *stream) {{
   RN_REQUIRE(n >= 0 && T >= 0 && x && P && Q && kinds && dts && z && R, rn::ERR_ARG);
   if (n == 0 || T == 0) return rn::OK;
@@ -389,8 +393,6 @@ int {name}_batch_predict_update_{k.kind}{sfx}(double *x, double *P, const double
   if has_rts:
     if use_rts4:
       launch = emit_rts4.launch(spec)
-    elif use_rts3:
-      launch = emit_rts3.launch(spec)
     elif group_rts:
       GLr = 16 if M <= 16 else (32 if M <= 32 else 64)
       launch = f"""  const int64_t tiles = (n + {64 // GLr - 1}) / {64 // GLr};

@@ -36,8 +36,10 @@ The price: 22 of 32 row slots busy (k_rts3: 22 of 24), i.e. ~1.15 x the vector i
     I <- U (mirrored);  Pk_n = Pk_k + U: one coalesced read-add-write over the tile's records, the sum also goes back into I
     PS <- rows of I
 
-Generated for ordinary (non-MSCKF) lane-group models with an even number of error states whose 4 images + vectors fit 20 KB of
-LDS (8 .. 22 error states: live); every other lane-group model keeps k_rts3 / rn::k_rts_group.
+Generated for ordinary (non-MSCKF) lane-group models whose 4 images + vectors fit 20 KB of LDS (8 .. 22 error states, odd counts
+included: live, kinematic9); every other lane-group model -- MSCKF, more states, a dense F whose non-zeros do not fit the slot --
+keeps rn::k_rts_group, which is also the fallback (`no_rts4`).  (k_rts3, the round-4 smoother in the fused run's layout, served the
+odd counts until round 6 and is gone.)
 """
 from rednose_amd.codegen.emit_common import term, sum_terms
 
@@ -79,6 +81,44 @@ def lds_bytes(spec, slot):
   return 8 * (FPW * E * E + 2 + FPW * slot + 2 * (FPW * D + 2) + FPW * E + 2 + E + 2 * FPW * (GL - -(-E // rows_per_lane(spec))) + 2)
 
 
+class RtsLayout:
+  """Scalar slot of the smoother (doubles per filter): x' = f(x) [normalised], the non-trivial entries of F, dt."""
+
+  def __init__(self, spec, f_vars, he_vars_by_kind):        # same constructor as emit_wide2.Layout / emit_wide3.RunLayout
+    D = spec.dim_x
+    self.zmax = max(k.zdim for k in spec.kinds)
+    self.nf = len(f_vars)
+    self.nh = 0
+    self.OFF_X = 0
+    self.OFF_F = D
+    self.OFF_DT = D + self.nf
+    n = self.OFF_DT + 1
+    # fields the shared scalar functions of emit_wide2.device_functions address but the smoother never calls
+    self.OFF_HE = self.OFF_DX = self.OFF_Y = self.OFF_FL = self.OFF_RF = self.OFF_RP = self.OFF_YP = n
+    self.zf = 0
+    self.SLOT = n + 1 - (n & 1)
+
+
+def _tables(spec):
+  from rednose_amd.codegen import emit_wide2 as w2
+  _, _, F, f_vars = w2._lowered_predict(spec)                  # pylint: disable=protected-access
+  lay = RtsLayout(spec, f_vars, {})
+  return lay, w2._slotted(F, f_vars, lay.OFF_F)                # pylint: disable=protected-access
+
+
+def _scal_text(spec):
+  """scal_predict against RtsLayout under the suffix _s (only that function of emit_wide2.device_functions is used)."""
+  from rednose_amd.codegen import emit_wide2 as w2
+  text, lay = w2.device_functions(spec, lay_cls=RtsLayout, sfx="_s")
+  # keep scal_predict_s only: the observation / injection functions address slot fields the smoother does not have
+  keep = []
+  for fn in text.split("\n\n"):
+    if "void scal_predict_s(" in fn:
+      keep.append(fn)
+  assert len(keep) == 1
+  return keep[0], lay
+
+
 def dt0_path(spec):
   """Steps with dt == 0 take the identity-gain path (see kernel()): only for models whose predict(dt = 0) is the identity symbolically."""
   from rednose_amd.codegen import tuning
@@ -86,26 +126,26 @@ def dt0_path(spec):
 
 
 def applicable(spec):
-  from rednose_amd.codegen import emit_rts3
-  if not emit_rts3.applicable(spec):
+  """Ordinary (non-MSCKF) lane-group models with 8 .. 32 error states whose four images + vectors fit LDS_BUDGET."""
+  msckf = any(k.He_sym is not None for k in spec.kinds) or spec.N > 0
+  if msckf or spec.dim_main_err != spec.dim_err:
     return False
   E = spec.dim_err
-  if E % 2 or E < 8 or E > 2 * GL:
+  if E < 8 or E > 2 * GL:
     return False
-  lay, _ = emit_rts3._tables(spec)           # pylint: disable=protected-access
+  lay, _ = _tables(spec)
   return lds_bytes(spec, lay.SLOT) <= LDS_BUDGET
 
 
 def kernel(spec):
-  from rednose_amd.codegen import emit_rts3
   D, E = spec.dim_x, spec.dim_err
   EE = E * E
   R = rows_per_lane(spec)
   S = range(R)
   RS = -(-E // R)        # rows per slot: row r lives in slot r // RS of lane r % RS (22 states: 2 x 11 -- balanced slots keep the block lower
                          # triangles of the symmetric matrices at 11 + 22 columns per lane instead of 16 + 22, and lanes RS .. 15 idle)
-  scal, lay = emit_rts3._scal_text(spec)      # pylint: disable=protected-access
-  _, Fs = emit_rts3._tables(spec)             # pylint: disable=protected-access
+  scal, lay = _scal_text(spec)
+  _, Fs = _tables(spec)
   scal = scal.replace("scal_predict_s(", "scal_predict_s4(")
   quat = "".join(f" rn::normalize_quat<{D}>(xv, {q});" for q in spec.quaternion_idxs)
   b = []
@@ -239,7 +279,14 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
     A(f"      const double qd{s} = gQ[rq{s} * {E + 1}];      // (not kept across steps: four registers of a kernel that has none to spare)")
   A("      RN_RTS_STAMP(0);")
   A("      // ---- A. filtered pair of step k: Pk_k -> image in one coalesced burst, xk_k -> LDS ----")
-  A(f"      if (cnt == {FPW}) {{      // (full tile: unguarded transfers -- sixteen predicated regions otherwise)")
+  if EE % 2:
+    # Records of an odd number of doubles: the tile of step k starts at (k n + base) E^2 doubles, 16-byte aligned only when k n is even.  The
+    # direct HBM -> LDS transfer wants 16-byte aligned global addresses; ordinary 16-byte vector loads do not (dword alignment is enough on the
+    # device), so these models stage the tile through registers -- the copy is not hidden under the scalar phase (the test models and kinematic9).
+    A(f"      rn::copy_g2l<{FPW} * {EE}>(Pf + (k * n + base) * {EE}, cnt * {EE}, s_I, lb);")
+    A("      if (false) {")
+  else:
+    A(f"      if (cnt == {FPW}) {{      // (full tile: unguarded transfers -- sixteen predicated regions otherwise)")
   A(f"        const double* __restrict__ gp = Pf + (k * n + base) * {EE};")
   A("#pragma unroll")
   A(f"        for (int it = 0; it < {IT}; it++) {{")
@@ -249,6 +296,9 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   A("      } else {")
   A(f"        rn::async_copy_g2l<{FPW} * {EE}>(Pf + (k * n + base) * {EE}, cnt * {EE}, s_I, lb);      // no register staging: lands under the scalar phase")
   A("      }")
+  if EE % 2:      # (the two branches above are dead text for these models; dropped from the output)
+    i_ = max(i for i, ln in enumerate(b) if ln.strip() == "if (false) {")
+    del b[i_:]
   A("      const double dt = dtc;")
   A("      rn::wave_lds_sync();")
   A("      RN_RTS_STAMP(1);")
@@ -317,6 +367,8 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
           A("#pragma unroll")
           A(f"          for (int j = 0; j < {RS * s}; j++) swc[j * st] = ps{s}[j]; }}")
       A("        rn::wave_lds_sync();")
+    else:
+      A("        rn::wave_lds_sync();      // every lane has read what it mirrors from other rows: the rows take the sums")
     for s in S:
       A("        {")
       A(f"          double o_[{E}];")
@@ -335,12 +387,14 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
     A("        {      // Pk_n leaves: one coalesced pass over the tile's records")
     A("          typedef double rts4_d2 __attribute__((ext_vector_type(2)));")
     A(f"          rts4_d2* __restrict__ out2 = reinterpret_cast<rts4_d2*>(Ps + (k * n + base) * {EE});")
-    A(f"          const int nv = cnt * {EE // 2};")
+    A(f"          const int nv = (cnt * {EE}) / 2;")
     A("#pragma unroll")
     A(f"          for (int it = 0; it < {IT}; it++) {{")
     A("            const int idx = lo + 64 * it;")
     A(f"            if ((cnt == {FPW} && it < {ITF}) || idx < nv) out2[idx] = *reinterpret_cast<const rts4_d2*>(s_I + 2 * idx);")
     A("          }")
+    if EE % 2:
+      A(f"          if (((cnt * {EE}) & 1) && lo == 0) Ps[(k * n + base) * {EE} + cnt * {EE} - 1] = s_I[cnt * {EE} - 1];      // (odd record length, ragged tile: the last double)")
     A("        }")
     A('        asm volatile("" : ' + ", ".join(f'"+v"(rq{s})' for s in S) + ");")
     lower_rows("ps", ind="        ", full=False)
@@ -583,7 +637,7 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   A('      asm volatile("" : "+v"(le));')
   A(f"      const rts4_d2* __restrict__ in2 = reinterpret_cast<const rts4_d2*>(Pf + (k * n + base) * {EE});")
   A(f"      rts4_d2* __restrict__ out2 = reinterpret_cast<rts4_d2*>(Ps + (k * n + base) * {EE});")
-  A(f"      const int nv = cnt * {EE // 2};")
+  A(f"      const int nv = (cnt * {EE}) / 2;")
   A(f"      rts4_d2 v[{IT}];")
   A(f"      double xnext[{XT}];      // filtered state of the next (older) step")
   # U in column blocks of one slot's rows each, ordered so that row sets die early: a block of columns [RS q, RS q + RS) broadcasts only
@@ -671,6 +725,13 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   A("            *im = w_;")
   A("          }")
   A("        }")
+  if EE % 2:
+    A(f"        if (((cnt * {EE}) & 1) && le == 0) {{      // odd record length, ragged tile: the last double")
+    A(f"          const int e_ = cnt * {EE} - 1;")
+    A(f"          const double w_ = Pf[(k * n + base) * {EE} + e_] + s_I[e_];")
+    A(f"          Ps[(k * n + base) * {EE} + e_] = w_;")
+    A("          s_I[e_] = w_;")
+    A("        }")
   A("      }")
   A("      rn::wave_lds_sync();")
   A('      asm volatile("" : ' + ", ".join(f'"+v"(rq{s})' for s in S) + ");      // (fresh addresses: those of the step's first row read are not worth registers across the step)")

@@ -147,22 +147,30 @@ def update_regs(spec, k, sym=False):
   # columns He touches for C below, all rows of those; an entry below the diagonal starts from its mirror image and lives in the
   # (otherwise unused) lower half of the array until the final mirroring overwrites it.
   hcols = sorted({j for zi in range(Z) for j, _ in He.row_nz(zi)})
+  # The rank-Z passes are printed as nested multiply-adds, acc -+ a0 b0 -+ a1 b1 .. = fma(-+a0, b0, fma(-+a1, b1, .. acc)): Z instructions per
+  # entry.  Printed as `acc -= a0*b0 + a1*b1 + ..` hipcc contracts the sum (1 multiply + Z - 1 multiply-adds) but does not reassociate it into
+  # the accumulator: one more add per entry, 20-25 % of this issue-bound kernel's fp64 instructions (ekf_c.c:105,115: same products, the sum
+  # taken in another order).
+  def chain(acc, pairs, neg=False):
+    out = acc
+    for a_, b_ in reversed(list(pairs)):
+      out = f"fma({'-' if neg else ''}{a_}, {b_}, {out})"
+    return out
   if sym:       # the entries below the diagonal first: they start from upper-triangle values the in-place pass below overwrites
     for i in range(E):
       for j in (c_ for c_ in hcols if c_ < i):
-        b.append(f"P[{i * E + j}] = {U(i, j)} - (" + " + ".join(f"{K(i, zi)}*G_{zi}_{j}" for zi in range(Z)) + ");")
+        b.append(f"P[{i * E + j}] = {chain(U(i, j), ((K(i, zi), f'G_{zi}_{j}') for zi in range(Z)), neg=True)};")
   for i in range(E):
     for j in range(i if sym else 0, E):
-      b.append(f"P[{i * E + j}] -= " + " + ".join(f"{K(i, zi)}*G_{zi}_{j}" for zi in range(Z)) + ";")
+      b.append(f"P[{i * E + j}] = {chain(f'P[{i * E + j}]', ((K(i, zi), f'G_{zi}_{j}') for zi in range(Z)), neg=True)};")
   # C = B He^T, D = K R - C
   for i in range(E):
     for zi in range(Z):
       c = sum_terms(term(cf, f"P[{i * E + j}]") for j, cf in He.row_nz(zi))
-      kr = " + ".join(f"{K(i, w)}*Rl[{w * Z + zi}]" for w in range(Z))
-      b.append(f"const double Dm_{i}_{zi} = ({kr}) - ({c});")
+      b.append(f"const double Dm_{i}_{zi} = {chain(f'-({c})', ((K(i, w), f'Rl[{w * Z + zi}]') for w in range(Z)))};")
   for i in range(E):
     for j in range(i if sym else 0, E):
-      b.append(f"P[{i * E + j}] += " + " + ".join(f"Dm_{i}_{zi}*{K(j, zi)}" for zi in range(Z)) + ";")
+      b.append(f"P[{i * E + j}] = {chain(f'P[{i * E + j}]', ((f'Dm_{i}_{zi}', K(j, zi)) for zi in range(Z)))};")
   if sym:
     b += [f"P[{j * E + i}] = P[{i * E + j}];" for i in range(E) for j in range(i + 1, E)]
   for i in range(D):

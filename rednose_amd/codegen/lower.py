@@ -75,8 +75,9 @@ NULLSPACE_RESIDUAL = r"""namespace rn {
 // (:120) and returns in its Estimate (ekf_sym.cc:164-184).  x and P do not depend on the basis (the update runs in the orthonormal one the
 // Householder reflectors give, templates/ekf_hip_rt.h), y does; so y alone is also formed here the way Eigen forms it: Gaussian
 // elimination of M = Hea^T (A x Z) with FULL pivoting, P M Q = L U, U = [U1 U2], kernel vectors Q [-U1^-1 U2 ; I] (column c has its 1 at
-// the (A + c)-th permuted position) -- the loops of oracle/ekf_oracle.c:fullpiv_kernel, the same pivot choice on ties (first maximum in
-// row-major order).  The pivots' positions are run-time values; every array here is indexed STATICALLY and the exchanges are selects
+// the (A + c)-th permuted position) -- the loops of oracle/ekf_oracle.c:fullpiv_kernel, Eigen's pivot choice on ties (its maxCoeff
+// visitor walks the corner column by column and keeps the FIRST maximum) and Eigen's rank decision (every pivot against
+// epsilon x min(A, Z) x the LARGEST pivot met, FullPivLU::threshold() / rank()).  The pivots' positions are run-time values; every array here is indexed STATICALLY and the exchanges are selects
 // (a register array indexed at run time goes to scratch memory, and a first version that kept U in the filter's LDS slot spent 3 us per
 // tile in ~20 dependent LDS round trips on the one lane per filter that runs this: feature36 launch 83.5 -> 89.8 us; this form: see
 // profiles/tuning_notes.md).  One division per pivot.  Returns false (yout = 0) when Hea^T has rank < A by Eigen's threshold.
@@ -91,24 +92,23 @@ __device__ __forceinline__ bool nullspace_residual(const double (&Hea)[Z * A], c
   }
 #pragma unroll
   for (int j = 0; j < Z; j++) pm[j] = j;
-  bool full = true;
   double maxpiv = 0.0;
-  double ipv[A];
+  double ipv[A], piv[A];
 #pragma unroll
   for (int k = 0; k < A; k++) {
     int pr = k, pc = k;
     double best = 0.0;
 #pragma unroll
-    for (int i = k; i < A; i++) {
+    for (int j = k; j < Z; j++) {          // column by column, first maximum: Eigen's visitor order (a tie between equal entries picks the same one)
 #pragma unroll
-      for (int j = k; j < Z; j++) {
+      for (int i = k; i < A; i++) {
         const double a = fabs(U[i * Z + j]);
         const bool gt = a > best;
         best = gt ? a : best; pr = gt ? i : pr; pc = gt ? j : pc;
       }
     }
-    if (k == 0) maxpiv = best;
-    full = full && (best > 2.220446049250313e-16 * Z * maxpiv);
+    piv[k] = best;
+    maxpiv = best > maxpiv ? best : maxpiv;          // the largest pivot so far (later pivots of a Schur complement can exceed the first)
     // rows k <-> pr (columns left of k hold nothing that is read again)
 #pragma unroll
     for (int j = k; j < Z; j++) {
@@ -142,6 +142,9 @@ __device__ __forceinline__ bool nullspace_residual(const double (&Hea)[Z * A], c
       for (int j = k; j < Z; j++) U[i * Z + j] -= l * U[k * Z + j];
     }
   }
+  bool full = true;      // rank == A: every pivot above epsilon x diagonalSize x largest pivot (an exact zero pivot fails it too)
+#pragma unroll
+  for (int k = 0; k < A; k++) full = full && (piv[k] > 2.220446049250313e-16 * (A < Z ? A : Z) * maxpiv);
   double yp[Z];      // y in pivot order
 #pragma unroll
   for (int j = 0; j < Z; j++) {

@@ -18,10 +18,9 @@ variants do not overwrite generated/).  What each alternative measured: profiles
   exact_math   1 = IEEE division / square root and ocml sin / cos in place of the fast primitives (reference build for the accuracy tests; full sin / cos range)
   run2         1 = fused run of lane-group models up to 22 error states as TWO wavefronts per tile, matrix + scalar (emit_run2), 0 = k_run (emit_wide3)
   run2_prio    s_setprio level of emit_run2's scalar wavefront (its chain of dependent instructions issues ahead of the co-resident matrix wavefront's FMAs); 0 = none
-  rts4         1 = smoother of lane-group models with register-broadcast operands (emit_rts4: 16 lanes x 2 rows, 4 filters per wavefront, two wavefronts per SIMD), 0 = rts3
+  rts4         1 = smoother of lane-group models with register-broadcast operands (emit_rts4: 16 lanes x 2 rows, 4 filters per wavefront, two wavefronts per SIMD), 0 = rn::k_rts_group
   rts_dt0      1 = backward steps with dt == 0 of a model whose predict(dt = 0) is the identity take the identity-gain path of k_rts4 (Ck = I: no
                factorisation, no products); 0 = the full solve on every step
-  rts3         1 = smoother of lane-group models in the fused run's layout (emit_rts3: 8 filters per wavefront), 0 = rn::k_rts_group
 """
 import os
 from dataclasses import dataclass, fields
@@ -39,10 +38,9 @@ class Tuning:
   small_waves: int = 0
   small_max_e: int = 7
   run_block: int = 0
-  rts3: int = 1
   run2_prio: int = 0              # (measured: 20.5-20.9 ms per config-4 chunk at 3 against 20.4 at 0 -- the scalar wavefront is not on the critical path)
   run2: int = 1              # fused run with a scalar wavefront beside the matrix wavefront (emit_run2: two wavefronts per SIMD); 0 = emit_wide3's k_run
-  rts4: int = 1              # smoother with every cross-lane operand by row_newbcast, two wavefronts per SIMD (emit_rts4: even E, 8 .. 22 error states); 0 = emit_rts3
+  rts4: int = 1              # smoother with every cross-lane operand by row_newbcast, two wavefronts per SIMD (emit_rts4: 8 .. 22 error states); 0 = rn::k_rts_group
   rts_dt0: int = 1           # identity-gain path for dt == 0 steps in k_rts4 (models with identity_at_dt0 only); 0 = full solve on every step
   exact_math: int = 0        # 1 = IEEE division / sqrt and the library's sin / cos instead of the hardware-seed + Newton primitives and rn::sincos_fast (a reference build for tests: tests/test_gpu_live.py)
   nt_trace: int = 1          # the fused run's covariance trace leaves with nontemporal stores (config 4 forward: 23.5 vs 24.5 ms per chunk, same call)

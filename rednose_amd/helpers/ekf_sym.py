@@ -76,9 +76,8 @@ def gen_code(folder, name, f_sym, dt_sym, x_sym, obs_eqs, dim_x, dim_err, eskf_p
       if bad and rn_emit.family(spec, ()) == "small":
         usage, bad = fall_back("force_wide", f"lane-per-filter kernels {bad} spill registers: regenerating in the lane-group family")
       if "k_rts4" in bad:
-        usage, bad = fall_back("no_rts4", "the register-broadcast smoother spills under its two-wavefronts-per-SIMD budget: the fused run's layout instead")
-      if "k_rts3" in bad:
-        usage, bad = fall_back("no_rts3", "the smoother in the fused run's layout spills registers: lane-group smoother instead")
+        usage, bad = fall_back("no_rts4", "the register-broadcast smoother spills under its two-wavefronts-per-SIMD budget (or a DPP read follows the write of its "
+                                          "source too closely): lane-group smoother instead")
       if "k_run2" in bad:
         usage, bad = fall_back("no_run2", "the two-wavefront fused run spills under its 256-register budget: the single-wavefront k_run instead")
       if "k_run" in bad and usage["k_run"]["scratch"] > 0 and rn_emit.family(spec, tuple(fallbacks)) == "wide":
@@ -405,8 +404,9 @@ class BatchedEKF:
   The batch axis does not exist in the reference (its `predict_and_update_batch` applies n observations
   to ONE filter, ekf_sym.py:484-531); this class adds it behind the same vocabulary.  Layout is the
   natural batch of the reference's per-filter buffers: x (N, D), P (N, E, E) row-major fp64, contiguous.
-  A call carries ONE observation kind; z is (N, Z) -- one observation per filter -- and R is one shared (Z, Z) matrix or
-  (N, Z, Z).  Two time models:
+  A call carries ONE observation kind; z is (N, Z) -- one observation per filter, R one shared (Z, Z) matrix or (N, Z, Z) -- or
+  (N, n, Z): the reference's n observations per call (ekf_sym.py:512-524, ekf_sym.cc:172-180: ONE predict, n sequential updates,
+  ONE checkpoint), R then (Z, Z), (n, Z, Z) or (N, n, Z, Z) and extra_args (n, EA) or (N, n, EA).  Two time models:
     * shared timeline (default): every call advances all filters to one time t;
     * per-filter timelines (per_filter=True, or the first call that passes a time vector / an `active` mask): every filter
       keeps its own filter_time, a call advances exactly the filters named by `active` to their own t[i], and -- with
@@ -664,10 +664,141 @@ class BatchedEKF:
     if self.rewind_to_keep > 0:
       assert not augment, "augment with the rewind ring is not supported (the reference asserts the same, ekf_sym.cc:186)"
       return self._predict_and_update_with_rewind(t, kind, z, R, extra_args, keep_estimate)
-    ret = self._predict_and_update(t, kind, z, R, extra_args, keep_estimate)
+    ret = self._apply(t, kind, z, R, extra_args, keep_estimate)
     if augment:
       self.augment()
     return ret
+
+  def _apply(self, t, kind, z, R, extra_args, keep_estimate):
+    """predict to t + the observation(s) of one call on the shared timeline: z (N, Z) one per filter, z (N, n, Z) n per filter."""
+    if getattr(z, "ndim", None) == 3 or (not hasattr(z, "ndim") and np.ndim(z) == 3):
+      return self._predict_and_update_multi(t, kind, z, R, extra_args, keep_estimate)
+    return self._predict_and_update(t, kind, z, R, extra_args, keep_estimate)
+
+  # -- n observations per call (SURVEY.md a13: the reference's predict_and_update_batch proper) ---------------------
+  multi_obs_fused = None      # None: one batch_run launch where the library allows it (see _predict_and_update_multi); False: step-granular launches
+
+  def _multi_obs(self, kind, z, R, extra_args):
+    """The n observations of one call in canonical form: zl = n device tensors (N, Z), each in its own allocation (the kernels want
+    16-byte aligned rows and overwrite them with the residuals), Rl = n device noise matrices ((Z, Z) shared by the filters or
+    (N, Z, Z)), per = 1 for per-filter noise, eal = n (N, EA) tensors or Nones.  Shapes accepted: z (N, n, Z) [or (1, n, Z): the same
+    observations for every filter]; R (Z, Z) | (n, Z, Z) | (N, n, Z, Z) -- the reference passes (n, Z, Z), KalmanFilter.get_R(kind, n);
+    extra_args (n, EA) | (N, n, EA)."""
+    torch = self._torch
+    if kind not in self.zdims:
+      raise KeyError(kind)
+    N, Z, EA = self.batch, self.zdims[kind], self.eadims.get(kind, 0)
+    zt = z if isinstance(z, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(z, dtype=np.float64))
+    if zt.ndim != 3 or zt.shape[0] not in (1, N) or zt.shape[2] != Z:
+      raise KalmanError(f"n observations per call: z must be (N, n, {Z}) for kind {kind}, got {tuple(zt.shape)}")
+    n = int(zt.shape[1])
+    if n == 0:
+      return [], [], 0, []
+    zt = zt.to(device=self.device, dtype=torch.float64).expand(N, n, Z)
+    Rt = R if isinstance(R, torch.Tensor) else np.asarray(R, dtype=np.float64)
+    if Rt.ndim == 2:
+      Rj = [Rt] * n
+    elif Rt.ndim == 3:
+      if Rt.shape[0] != n:
+        raise KalmanError(f"n observations per call: a 3-D R is (n, Z, Z) -- one matrix per observation, like the reference's -- got {tuple(Rt.shape)} for n = {n}")
+      Rj = [Rt[j] for j in range(n)]
+    elif Rt.ndim == 4:
+      if tuple(Rt.shape[:2]) != (N, n):
+        raise KalmanError(f"n observations per call: a 4-D R is (N, n, Z, Z), got {tuple(Rt.shape)}")
+      Rj = [Rt[:, j] for j in range(n)]
+    else:
+      raise KalmanError(f"R: unexpected shape {tuple(Rt.shape)}")
+    zl, Rl, pers = [], [], set()
+    for j in range(n):
+      zj = zt[:, j].contiguous()
+      if zj.data_ptr() == zt.data_ptr() and n > 1:      # (cannot happen for n > 1; for n == 1 the caller's tensor is consumed like a 2-D z)
+        zj = zj.clone()
+      zj, Rd, per = self._obs_args(kind, zj, Rj[j])
+      zl.append(zj)
+      Rl.append(Rd)
+      pers.add(per)
+    assert len(pers) == 1
+    if EA == 0:
+      eal = [None] * n
+    else:
+      if extra_args is None:
+        raise KalmanError(f"kind {kind} takes {EA} extra arguments per observation")
+      ea = extra_args if isinstance(extra_args, torch.Tensor) else np.asarray(extra_args, dtype=np.float64)
+      if ea.ndim == 2 and tuple(ea.shape) == (n, EA):
+        eal = [self._ea(kind, ea[j]) for j in range(n)]
+      elif ea.ndim == 3 and tuple(ea.shape) == (N, n, EA):
+        eal = [self._ea(kind, ea[:, j]) for j in range(n)]
+      else:
+        raise KalmanError(f"n observations per call: extra_args must be ({n}, {EA}) or ({N}, {n}, {EA}), got {tuple(ea.shape)}")
+    return zl, Rl, pers.pop(), eal
+
+  def _identity_dt0(self):
+    fn = getattr(self._lib, f"{self.name}_predict_identity_at_dt0", None)
+    return bool(fn()) if fn is not None else False
+
+  def _predict_and_update_multi(self, t, kind, z, R, extra_args, keep_estimate):
+    """EKFSym::predict_and_update_batch with n observations (ekf_sym.cc:158-194, ekf_sym.py:484-531) for every filter of the batch: ONE
+    predict to t, then the n observations z[:, i] applied in order (quaternions renormalised after each, :521), one Estimate.
+
+    Served by ONE batch_run launch -- a schedule of n steps of this kind with dts = (dt, 0, ..., 0), x and P on chip between the
+    updates -- when the noise is shared by the filters, the library has the fused run and its predict(dt = 0) is the identity
+    ({name}_predict_identity_at_dt0: the fused run predicts on every step, the reference only once); otherwise by one fused
+    predict + update launch and n - 1 batch_update launches.  (batch_run reads (P + P^T) / 2: include/rednose_amd_filter.h;
+    multi_obs_fused = False keeps the step-granular launches, the reference's arithmetic on any P.)
+    Returns y (N, n, Z), or with keep_estimate the reference's 9-tuple with y a list of n (N, Z) tensors and z (N, n, Z)."""
+    torch = self._torch
+    zl, Rl, per, eal = self._multi_obs(kind, z, R, extra_args)
+    n, N, Z = len(zl), self.batch, self.zdims[kind]
+    dt = self._dt(t)
+    if n == 0:              # no observations: the reference's loop body never runs -- a predict and a checkpoint
+      self.predict_dt(dt)
+      self.filter_time = t
+      y = torch.empty((N, 0, Z), dtype=torch.float64, device=self.device)
+      return (self.x.clone(), self.x.clone(), self.P.clone(), self.P.clone(), t, kind, [], y, extra_args) if keep_estimate else y
+    z_orig = torch.stack(zl, 1) if keep_estimate else None
+    fl = torch.zeros((n, N), dtype=torch.uint8, device=self.device)
+    xk_km1 = Pk_km1 = None
+    if keep_estimate:
+      self.predict_dt(dt)
+      xk_km1, Pk_km1 = self.x.clone(), self.P.clone()
+    can_fuse = (per == 0 and not isinstance(dt, torch.Tensor) and n > 1 and self._has_batch_run() and self._identity_dt0())
+    fused = can_fuse if self.multi_obs_fused is None else (bool(self.multi_obs_fused) and can_fuse)
+    if fused:
+      zmax = getattr(self._lib, f"{self.name}_zmax")()
+      zs = torch.zeros((n, N, zmax), dtype=torch.float64, device=self.device)
+      zs[:, :, :Z] = torch.stack(zl, 0)
+      table = torch.zeros((n, zmax * zmax), dtype=torch.float64, device=self.device)
+      table[:, :Z * Z] = torch.stack([r_.reshape(-1) for r_ in Rl], 0)
+      kd = torch.full((n,), int(kind), dtype=torch.int32, device=self.device)
+      dd = torch.zeros(n, dtype=torch.float64, device=self.device)
+      if not keep_estimate:
+        dd[0] = float(dt)
+      ead = max(list(self.eadims.values()) + [0])
+      ea = None
+      if eal[0] is not None:
+        ea = torch.zeros((n, N, ead), dtype=torch.float64, device=self.device)
+        ea[:, :, :eal[0].shape[1]] = torch.stack(eal, 0)
+      self._call("batch_run", self._p(self.x), self._p(self.P), self._p(self.Q), self._p(kd), self._p(dd), n, self._p(zs), self._p(table), N,
+                 self.norm_quats, self._p(fl), None, None, self._p(ea), None, self._stream())
+      self._keepalive_multi = (kd, dd, table, ea, zs)
+      y = zs[:, :, :Z].permute(1, 0, 2).contiguous()
+    else:
+      dt_ptr, dt_s = self._dt_args(dt)
+      for j in range(n):
+        if j == 0 and not keep_estimate:
+          self._call(f"batch_predict_update_{kind}", self._p(self.x), self._p(self.P), self._p(self.Q), dt_ptr, dt_s, self._p(zl[0]), self._p(Rl[0]), per,
+                     self._p(eal[0]), N, self.norm_quats, self._p(fl[0]), self._stream())
+        else:
+          self._call(f"batch_update_{kind}", self._p(self.x), self._p(self.P), self._p(zl[j]), self._p(Rl[j]), per, self._p(eal[j]), N, self.norm_quats,
+                     self._p(fl[j]), self._stream())
+      self._keepalive_multi = (zl, Rl, eal)
+      y = torch.stack(zl, 1)
+    self.filter_time = t
+    self.flags.copy_(fl[n - 1])      # flags: the last observation's, as after n single-observation calls; flags_obs: all of them
+    self.flags_obs = fl.t()
+    if keep_estimate:
+      return xk_km1, self.x.clone(), Pk_km1, self.P.clone(), t, kind, list(y.unbind(1)), z_orig, extra_args
+    return y
 
   # -- per-filter timelines (SURVEY.md 8f row 1) -------------------------------------------------------------------
   def filter_times(self):
@@ -678,19 +809,36 @@ class BatchedEKF:
       return ft
     return torch.full((self.batch,), float("nan") if ft is None else float(ft), dtype=torch.float64, device=self.device)
 
-  def _masked_step(self, kind, zin, Rd, per, ea, dt, act_u8, keep_estimate=False):
-    """One launch over the batch that touches only the filters with act_u8 != 0; dt: (N,) device tensor."""
+  def _masked_step(self, kind, zl, Rl, per, eal, dt, act_u8, keep_estimate=False, nobs=None):
+    """The observation(s) of one call for the filters with act_u8 != 0 only; dt: (N,) device tensor.  zl / Rl / eal: lists of n (one
+    entry per observation of the call: _multi_obs; a single observation is n = 1).  ONE predict -- fused with the first update unless
+    the Estimate's predicted pair is wanted -- then the remaining updates as update-only launches (never a predict(0): it is not the
+    identity for every model).  nobs (N,) int tensor: filter i has only its first nobs[i] observations (replayed ring entries of
+    different calls); None: all n."""
+    torch = self._torch
     dt = dt.contiguous()
-    args_obs = (self._p(zin), self._p(Rd), per, self._p(ea), self.batch, self.norm_quats, self._p(self.flags), self._p(act_u8), self._stream())
-    self._keepalive_masked = (dt, act_u8, zin, Rd, ea)
-    if not keep_estimate:
-      self._call(f"batch_predict_update_{kind}_masked", self._p(self.x), self._p(self.P), self._p(self.Q), self._p(dt), 0.0, *args_obs)
-      return None
-    self._call("batch_predict_masked", self._p(self.x), self._p(self.P), self._p(self.Q), self._p(dt), 0.0, self.batch, self.norm_quats,
-               self._p(act_u8), self._stream())
-    xk_km1, Pk_km1 = self.x.clone(), self.P.clone()
-    self._call(f"batch_update_{kind}_masked", self._p(self.x), self._p(self.P), *args_obs)
-    return xk_km1, Pk_km1
+    keep = [dt, act_u8]
+    est = None
+
+    def obs_args(j, a8):
+      keep.extend((zl[j], Rl[j], eal[j], a8))
+      return (self._p(zl[j]), self._p(Rl[j]), per, self._p(eal[j]), self.batch, self.norm_quats, self._p(self.flags), self._p(a8), self._stream())
+    if keep_estimate:
+      self._call("batch_predict_masked", self._p(self.x), self._p(self.P), self._p(self.Q), self._p(dt), 0.0, self.batch, self.norm_quats,
+                 self._p(act_u8), self._stream())
+      est = (self.x.clone(), self.P.clone())
+    for j in range(len(zl)):
+      a8 = act_u8 if nobs is None else (act_u8 * (nobs > j).to(torch.uint8))
+      if j > 0 and nobs is not None:
+        fl_old = self.flags.clone()
+      if j == 0 and not keep_estimate:
+        self._call(f"batch_predict_update_{kind}_masked", self._p(self.x), self._p(self.P), self._p(self.Q), self._p(dt), 0.0, *obs_args(j, a8))
+      else:
+        self._call(f"batch_update_{kind}_masked", self._p(self.x), self._p(self.P), *obs_args(j, a8))
+      if j > 0 and nobs is not None:      # a filter with fewer observations keeps the flags of its last one (the launch wrote "not active" for it)
+        self.flags.copy_(torch.where(a8 != 0, self.flags, fl_old))
+    self._keepalive_masked = keep
+    return est
 
   def _predict_and_update_per_filter(self, t, kind, z, R, extra_args, active, keep_estimate=False):
     torch = self._torch
@@ -702,11 +850,17 @@ class BatchedEKF:
     tt = (torch.full((N,), float(t), dtype=torch.float64, device=self.device) if np.isscalar(t) else self._dev(t, (N,)))
     act = (torch.ones(N, dtype=torch.bool, device=self.device) if active is None
            else torch.as_tensor(active, device=self.device).to(torch.bool).expand(N).clone())
-    zin, Rd, per = self._obs_args(kind, z, R)
-    if isinstance(z, torch.Tensor) and zin.data_ptr() == z.data_ptr() and keep_estimate:
-      zin = zin.clone()
-    ea = self._ea(kind, extra_args)
-    z_obs = zin.clone() if (self.rewind_to_keep > 0 or keep_estimate) else None       # the kernel overwrites z with the residual
+    multi = (z.ndim if hasattr(z, "ndim") else np.ndim(z)) == 3      # (N, n, Z): n observations per filter in this call
+    if multi:
+      zl, Rl, per, eal = self._multi_obs(kind, z, R, extra_args)
+      if not zl:
+        raise KalmanError("per-filter timelines: a call needs at least one observation per filter (use predict(t, active) to propagate only)")
+    else:
+      zin, Rd, per = self._obs_args(kind, z, R)
+      if isinstance(z, torch.Tensor) and zin.data_ptr() == z.data_ptr() and keep_estimate:
+        zin = zin.clone()
+      zl, Rl, eal = [zin], [Rd], [self._ea(kind, extra_args)]
+    z_obs = [zj.clone() for zj in zl] if (self.rewind_to_keep > 0 or keep_estimate) else None       # the kernels overwrite z with the residuals
     ft = self.filter_times()
     self.filter_time = ft
     late = act & ~torch.isnan(ft) & (tt < ft)
@@ -721,12 +875,12 @@ class BatchedEKF:
       act = act & ~dropped
       ft = self.filter_time
     dt = torch.where(act, torch.nan_to_num(tt - ft, nan=0.0), torch.zeros_like(tt))
-    est = self._masked_step(kind, zin, Rd, per, ea, dt, act.to(torch.uint8), keep_estimate)
+    est = self._masked_step(kind, zl, Rl, per, eal, dt, act.to(torch.uint8), keep_estimate)
     self.filter_time = torch.where(act, tt, ft)
     if self.rewind_to_keep > 0:
-      self._ring_push(act, self.filter_time, kind, z_obs, Rd, per, ea)
-    # The Estimate is the state right after THIS observation -- the reference captures `ret` before it fast-forwards over the
-    # observations the rewind overtook (ekf_sym.py:473-479) -- and the flags the caller reads are this observation's too: the
+      self._ring_push(act, self.filter_time, kind, z_obs, Rl, per, eal)
+    # The Estimate is the state right after THIS call's observations -- the reference captures `ret` before it fast-forwards over the
+    # observations the rewind overtook (ekf_sym.py:473-479) -- and the flags the caller reads are this call's too: the
     # replay launches write the replayed (older) observations' flags into the same buffer.
     xk_k, Pk_k = (self.x.clone(), self.P.clone()) if keep_estimate else (None, None)
     if replay is not None:
@@ -735,28 +889,43 @@ class BatchedEKF:
       self.flags.copy_(fl_new)        # (into the SAME buffer: bind_step() captured its address)
     if bool(dropped.any()):
       self.flags |= dropped.to(torch.uint8) * 32
+    if multi:
+      y = torch.stack(zl, 1)
+      if keep_estimate:
+        return est[0], xk_k, est[1], Pk_k, tt, kind, list(y.unbind(1)), torch.stack(z_obs, 1), extra_args
+      return y
     if keep_estimate:
-      return est[0], xk_k, est[1], Pk_k, tt, kind, zin, z_obs, extra_args
-    return zin
+      return est[0], xk_k, est[1], Pk_k, tt, kind, zl[0], z_obs[0], extra_args
+    return zl[0]
 
-  def _ring_alloc(self):
+  def _ring_alloc(self, nmax=1):
+    """Per-filter checkpoint rings in HBM: K entries per filter, an entry = time, state after the call, and the call's observation(s) --
+    up to `nmax` of them (grown on demand by the first call that carries more: _ring_push)."""
     torch = self._torch
     K, N, D, E = self.rewind_to_keep, self.batch, self.dim_x, self.dim_err
     zmax = max(self.zdims.values())
     eam = max(list(self.eadims.values()) + [0])
     f64 = dict(dtype=torch.float64, device=self.device)
+    old = self._ring
     self._ring = dict(
       t=torch.full((K, N), float("nan"), **f64), x=torch.empty((K, N, D), **f64), P=torch.empty((K, N, E, E), **f64),
-      kind=torch.zeros((K, N), dtype=torch.int32, device=self.device), z=torch.zeros((K, N, zmax), **f64),
-      R=torch.zeros((K, N, zmax, zmax), **f64), ea=torch.zeros((K, N, max(eam, 1)), **f64),
-      head=torch.zeros(N, dtype=torch.int64, device=self.device), length=torch.zeros(N, dtype=torch.int64, device=self.device))
+      kind=torch.zeros((K, N), dtype=torch.int32, device=self.device), nobs=torch.ones((K, N), dtype=torch.int32, device=self.device),
+      z=torch.zeros((K, N, nmax, zmax), **f64), R=torch.zeros((K, N, nmax, zmax, zmax), **f64), ea=torch.zeros((K, N, nmax, max(eam, 1)), **f64),
+      head=torch.zeros(N, dtype=torch.int64, device=self.device), length=torch.zeros(N, dtype=torch.int64, device=self.device), nmax=nmax)
+    if old is not None:         # grown: everything kept, the observation arrays copied into the wider ones
+      for key in ("t", "x", "P", "kind", "nobs", "head", "length"):
+        self._ring[key] = old[key]
+      for key in ("z", "R", "ea"):
+        self._ring[key][:, :, :old["nmax"]] = old[key]
 
-  def _ring_push(self, mask, times, kind, z_obs, Rd, per, ea):
-    """checkpoint (ekf_sym.py:440-450) of the filters in `mask`: state AFTER the step, its time, and the observation; each filter
-    has its own circular ring of rewind_to_keep entries in HBM."""
+  def _ring_push(self, mask, times, kind, z_obs, Rl, per, eal, nobs=None):
+    """checkpoint (ekf_sym.py:440-450) of the filters in `mask`: state AFTER the call, its time, and the call's observations (lists of n,
+    _masked_step; nobs (N,) int tensor when filters carry different counts); each filter has its own circular ring of rewind_to_keep
+    entries in HBM."""
     torch = self._torch
-    if self._ring is None:
-      self._ring_alloc()
+    n = len(z_obs)
+    if self._ring is None or self._ring["nmax"] < n:
+      self._ring_alloc(n)
     r, K = self._ring, self.rewind_to_keep
     idx = torch.nonzero(mask).flatten()
     if idx.numel() == 0:
@@ -770,10 +939,12 @@ class BatchedEKF:
     r["x"][slot, idx] = self.x[idx]
     r["P"][slot, idx] = self.P[idx]
     r["kind"][slot, idx] = int(kind)
-    r["z"][slot, idx, :Z] = z_obs[idx]
-    r["R"][slot, idx, :Z, :Z] = Rd[idx] if per else Rd
-    if ea is not None:
-      r["ea"][slot, idx, :ea.shape[1]] = ea[idx]
+    r["nobs"][slot, idx] = n if nobs is None else nobs[idx].to(torch.int32)
+    for j in range(n):
+      r["z"][slot, idx, j, :Z] = z_obs[j][idx]
+      r["R"][slot, idx, j, :Z, :Z] = Rl[j][idx] if per else Rl[j]
+      if eal[j] is not None:
+        r["ea"][slot, idx, j, :eal[j].shape[1]] = eal[j][idx]
 
   def _ring_rewind(self, late, tt):
     """rewind (ekf_sym.py:418-438) of the filters in `late`, each in its own ring: back to its last checkpoint at or before its
@@ -805,17 +976,18 @@ class BatchedEKF:
     self.filter_time = ft
     nrep = gL - gix
     maxrep = int(nrep.max())
-    rep = dict(idx=gi, n=nrep, t=[], kind=[], z=[], R=[], ea=[])
+    rep = dict(idx=gi, n=nrep, t=[], kind=[], nobs=[], z=[], R=[], ea=[])
     for q in range(maxrep):                                      # copies: the pushes below reuse these slots
       p_ = (gH + gix + q) % K
-      for key in ("t", "kind", "z", "R", "ea"):
+      for key in ("t", "kind", "nobs", "z", "R", "ea"):
         rep[key].append(r[key][p_, gi])
     r["length"][gi] = gix
     return dropped, rep
 
   def _ring_replay(self, rep):
-    """fast-forward (ekf_sym.py:477-479): the overtaken observations of every rewound filter are applied again, oldest first;
-    position q of all rewound filters is one launch per observation kind present at that position."""
+    """fast-forward (ekf_sym.py:477-479): the overtaken calls of every rewound filter are applied again, oldest first; position q of
+    all rewound filters is one group of launches per observation kind present at that position (a call's n observations: one
+    predict + update launch and n - 1 update launches, masked to the filters that have that many)."""
     torch = self._torch
     N, gi = self.batch, rep["idx"]
     for q in range(len(rep["t"])):
@@ -828,22 +1000,31 @@ class BatchedEKF:
         act[fi] = True
         tt = self.filter_time.clone()
         tt[fi] = rep["t"][q][sel]
-        zin = torch.zeros((N, Z), dtype=torch.float64, device=self.device)
-        zin[fi] = rep["z"][q][sel][:, :Z]
-        Rd = torch.zeros((N, Z, Z), dtype=torch.float64, device=self.device)
-        Rd[fi] = rep["R"][q][sel][:, :Z, :Z]
+        nobs = torch.zeros(N, dtype=torch.int32, device=self.device)
+        nobs[fi] = rep["nobs"][q][sel]
+        nq = int(nobs.max())
         EA = self.eadims.get(kind, 0)
-        ea = None
-        if EA:
-          ea = torch.zeros((N, EA), dtype=torch.float64, device=self.device)
-          ea[fi] = rep["ea"][q][sel][:, :EA]
-        z_obs = zin.clone()
+        zl, Rl, eal = [], [], []
+        for j in range(nq):
+          zin = torch.zeros((N, Z), dtype=torch.float64, device=self.device)
+          zin[fi] = rep["z"][q][sel][:, j, :Z]
+          Rd = torch.zeros((N, Z, Z), dtype=torch.float64, device=self.device)
+          Rd[fi] = rep["R"][q][sel][:, j, :Z, :Z]
+          Rd[nobs <= j] = torch.eye(Z, dtype=torch.float64, device=self.device)      # (filters masked out of launch j: any regular matrix)
+          ea = None
+          if EA:
+            ea = torch.zeros((N, EA), dtype=torch.float64, device=self.device)
+            ea[fi] = rep["ea"][q][sel][:, j, :EA]
+          zl.append(zin)
+          Rl.append(Rd)
+          eal.append(ea)
+        z_obs = [zj.clone() for zj in zl]
         dt = torch.where(act, tt - self.filter_time, torch.zeros_like(tt))
         fl = self.flags.clone()
-        self._masked_step(kind, zin, Rd, 1, ea, dt, act.to(torch.uint8))
+        self._masked_step(kind, zl, Rl, 1, eal, dt, act.to(torch.uint8), nobs=nobs)
         self.flags.copy_(torch.where(act, self.flags, fl))         # flags of the filters this replay did not touch stay (same buffer: bind_step() holds its address)
         self.filter_time = torch.where(act, tt, self.filter_time)
-        self._ring_push(act, self.filter_time, kind, z_obs, Rd, 1, ea)
+        self._ring_push(act, self.filter_time, kind, z_obs, Rl, 1, eal, nobs=nobs)
 
   def _predict_and_update_with_rewind(self, t, kind, z, R, extra_args, keep_estimate):
     """Reference semantics of EKFSym::predict_and_update_batch (ekf_sym.cc:83-117) for the whole batch: an
@@ -876,6 +1057,15 @@ class BatchedEKF:
     return ret
 
   def _checkpointed_step(self, t, kind, z, R, extra_args, keep_estimate):
+    if np.ndim(z) == 3 if not hasattr(z, "ndim") else z.ndim == 3:      # n observations per filter: ONE checkpoint for the call (ekf_sym.cc:191)
+      torch = self._torch
+      zt = (z if isinstance(z, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(z, dtype=np.float64))).to(device=self.device, dtype=torch.float64)
+      z_keep = zt.clone()
+      ret = self._predict_and_update_multi(t, kind, zt, R, extra_args, keep_estimate)
+      self.rewind_t.append(self.filter_time)
+      self.rewind_states.append((self.x.clone(), self.P.clone()))
+      self.rewind_obscache.append((t, kind, z_keep, R, extra_args))
+      return ret
     zin, Rd, _ = self._obs_args(kind, z, R)
     z_keep = zin.clone()                     # the kernel overwrites z with the residual; the ring needs the observation
     ret = self._predict_and_update(t, kind, zin, Rd, extra_args, keep_estimate)

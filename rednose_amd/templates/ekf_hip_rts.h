@@ -16,6 +16,13 @@
 // the forward pass; the predicted pair (xk1_k, Pk1_k) is recomputed here from the filtered pair of step k with the
 // same f/F code -- half the trace (140 GB instead of 279 GB at 2100 x 16384 live steps).  Outputs may alias inputs.
 //
+// Steps with dt == 0 (Model::ID0: models whose predict(dt = 0) is the identity symbolically -- f(x, 0) == x, F(x, 0) == I --, tuning knob
+// rts_dt0).  There the predicted pair IS the filtered one, Pk1_k = Pk_k bit for bit, and Ck = solve(Pk1_k, Pk_k^T)^T is the identity up to the
+// rounding of the solve (2e-9 in the reference's own live golden, np.linalg.solve).  Every kernel here takes Ck = I on such a step:
+//     xk_n = err(xk_k, inv_err(xk1_k, xk1_n))   (NOT xk1_n: err o inv_err is not the identity for finite rotations),   Pk_n = Pk_k + (Pk1_n - Pk1_k)
+// -- no factorisation, no substitutions, no products.  In an IMU + GNSS stream with several observations per tick that is half the steps.  The
+// recursion's first step always takes the full path.  (The register-broadcast smoother of the lane-group models, codegen/emit_rts4.py, does the same.)
+//
 // Two kernels: k_rts for lane-per-filter models (the first mapping written: 2 filters per wavefront, every E x E matrix in
 // LDS, rolled loops -- these models have at most 7 error states, 4 - 7 wavefronts per SIMD) and k_rts_group for lane-group
 // models (see its header).  No MFMA: the blocks are <= 64 x 64 fp64 per filter and on CDNA4 the fp64 matrix rate equals the
@@ -163,6 +170,24 @@ __global__ __launch_bounds__(64) void k_rts(const double* __restrict__ xf, const
       wave_lds_sync();
       copy_l2g<FPW * D>(xs + ((k + 1) * n + base) * D, cnt * D, s_x, lane);
       copy_l2g<FPW * EE>(Ps + ((k + 1) * n + base) * EE, cnt * EE, s_N, lane);
+
+      if (Model::ID0 && dt == 0.0 && !first) {
+        // identity-gain step (see the head of this file): Ck = I.  Dm is symmetric by now (mirrored from its lower triangle above); the filtered
+        // covariance enters the sum as stored.  dt is a scalar of the launch: the branch is uniform.
+        double delta[E];
+        Model::inv_err(x1k, xn1, delta);
+        Model::err(xk, delta, xn1);          // xk_n, becomes xk1_n of the next (older) step
+        double nrow[E];
+#pragma unroll
+        for (int m = 0; m < E; m++) nrow[m] = A[cc * E + m] + Dm[cc * E + m];
+        wave_lds_sync();           // copy_l2g above has read s_N
+        if (on) {
+#pragma unroll
+          for (int m = 0; m < E; m++) Nn[c * E + m] = nrow[m];      // Pk1_n of the next (older) step
+        }
+        wave_lds_sync();
+        continue;
+      }
 
       // ---- Cholesky of Pk1_k in LDS (left-looking by columns), lane c owns row c; loops stay rolled -------------
 #pragma unroll 1
@@ -550,6 +575,7 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
       // ---- A. filtered pair of step k: row c of Pk_k to registers, xk_k to LDS --------------------------------------
       const double* Pk = Pf + ((k * n + fil) * EE + (int64_t)cc * E);
       double y[EM];
+      const double dt = ts[k + 1] - ts[k];
       RN_RTS_STAMP(0);
       {
         // row c of Pk_k is requested first: its HBM / L2 latency passes under the scalar phase, which
@@ -557,7 +583,6 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
         double prow[EM];
         if constexpr (EM <= 32) rts_load_row_lower<E, EM>(Pk, Pf + ((k * n + fil) * EE + cc), cc, prow);
         for (int i = c; i < D; i += GL) sxk[i] = xf[(k * n + fil) * D + i];
-        const double dt = ts[k + 1] - ts[k];
         wave_lds_sync();
         // ---- B. f(xk_k), non-zeros of Fk: once per filter -> slot ----------------------------------------------------------
         RN_RTS_STAMP(1);
@@ -586,8 +611,9 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
 #pragma unroll
           for (int j = 0; j < EM; j++) nrow[j] = lrow[j];
         }
-        if (g < cnt) {
-          for (int i = c; i < D; i += GL) sxn[i] = (xl != nullptr) ? xl[fil * D + i] : sl[Model::OFF_X + i];
+        if (g < cnt) {      // (two loops, not one select between a global and an LDS source: hipcc 7.2 trips over the generic pointer)
+          if (xl != nullptr) { for (int i = c; i < D; i += GL) sxn[i] = xl[fil * D + i]; }
+          else { for (int i = c; i < D; i += GL) sxn[i] = sl[Model::OFF_X + i]; }
         }
         wave_lds_sync();
       }
@@ -628,6 +654,28 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
       }
 
       RN_RTS_STAMP(4);
+      if (Model::ID0 && dt == 0.0 && !first) {
+        // ---- identity-gain step (see the head of this file): Ck = I on the main block.  The difference buffer holds D = Pk1_n - Pk1_k,
+        // symmetric; the filtered row enters the sum as stored.  dt is a scalar of the launch: the branch is uniform. ----
+        wave_lds_sync();           // the group has written xk1_n out: the buffer takes xk_n
+        if (lead) {
+          double xb[D], xn1[D], xa[D], xnew[D], delta[E];
+#pragma unroll
+          for (int i = 0; i < D; i++) { xb[i] = sl[Model::OFF_X + i]; xn1[i] = sxn[i]; xa[i] = sxk[i]; }
+          Model::inv_err(xb, xn1, delta);
+          Model::err(xa, delta, xnew);
+#pragma unroll
+          for (int i = 0; i < D; i++) sxn[i] = (i < DM) ? xnew[i] : xa[i];       // xk_n: becomes xk1_n of the next (older) step
+        }
+        if (on) {
+          double pr[EM];
+          rts_load_row<E, EM>(Pk, pr);
+#pragma unroll
+          for (int j = 0; j < EM; j++) C[c * EM + j] += pr[j];                   // row c of Pk_n = Pk_k + D: Pk1_n of the next (older) step
+        }
+        wave_lds_sync();
+        continue;
+      }
       // ---- E. Cholesky of Pk1_k, left-looking: lane c owns row c in registers; pivot row j (final since column j - 1) is
       // broadcast from LDS and every lane forms its own entry AND the pivot redundantly -- no publish / wait per column -------
       static_for<EM>([&](auto J) {

@@ -56,3 +56,40 @@ def _poison_lds(request):
       ctypes.CDLL(lib).lds_poison(None)
       torch.cuda.synchronize()
   yield
+
+
+def fullpiv_kernel(M):
+  """Basis of the right null space of M (rows x cols) the way Eigen's FullPivLU::kernel() builds it (ekf_c.c:71 calls it on Hea^T):
+  Gaussian elimination with full pivoting, P M Q = L U, U = [U1 U2], kernel vectors Q [-U1^-1 U2 ; I].  Pivot search column by column,
+  first maximum (Eigen's maxCoeff visitor); all min(rows, cols) steps unless the corner is exactly zero; a pivot counts towards the rank
+  when it exceeds epsilon x min(rows, cols) x the largest pivot met.  oracle/ekf_oracle.c:fullpiv_kernel and rn::nullspace_residual
+  (rednose_amd/codegen/lower.py) are the same restatement in C / HIP."""
+  import numpy as np
+  U = np.array(M, dtype=np.float64)
+  rows, cols = U.shape
+  perm = list(range(cols))
+  piv = []
+  for k in range(min(rows, cols)):
+    sub = np.abs(U[k:, k:])
+    pc, pr = np.unravel_index(np.argmax(sub.T), sub.T.shape)      # column-major scan, first maximum
+    best = sub[pr, pc]
+    pr, pc = pr + k, pc + k
+    if best == 0.0:
+      break
+    piv.append(best)
+    U[[k, pr]] = U[[pr, k]]
+    U[:, [k, pc]] = U[:, [pc, k]]
+    perm[k], perm[pc] = perm[pc], perm[k]
+    for i in range(k + 1, rows):
+      U[i, k:] -= U[i, k] / U[k, k] * U[k, k:]
+  rank = 0
+  while rank < len(piv) and piv[rank] > 2.220446049250313e-16 * min(rows, cols) * max(piv):
+    rank += 1
+  nk = cols - rank
+  ker = np.zeros((cols, nk))
+  for c in range(nk):
+    v = np.linalg.solve(np.triu(U[:rank, :rank]), -U[:rank, rank + c])
+    for i in range(rank):
+      ker[perm[i], c] = v[i]
+    ker[perm[rank + c], c] = 1.0
+  return ker

@@ -112,6 +112,62 @@ static int run_robustness(const char* dir) {
   return 0;
 }
 
+// Multi mode: n observations per call (EKFSym::predict_and_update_batch with vectors of z / R, ekf_sym.cc:83-117,158-194) on the 9-state
+// model with the shared-timeline ring.  The log is one filter's of tests/golden/multi_obs.npz part A -- calls of 1-3 observations with a
+// different noise matrix each, one LATE multi-observation call that rewinds over multi-observation checkpoints -- fed to a batch of
+// identical filters.  File: Q (81), x0 (9), P0 (81), R of kinds 1 / 2 / 3 (9 + 1 + 9), then per call "t kind nobs" and per
+// observation Z values + the noise scale.  Prints per call: applied, filter time, x of filter 0 and of the last filter, and the
+// residuals of filter 0 (nobs x Z).
+static int run_multi(const char* dir, const char* stream, int64_t n) {
+  std::ifstream in(stream);
+  std::vector<double> Q(81), x0(9), P0(81), R1(9), R2(1), R3(9);
+  for (auto* v : {&Q, &x0, &P0, &R1, &R2, &R3}) for (double& e : *v) in >> e;
+  rednose_amd::EKFSymBatch kf(dir, "kinematic9", Q, x0, P0, n, false, nullptr, 64, 1.0);
+  const int NM = 3;
+  std::vector<double*> zbuf(NM, nullptr);
+  uint8_t* fl_dev = nullptr;
+  for (auto& p : zbuf) if (hipMalloc((void**)&p, sizeof(double) * n * 3 + 16) != hipSuccess) return 3;
+  if (hipMalloc((void**)&fl_dev, NM * n) != hipSuccess) return 3;
+  double t;
+  int kind, nobs;
+  while (in >> t >> kind >> nobs) {
+    const int Z = kf.zdim(kind);
+    const std::vector<double>& Rk = kind == 1 ? R1 : (kind == 2 ? R2 : R3);
+    std::vector<std::vector<double>> Rs(nobs);
+    std::vector<double*> zs;
+    std::vector<const double*> Rp;
+    for (int i = 0; i < nobs; i++) {
+      std::vector<double> zi(Z), host((size_t)n * Z);
+      for (double& e : zi) in >> e;
+      double scale;
+      in >> scale;
+      for (int64_t f = 0; f < n; f++) std::copy(zi.begin(), zi.end(), host.begin() + f * Z);
+      if (hipMemcpy(zbuf[i], host.data(), sizeof(double) * n * Z, hipMemcpyHostToDevice) != hipSuccess) return 3;
+      Rs[i] = Rk;
+      for (double& e : Rs[i]) e *= scale;
+      zs.push_back(zbuf[i]);
+      Rp.push_back(Rs[i].data());
+    }
+    const bool applied = kf.predict_and_update_batch(t, kind, zs, Rp, fl_dev);
+    kf.synchronize();
+    const std::vector<double> x = kf.state();
+    std::printf("%d %.17g", applied ? 1 : 0, kf.get_filter_time());
+    for (int64_t f : {(int64_t)0, n - 1}) for (int j = 0; j < 9; j++) std::printf(" %.17g", x[f * 9 + j]);
+    for (int i = 0; i < nobs; i++) {
+      std::vector<double> y(Z);
+      if (hipMemcpy(y.data(), zbuf[i], sizeof(double) * Z, hipMemcpyDeviceToHost) != hipSuccess) return 3;
+      for (double e : y) std::printf(" %.17g", e);
+    }
+    std::printf("\n");
+  }
+  bool threw = false;      // n = 0 observations / mismatched vectors are refused (the reference asserts, ekf_sym.cc:159-160)
+  try { kf.predict_and_update_batch(1e3, 1, std::vector<double*>{zbuf[0], zbuf[1]}, std::vector<const double*>{R1.data()}); } catch (const std::runtime_error&) { threw = true; }
+  std::printf("mismatch_threw %d\n", threw ? 1 : 0);
+  for (auto p : zbuf) (void)hipFree(p);
+  (void)hipFree(fl_dev);
+  return 0;
+}
+
 // Globals mode: set_global / get_extra_routine on a model generated with global_vars (tests/test_global_vars.py's gv_runtime)
 static int run_globals(const char* dir) {
   rednose_amd::EKFSymBatch kf(dir, "gv_runtime", {0.01, 0.0, 0.0, 4.0}, {0.5, 0.3}, {1.0, 0.0, 0.0, 1.0}, 3);
@@ -138,6 +194,7 @@ int main(int argc, char** argv) {
     if (argc >= 5 && std::string(argv[4]) == "globals") return run_globals(argv[1]);
     if (argc >= 5 && std::string(argv[4]) == "robustness") return run_robustness(argv[1]);
     if (argc >= 5 && std::string(argv[4]) == "timelines") return run_timelines(argv[1], argv[2], n);
+    if (argc >= 5 && std::string(argv[4]) == "multi") return run_multi(argv[1], argv[2], n);
     rednose_amd::EKFSymBatch kf(argv[1], "kinematic", {0.1 * 0.1, 0.0, 0.0, 2.0 * 2.0}, {0.5, 0.0}, {1.0, 0.0, 0.0, 1.0}, n);
     std::ifstream in(argv[2]);
     std::vector<double> zs(n);

@@ -165,6 +165,25 @@ def test_dpp_hazard_detector_on_a_synthetic_listing():
   assert not rb.dpp_hazards(other_kernel)
 
 
+def test_compiled_python_binding_builds_and_fails_loudly_without_a_device(gen_dir):
+  """rednose_amd/helpers/_ekf_sym_batch*.so -- pybind11 over the C++ orchestrator EKFSymBatch, the analogue of the reference's Cython module
+  (rednose/helpers/ekf_sym_pyx.pyx) -- builds in-tree with hipcc, imports without a GPU, exposes the EKF_sym_pyx surface, and constructing a
+  filter without a device raises (no CPU path behind it)."""
+  from rednose_amd import build as rb
+  path = rb.build_python_binding()
+  assert os.path.exists(path) and os.path.dirname(path).endswith(os.path.join("rednose_amd", "helpers"))
+  from rednose_amd.helpers import _ekf_sym_batch as m
+  from rednose_amd.helpers.ekf_sym_pyx import EKF_sym_pyx
+  for meth in ("init_state", "state", "covs", "set_filter_time", "get_filter_time", "set_global", "reset_rewind", "predict", "predict_and_update_batch"):
+    assert hasattr(m.EKFSymBatch, meth) and hasattr(EKF_sym_pyx, meth), meth          # ekf_sym_pyx.pyx:85-179
+  for meth in ("augment", "get_augment_times", "rts_smooth", "maha_test"):            # :181-192 -- NotImplementedError there and here
+    assert hasattr(EKF_sym_pyx, meth)
+  import torch
+  if not torch.cuda.is_available():
+    with pytest.raises(RuntimeError, match="device|hipMalloc"):
+      EKF_sym_pyx(gen_dir, "kinematic", np.diag([0.01, 4.0]), np.array([0.5, 0.0]), np.eye(2), 2, 2)
+
+
 def test_loader_backends(gen_dir):
   """load_code binds the same prototypes through either backend: cffi when importable (what the reference uses), ctypes
   otherwise or on request.  BatchedEKF always asks for ctypes (it passes ctypes pointers); a forced "cffi" without cffi

@@ -98,37 +98,7 @@ def test_both_kinds_vs_oracle_strict(env, n):
         assert np.array_equal(yh[:, Zp:], z[:, Zp:]), what + ": the last 3 entries of z pass through (y has Z - 3 rows, ekf_c.c:120)"
 
 
-def _fullpiv_kernel(M):
-  """Basis of the right null space of M (rows x cols) the way Eigen's FullPivLU::kernel() builds it (ekf_c.c:71 calls it on Hea^T):
-  Gaussian elimination with full pivoting, P M Q = L U, U = [U1 U2], kernel vectors Q [-U1^-1 U2 ; I] (oracle/ekf_oracle.c
-  fullpiv_kernel is the same restatement in C)."""
-  U = np.array(M, dtype=np.float64)
-  rows, cols = U.shape
-  perm = list(range(cols))
-  rank, maxpiv = 0, 0.0
-  for k in range(min(rows, cols)):
-    sub = np.abs(U[k:, k:])
-    pr, pc = np.unravel_index(np.argmax(sub), sub.shape)
-    best = sub[pr, pc]
-    pr, pc = pr + k, pc + k
-    if k == 0:
-      maxpiv = best
-    if best <= 2.220446049250313e-16 * max(rows, cols) * maxpiv:
-      break
-    U[[k, pr]] = U[[pr, k]]
-    U[:, [k, pc]] = U[:, [pc, k]]
-    perm[k], perm[pc] = perm[pc], perm[k]
-    for i in range(k + 1, rows):
-      U[i, k:] -= U[i, k] / U[k, k] * U[k, k:]
-    rank += 1
-  nk = cols - rank
-  ker = np.zeros((cols, nk))
-  for c in range(nk):
-    v = np.linalg.solve(np.triu(U[:rank, :rank]), -U[:rank, rank + c])
-    for i in range(rank):
-      ker[perm[i], c] = v[i]
-    ker[perm[rank + c], c] = 1.0
-  return ker
+from conftest import fullpiv_kernel as _fullpiv_kernel      # noqa: E402  (Eigen's FullPivLU::kernel() restated in numpy)
 
 
 def test_stream_with_window_shifts_vs_reference_numpy(env):

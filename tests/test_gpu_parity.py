@@ -73,15 +73,50 @@ def test_stream_fast_path_known_answers(gen_dir, torch_cuda):
 
 def test_pyx_named_class_is_the_same_orchestrator(gen_dir, torch_cuda):
   """Models written for the reference construct `EKF_sym_pyx(gen_dir, name, Q, x0, P0, dim, dim_err, ...)`
-  (/root/reference/examples/kinematic_kf.py:69, ekf_sym_pyx.pyx:87-90)."""
-  from rednose_amd.helpers.ekf_sym_pyx import EKF_sym_pyx
+  (/root/reference/examples/kinematic_kf.py:69, ekf_sym_pyx.pyx:87-90): here a COMPILED binding (pybind11) of the C++ orchestrator
+  EKFSymBatch, like the reference's Cython class over its C++ EKFSym.  The known-answer stream of test_kinematic_kf.py with the
+  reference's shapes (one filter), the swapped-sample stream of test_compare.py through its checkpoint ring, the Estimate 9-tuple
+  against the Python orchestrator's, and the methods the reference's class leaves unimplemented."""
+  from rednose_amd.helpers.ekf_sym_pyx import EKF_sym_pyx, _module
+  from rednose_amd.helpers.ekf_sym import EKF_sym
+  assert _module().__file__.endswith(".so")
   g = golden("kinematic_stream.npz")
-  f = EKF_sym_pyx(gen_dir, "kinematic", np.diag([0.1**2, 2.0**2]), np.array([0.5, 0.0]), np.eye(2), 2, 2)
-  for t, meas in zip(g["ts"][:50], g["zs"][:50]):
-    est = f.predict_and_update_batch(t, 1, np.array([[meas]]), np.array([[[0.1**2]]]))
-  assert len(est) == 9
-  assert_close(f.state(), g["xs"][49], rtol=1e-10, floor=1e-12)
-  assert_close(f.covs().reshape(-1), g["Ps"][49].reshape(-1), rtol=1e-10, floor=1e-12)
+  Q, x0, P0, R = np.diag([0.1**2, 2.0**2]), np.array([0.5, 0.0]), np.eye(2), np.array([[[0.1**2]]])
+  f = EKF_sym_pyx(gen_dir, "kinematic", Q, x0, P0, 2, 2)
+  p = EKF_sym(gen_dir, "kinematic", Q, x0, P0, 2, 2)
+  assert f.get_filter_time() is None
+  for i, (t, meas) in enumerate(zip(g["ts"], g["zs"])):
+    est = f.predict_and_update_batch(t, 1, np.array([[meas]]), R)
+    if i < 40:
+      ref = p.predict_and_update_batch(t, 1, np.array([[meas]]), R)
+      assert len(est) == 9 and est[4] == ref[4] and est[5] == ref[5] and len(est[6]) == 1
+      for a, b in ((est[0], ref[0]), (est[1], ref[1]), (est[2], ref[2]), (est[3], ref[3]), (est[6][0], ref[6][0])):
+        assert np.shape(a) == np.shape(np.asarray(b)) or np.size(a) == np.size(b)
+        assert_close(np.ravel(a), np.ravel(b), rtol=1e-11, floor=1e-13, what=f"Estimate of sample {i}")
+    if i == 49:
+      assert f.state().shape == (2,) and f.covs().shape == (2, 2)
+      assert_close(f.state(), g["xs"][49], rtol=1e-10, floor=1e-12)
+      assert_close(f.covs().reshape(-1), g["Ps"][49].reshape(-1), rtol=1e-10, floor=1e-12)
+  x, std = f.state(), np.sqrt(np.diag(f.covs()))
+  for got, want in zip((x[0], std[0], x[1], std[1]), g["literals"]):
+    assert round(abs(got - want), 7) == 0                                # the reference's assertAlmostEqual (test_kinematic_kf.py:52-55)
+  assert f.get_filter_time() == pytest.approx(float(g["ts"][-1]))
+  # late observations through the ring (test_compare.py:103-120), a batch of three filters, and one that is too old
+  c = golden("compare_rewind.npz")
+  b = EKF_sym_pyx(gen_dir, "kinematic", Q, x0, P0, 2, 2, batch=3)
+  for t, meas in zip(c["ts"], c["zs"]):
+    assert b.predict_and_update_batch(float(t), 1, [np.array([meas])], R, estimate=False) is True
+  assert b.state().shape == (3, 2)
+  assert_close(b.state(), np.tile(c["xs"][-1], (3, 1)), rtol=1e-9, floor=1e-11, what="after the swapped-sample stream")
+  assert b.predict_and_update_batch(float(c["ts"][-1]) - 5.0, 1, [np.array([0.0])], R) is None
+  for call in (f.augment, f.get_augment_times, lambda: f.rts_smooth([]), lambda: f.maha_test(None, None, 1, None, None)):
+    with pytest.raises(NotImplementedError):
+      call()
+  f.reset_rewind()
+  f.init_state(x0, P0, None)
+  f.predict(1.0)
+  f.predict(1.5)
+  assert f.get_filter_time() == 1.5 and abs(f.state()[0] - 0.5) < 1e-15
 
 
 def test_scalar_sympy_routines_on_gpu(gen_dir, torch_cuda):

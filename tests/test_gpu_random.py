@@ -213,48 +213,65 @@ def test_trace_vs_step_path_many_shapes(dim):
       assert dx < 1e-9 and dP < 1e-9, f"{M.name} rep {rep} n={n} T={T} t={t}: |dx|={dx:.3e} |dP|={dP:.3e}"
 
 
-@pytest.mark.parametrize("dim", [8, 13, 24, 32])
-def test_smoother_many_shapes(dim):
-  """The smoother against the numpy restatement over several random batch sizes / trace lengths (every filter, every step)."""
+@pytest.mark.parametrize("cls", ["Random3Kalman", "Random5Kalman", "Random8Kalman", "RandomWideObs10Kalman", "Random11Kalman", "Random13Kalman", "Random17Kalman",
+                                 "Random24Kalman", "Random32Kalman", "Random40Kalman", "Random56Kalman", "RandomAffine5Kalman", "RandomAffine11Kalman"])
+def test_smoother_many_shapes(cls):
+  """The smoother against the numpy restatement of ekf_sym.py:651-690 over several random batch sizes / trace lengths -- every filter,
+  every step, states AND covariances -- for every size class the selection logic routes to each kernel (tests/test_host_logic.py lists
+  the map): rn::k_rts (3, 5), k_rts4 (8 .. 17, odd counts included), rn::k_rts_group (24 .. 56).  A third of the time differences are exactly
+  0: models whose predict(0) is the identity take the identity-gain path there (Ck = I; np.linalg.solve gives I to rounding), the two
+  affine models (predict(0) != identity) must keep the full step.  The covariance recursion is resynchronised every step on the
+  kernel's own Ps[k + 1], so the bound is per step."""
   import torch
   from examples import ensure_generated
   import examples.random_kf as R
   from oracle_lib import OracleLib
   from rednose_amd.helpers.ekf_sym import BatchedEKF
-  M = getattr(R, f"Random{dim}Kalman")
+  M = getattr(R, cls)
+  dim = int(M.initial_x.shape[0])
   gen = ensure_generated([M.name]); o = OracleLib(M.name)
   rng = np.random.default_rng(5)
-  Rs = {k: M.obs_noise[k] for k in (1, 2, 3)}
-  for rep in range(6):
+  Rs = {k: M.obs_noise[k] for k in M.obs_noise}
+  kset = sorted(Rs)
+  zmax = max(np.atleast_2d(r_).shape[0] for r_ in Rs.values())
+  sym = lambda a: np.tril(a) + np.tril(a, -1).T      # noqa: E731  (the contract of batch_rts: lower triangles are read)
+  for rep in range(4 if dim > 32 else 6):
     n = int(rng.integers(1, 90)); T = int(rng.integers(3, 22))
     x0 = M.initial_x[None] + rng.normal(size=(n, dim)) * 0.3
     A = rng.normal(size=(n, dim, dim)) * 0.2
     P0 = np.diag(M.initial_P_diag)[None] + A @ A.transpose(0, 2, 1)
-    kinds = rng.integers(1, 4, size=T).astype(np.int32)
-    ts = np.cumsum(rng.uniform(0.005, 0.03, size=T))
-    zs = rng.normal(size=(T, n, 3)) * 0.5
+    kinds = rng.choice(kset, size=T).astype(np.int32)
+    dts = rng.uniform(0.005, 0.03, size=T)
+    dts[rng.random(T) < 0.35] = 0.0
+    ts = np.cumsum(dts)
+    zs = rng.normal(size=(T, n, zmax)) * 0.5
     f = BatchedEKF(gen, M.name, M.Q, M.initial_x, np.diag(M.initial_P_diag), dim, dim, batch=n); f.init_state(x0, P0, 0.0)
     _, tx, tP, _ = f.run(ts, kinds, zs.copy(), Rs, trace=True)
     xs, Ps = f.rts_smooth(tx, tP, ts)
     torch.cuda.synchronize()
     xs, Ps = xs.cpu().numpy(), Ps.cpu().numpy(); X, P = tx.cpu().numpy(), tP.cpu().numpy()
     assert np.isfinite(xs).all() and np.isfinite(Ps).all()
-    worst = 0.0
-    for j in range(n):
+    worst = worstP = 0.0
+    for j in range(n if dim <= 32 else min(n, 12)):
       x1n = None
       for k in range(T - 2, -1, -1):
         dt = ts[k + 1] - ts[k]
         x1k = np.zeros(dim); Fk = np.zeros(dim * dim)
         o.call("f_fun", X[k, j].copy(), float(dt), x1k); o.call("F_fun", X[k, j].copy(), float(dt), Fk)
         Fk = Fk.reshape(dim, dim)
-        P1k = Fk @ P[k, j] @ Fk.T + dt * M.Q
+        Pkk = sym(P[k, j])
+        P1k = Fk @ Pkk @ Fk.T + dt * M.Q
         if k == T - 2:
           x1n = x1k.copy()
-        Ck = np.linalg.solve(P1k, Fk @ P[k, j].T).T
+          worstP = max(worstP, np.abs(Ps[T - 1, j] - P1k).max() / np.abs(P1k).max())
+        Ck = np.linalg.solve(P1k, Fk @ Pkk.T).T
         xkn = X[k, j] + Ck @ (x1n - x1k)
         worst = max(worst, np.abs(xs[k, j] - xkn).max() / max(1.0, np.abs(xkn).max()))
+        Pkn = P[k, j] + Ck @ (sym(Ps[k + 1, j]) - P1k) @ Ck.T
+        worstP = max(worstP, np.abs(Ps[k, j] - Pkn).max() / np.abs(Pkn).max())
         x1n = xs[k, j].copy()
     assert worst < 1e-7, f"{M.name} rep {rep} n={n} T={T}: smoothed states off by {worst:.2e} (relative)"
+    assert worstP < 1e-7, f"{M.name} rep {rep} n={n} T={T}: smoothed covariances off by {worstP:.2e} of the matrix maximum"
 
 
 @pytest.mark.parametrize("dim", [5, 11])

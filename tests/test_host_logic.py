@@ -7,6 +7,7 @@ be exercised without a GPU and compared with trajectories produced by the refere
 (tests/golden/, oracle/make_golden.py).  The product path (generated HIP library) is covered by -m gpu tests.
 """
 import os
+import re
 
 import numpy as np
 import pytest
@@ -243,6 +244,101 @@ def test_cffi_branch_of_load_code_runs_the_known_answers(monkeypatch):
     sys.modules.pop("cffi", None)
 
 
+@pytest.mark.skipif(not os.path.exists("/root/reference/rednose/helpers/ekf_sym.py"), reason="needs the reference tree (this container only)")
+def test_reference_class_binds_the_hip_libraries():
+  """The drop-in claim of the boundary, as far as it can be taken on ONE machine: the reference's OWN, unmodified Python loader and
+  orchestrator (/root/reference/rednose/helpers/__init__.py:18-31 load_code, ekf_sym.py:258-349 EKF_sym.__init__) pointed at the HIP
+  builds generated/libkinematic.so and generated/liblive.so -- header parsed by its `void ` filter, library dlopen'ed, observation kinds
+  discovered by scanning dir(lib) for {name}_h_<int> / {name}_He_<int>, every function pointer bound.  Its compute calls then reach the
+  HIP entry points: with no device here they record an error in the library instead of touching x / P (checked), on the GPU box the same
+  symbols run the kernels (rednose_amd's twin of the class drives them there: the Python reference may not travel to the GPU box in any
+  form, and this container has no GPU).  Runs in a subprocess: `rednose` and the cffi stand-in stay out of this process."""
+  import subprocess
+  import sys
+  from conftest import REPO
+  from examples import ensure_generated
+  gen = ensure_generated(["kinematic", "live"])
+  code = r"""
+import ctypes, sys
+import numpy as np
+sys.path[:0] = [sys.argv[2], "/root/reference"]
+from rednose.helpers.ekf_sym import EKF_sym            # the reference's class, unmodified
+from rednose.helpers import load_code                   # ... and its loader
+gen = sys.argv[1]
+f = EKF_sym(gen, "kinematic", np.diag([0.01, 4.0]), np.array([0.5, 0.0]), np.eye(2), 2, 2)
+assert sorted(f.hs.keys()) == [1] and sorted(f.Hs.keys()) == [1] and f.feature_track_kinds == [], (f.hs.keys(), f.feature_track_kinds)
+x0, P0 = f.state().copy(), f.covs().copy()
+f.predict_and_update_batch(0.0, 1, np.array([[0.3]]), np.array([[[0.01]]]))       # reaches kinematic_predict / kinematic_update_1 of the HIP build
+dll = ctypes.CDLL(gen + "/libkinematic.so")
+dll.kinematic_last_error_string.restype = ctypes.c_char_p
+print("kinematic last_error", dll.kinematic_last_error(), dll.kinematic_last_error_string().decode())
+print("kinematic untouched", int(np.array_equal(f.state(), x0) and np.array_equal(f.covs(), P0)))
+Q = np.eye(22) * 1e-3
+x = np.zeros(23); x[3] = 1.0
+g = EKF_sym(gen, "live", Q, x, np.eye(22), 23, 22)
+print("live kinds", sorted(g.hs.keys()), "updates", sorted(g._updates.keys()) if hasattr(g, "_updates") else "-")
+ffi, lib = load_code(gen, "live")
+names = [n for n in dir(lib) if n.startswith("live_")]
+print("live symbols", len(names), int("live_predict" in names and "live_update_12" in names and "live_H_mod_fun" in names and "live_err_fun" in names))
+"""
+  res = subprocess.run([sys.executable, "-c", code, gen, os.path.join(REPO, "oracle", "cffi_shim")], capture_output=True, text=True, timeout=600,
+                       env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
+  assert res.returncode == 0, res.stderr[-3000:]
+  lines = res.stdout.strip().split("\n")
+  err = [ln for ln in lines if ln.startswith("kinematic last_error")][0].split(" ", 3)
+  assert int(err[2]) != 0, "a compute call without a device must leave an error in the library"
+  assert "kinematic untouched 1" in lines, "a failed call must not touch x / P"
+  assert [ln for ln in lines if ln.startswith("live kinds")][0].startswith("live kinds [3, 4, 9, 10, 12, 13, 14, 19]")
+  sym = [ln for ln in lines if ln.startswith("live symbols")][0].split()
+  assert int(sym[2]) >= 8 * 3 + 6 and sym[3] == "1"
+
+
+def test_nullspace_residual_follows_eigens_pivot_order_and_rank_decision(tmp_path):
+  """rn::nullspace_residual (codegen/lower.py: the MSCKF residual in the reference's basis, A = Hea^T.fullPivLu().kernel(), ekf_c.c:71-73)
+  compiled for the host against the numpy restatement of Eigen's FullPivLU (tests/conftest.py): random Jacobians, Jacobians with TIED
+  entries (equal magnitudes in different rows and columns -- which one becomes the pivot decides the basis: Eigen's visitor walks the
+  corner column by column and keeps the first maximum), a Jacobian whose LATER pivot exceeds the first (the rank threshold scales with the
+  largest pivot met, not the first), and rank-deficient ones (returns false, residual zeroed)."""
+  import ctypes
+  import subprocess
+  from conftest import fullpiv_kernel
+  from rednose_amd.codegen.lower import NULLSPACE_RESIDUAL
+  src = tmp_path / "ns.cpp"
+  src.write_text("#include <cmath>\n#define __device__\n#define __forceinline__ inline\nusing std::fabs;\n" + NULLSPACE_RESIDUAL + """
+extern "C" int ns63(const double* Hea, const double* y, double* out) {
+  double H[18], yy[6], o[3];
+  for (int i = 0; i < 18; i++) H[i] = Hea[i];
+  for (int i = 0; i < 6; i++) yy[i] = y[i];
+  const bool ok = rn::nullspace_residual<6, 3>(H, yy, o);
+  for (int i = 0; i < 3; i++) out[i] = o[i];
+  return ok ? 1 : 0;
+}
+""", encoding="utf-8")
+  lib = tmp_path / "libns.so"
+  subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas", str(src), "-o", str(lib)], check=True)
+  fn = ctypes.CDLL(str(lib)).ns63
+  dp = ctypes.POINTER(ctypes.c_double)
+  fn.argtypes = [dp, dp, dp]
+  rng = np.random.default_rng(11)
+  cases = [rng.normal(size=(6, 3)) for _ in range(40)]
+  tied = np.array([[2.0, -2.0, 1.0], [2.0, 1.0, -2.0], [-2.0, 2.0, 2.0], [1.0, 2.0, 0.5], [0.5, -1.0, 2.0], [2.0, 2.0, 2.0]])
+  cases += [tied, tied[::-1].copy(), tied[:, ::-1].copy(), np.sign(rng.normal(size=(6, 3))) * 3.0]
+  grow = np.array([[1.0, 1.0, 0.0], [1.0, -1.0, 0.0], [0.0, 0.0, 1e-3], [0.3, 0.2, 0.0], [0.1, 0.0, 0.0], [0.0, 0.1, 0.0]])      # second pivot (2) > first (1)
+  cases.append(grow)
+  for Hea in cases:
+    y = rng.normal(size=6)
+    Aref = fullpiv_kernel(Hea.T)
+    out = np.zeros(3)
+    ok = fn(np.ascontiguousarray(Hea).ctypes.data_as(dp), y.ctypes.data_as(dp), out.ctypes.data_as(dp))
+    assert ok == 1 and Aref.shape == (6, 3)
+    assert_close(out, Aref.T @ y, rtol=1e-12, floor=1e-14, what="residual in Eigen's kernel basis")
+  deficient = [np.tile(rng.normal(size=(2, 3)), (3, 1)), np.zeros((6, 3)), np.outer(rng.normal(size=6), rng.normal(size=3))]
+  for Hea in deficient:
+    out = np.ones(3)
+    assert fn(np.ascontiguousarray(Hea).ctypes.data_as(dp), rng.normal(size=6).ctypes.data_as(dp), out.ctypes.data_as(dp)) == 0
+    assert not out.any() and fullpiv_kernel(Hea.T).shape[1] > 3
+
+
 def test_lowered_sin_cos_pairs_and_their_accuracy(tmp_path):
   """rednose_amd/codegen/lower.py prints sin(a) / cos(a) through ONE rn::sincos_fast per distinct argument; the function itself (pure
   IEEE arithmetic: the host build computes what the device computes) against libm's long double routines over 2e6 arguments up to
@@ -365,26 +461,53 @@ def test_bench_prints_counter_traffic_only_for_the_build_it_was_taken_on(tmp_pat
 
 
 def test_register_broadcast_smoother_is_chosen_where_it_applies_and_falls_back():
-  """emit_rts4.applicable: ordinary lane-group models with an even number of error states whose four images fit 20 KB of LDS; the fallback
-  `no_rts4` (gen_code takes it when k_rts4 does not fit 256 registers without scratch) emits the fused run's layout (k_rts3) instead, and
-  libraries that contain k_rts4 ask for the exact register-pressure trackers (build.model_flags)."""
+  """Which smoother kernel a model's batch_rts launches -- the whole map: lane-per-filter models (<= 7 error states) rn::k_rts; ordinary
+  lane-group models whose four images fit 20 KB of LDS (8 .. 22 error states, odd counts included) k_rts4 (emit_rts4); MSCKF models, larger
+  models and dense models whose F does not fit the slot rn::k_rts_group, which is also the fallback `no_rts4` (gen_code takes it when k_rts4
+  does not fit 256 registers without scratch, or when one of its DPP reads follows the write of its source too closely); libraries that contain
+  k_rts4 ask for the exact register-pressure trackers (build.model_flags).  (k_rts3, the smoother in the fused run's layout, is gone.)"""
   import examples.random_kf as R
   from examples.kinematic9_kf import Kinematic9Kalman
+  from examples.kinematic6_kf import Kinematic6Kalman
+  from examples.live_kf import LiveKalman
+  from examples.feature_kf import FeatureKalman, WideFeatureKalman
   from rednose_amd import build as rb
   from rednose_amd.codegen import emit, emit_rts4
   from rednose_amd.codegen.spec import build_spec
+
+  def kernel_of(model):
+    spec = build_spec(**model.model())
+    _, text = emit.emit(spec)
+    m = re.search(r"int \w+_batch_rts\(.*?\n}", text, flags=re.S)
+    assert m, model
+    launched = re.search(r"hipLaunchKernelGGL\((?:rn::)?(k_rts\w*)", m.group(0)).group(1)
+    assert ("void k_rts4(" in text) == (launched == "k_rts4") and "k_rts3" not in text
+    assert rb.model_flags(text) == (rb.RTS4_FLAGS if launched == "k_rts4" else [])
+    return launched, spec
+  expected = {R.Random3Kalman: "k_rts", R.Random5Kalman: "k_rts", Kinematic6Kalman: "k_rts",
+              R.Random8Kalman: "k_rts4", Kinematic9Kalman: "k_rts4", R.RandomWideObs10Kalman: "k_rts4", R.Random11Kalman: "k_rts4", R.Random13Kalman: "k_rts4",
+              R.Random17Kalman: "k_rts4", LiveKalman: "k_rts4",
+              R.Random24Kalman: "k_rts_group", R.Random32Kalman: "k_rts_group", R.Random40Kalman: "k_rts_group", R.Random56Kalman: "k_rts_group",
+              FeatureKalman: "k_rts_group", WideFeatureKalman: "k_rts_group"}
+  for model, want in expected.items():
+    got, spec = kernel_of(model)
+    assert got == want, (model.__name__, spec.dim_err, got, want)
+    assert emit_rts4.applicable(spec) == (want == "k_rts4")
   s8 = build_spec(**R.Random8Kalman.model())
-  assert emit_rts4.applicable(s8) and emit_rts4.rows_per_lane(s8) == 1
+  assert emit_rts4.rows_per_lane(s8) == 1 and emit_rts4.rows_per_lane(build_spec(**R.Random17Kalman.model())) == 2
   _, text = emit.emit(s8)
-  assert "void k_rts4(" in text and "void k_rts3(" not in text and "hipLaunchKernelGGL(k_rts4," in text
-  assert "v_fmac_f64_dpp" in text and "row_newbcast" in text
-  assert rb.model_flags(text) == rb.RTS4_FLAGS
-  _, text3 = emit.emit(s8, fallbacks=("no_rts4",))
-  assert "void k_rts3(" in text3 and "void k_rts4(" not in text3 and rb.model_flags(text3) == []
-  _, textg = emit.emit(s8, fallbacks=("no_rts4", "no_rts3"))
-  assert "k_rts_group<RtsModel>" in textg and "void k_rts3(" not in textg
-  assert not emit_rts4.applicable(build_spec(**Kinematic9Kalman.model()))        # odd number of error states
-  assert not emit_rts4.applicable(build_spec(**R.Random24Kalman.model()))        # four 24 x 24 images do not fit 20 KB
+  assert "v_fmac_f64_dpp" in text and "row_newbcast" in text and "RN4_SETTLE();" in text
+  assert "if (dt == 0.0 && !first)" in text and "static constexpr bool ID0 = true;" in text      # the identity-gain path of dt = 0 steps
+  _, textg = emit.emit(s8, fallbacks=("no_rts4",))
+  assert "k_rts_group<RtsModel>" in textg and "void k_rts4(" not in textg and rb.model_flags(textg) == []
+  os.environ["RN_TUNE"] = "rts_dt0=0"
+  try:
+    _, text0 = emit.emit(s8)
+  finally:
+    del os.environ["RN_TUNE"]
+  assert "if (dt == 0.0 && !first)" not in text0 and "static constexpr bool ID0 = false;" in text0       # the knob keeps the full solve on every step
+  _, texta = emit.emit(build_spec(**R.RandomAffine11Kalman.model()))
+  assert "void k_rts4(" in texta and "if (dt == 0.0 && !first)" not in texta and "static constexpr bool ID0 = false;" in texta      # predict(0) is not the identity for this model
 
 
 def test_two_wavefront_fused_run_is_chosen_where_it_applies_and_falls_back():
