@@ -299,14 +299,10 @@ class EKFSymBatch {
     // flag bit 5 (include/rednose_amd_filter.h): "observation too old for this filter's ring, ignored" -- on top of bit 4, which
     // the kernel set for every filter that was not active in the launch
     if (flags_dev != nullptr && n_ignored > 0) {
-      // one round trip of the N flag bytes (a 1-byte copy per ignored filter from pageable memory was N synchronous copies when a
-      // whole batch dropped an observation); the staging vector is a member: it outlives the asynchronous upload
-      s.flag_stage.resize((size_t)n_);
-      hip(hipMemcpyAsync(s.flag_stage.data(), flags_dev, (size_t)n_, hipMemcpyDeviceToHost, stream_), "flags down");
-      hip(hipStreamSynchronize(stream_), "flags down sync");
-      for (int64_t i = 0; i < n_; i++)
-        if (s.ignored[i]) s.flag_stage[(size_t)i] = 16 | 32;
-      hip(hipMemcpyAsync(flags_dev, s.flag_stage.data(), (size_t)n_, hipMemcpyHostToDevice, stream_), "flags up");
+      // only the mask of the ignored filters goes up (N bytes; `upload` waits for that one copy because its source is pageable host memory), and a
+      // small kernel sets their bytes on the stream: no download of the flags, the other filters' bytes are not rewritten
+      upload(s.act, s.ignored.data(), (size_t)n_);
+      check(sym<int (*)(uint8_t*, const uint8_t*, int, int64_t, void*)>("batch_flags_set")(flags_dev, s.act, 16 | 32, n_, stream_), "batch_flags_set");
     }
     return n_ignored;
   }
@@ -438,7 +434,6 @@ class EKFSymBatch {
     int zmax = 0, ead = 0;
     std::vector<double> ft;                  // filter time per filter (NaN: not started)
     std::vector<uint8_t> ignored;
-    std::vector<uint8_t> flag_stage;          // host image of the flag bytes while bit 5 is merged in
     std::vector<int32_t> head, len;          // circular ring position per filter
     std::vector<double> rt;                  // (K, N) checkpoint times
     std::vector<int32_t> rkind, rridx;       // (K, N) observation kind / index into rtable

@@ -190,7 +190,10 @@ extern "C" {
 #define RN_DECLARE_BATCH_RING(name)                                                                              \
   int RN_FN(name, batch_ring_copy)(double *ring, int64_t ring_stride, double *flat, int64_t flat_stride,          \
                                    int64_t rec, const int32_t *slot, const uint8_t *active, int64_t n,            \
-                                   int to_ring, void *stream);
+                                   int to_ring, void *stream);                                                    \
+  /* flags[i] = value for the filters with mask[i] != 0 (both n bytes, DEVICE): how an orchestrator marks the filters whose observation was  \
+   * too old for their ring (bits 4 | 5) on the stream, without moving the flag bytes through the host */          \
+  int RN_FN(name, batch_flags_set)(uint8_t *flags, const uint8_t *mask, int value, int64_t n, void *stream);
 
 #define RN_DECLARE_BATCH_KIND_MASKED(name, k)                                                                    \
   int RN_FN(name, batch_update_##k##_masked)(double *x, double *P, double *z, const double *R, int r_per_filter,  \

@@ -338,6 +338,14 @@ int {name}_batch_predict_update_{k.kind}{sfx}(double *x, double *P, const double
   return rn::OK;
 }}""")
   hdr.append(f"int {name}_batch_ring_copy(double *ring, int64_t ring_stride, double *flat, int64_t flat_stride, int64_t rec, const int32_t *slot, const uint8_t *active, int64_t n, int to_ring, void *stream);")
+  abi.append(f"""int {name}_batch_flags_set(uint8_t *flags, const uint8_t *mask, int value, int64_t n, void *stream) {{
+  RN_REQUIRE(n >= 0 && flags && mask, rn::ERR_ARG);
+  if (n == 0) return rn::OK;
+  hipLaunchKernelGGL(rn::k_flags_set, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, (hipStream_t)stream, flags, mask, value, n);
+  RN_HIP(hipGetLastError());
+  return rn::OK;
+}}""")
+  hdr.append(f"int {name}_batch_flags_set(uint8_t *flags, const uint8_t *mask, int value, int64_t n, void *stream);")
 
   if hasattr(fam_mod, "launch_maha"):
     for k in spec.kinds:

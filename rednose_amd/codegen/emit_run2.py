@@ -286,7 +286,7 @@ def update_fn(spec):
 
 
 def kernels(spec):
-  """Scalar phase functions against Run2Layout (suffix _r2, x as a register array), the matrix functions, k_run2."""
+  """Scalar phase functions against Run2Layout (suffix _r2; the state lives in the filter's slot), the matrix functions, k_run2."""
   from rednose_amd.codegen import emit_wide2 as w2
   scal_text, lay = w2.device_functions(spec, lay_cls=Run2Layout, sfx="_r2")
   return "\n".join([f"constexpr int SLOT_R2 = {lay.SLOT};   // two-wavefront fused run: doubles per scalar slot", "", scal_text, "",

@@ -203,8 +203,10 @@ def _in_registers(smat, name):
 WIDE_Z_LDS = 7      # observation dimension from which the general update keeps the innovation covariance in LDS (below: in registers)
 
 
-def wide_z(k):
-  return k.zdim >= WIDE_Z_LDS
+def wide_z(k, E):
+  """The LDS path of the innovation covariance (_wide_obs_update: lane z forms row z of S, so Z <= E lanes of the filter's group are needed);
+  a kind with more rows than the model has error states (Z > E) keeps the in-register general update whatever its size."""
+  return WIDE_Z_LDS <= k.zdim <= E
 
 
 def wide_s_doubles(k):
@@ -380,11 +382,9 @@ def _lean_update(k, Hs, lay, E, rows_in_regs=False):
   return b
 
 
-def device_functions(spec, lay_cls=None, sfx="", xreg=False):
+def device_functions(spec, lay_cls=None, sfx=""):
   """Phase functions of the three-phase kernels -> (text, slot layout).  With `lay_cls` / `sfx` only the scalar phases are
-  emitted, against another slot layout and under suffixed names (the fused run keeps a more compact slot, emit_wide3).
-  xreg=True: the state is not in the slot at all -- every function takes it as an array of the calling lane (emit_run2: the
-  scalar wavefront carries x in registers from step to step)."""
+  emitted, against another slot layout and under suffixed names (the fused runs keep more compact slots: emit_wide3, emit_run2)."""
   D, E = spec.dim_x, spec.dim_err
   INL = "__forceinline__" if tuning.current().wide_inline else "__noinline__"
   pst, pstruct, F, f_vars = _lowered_predict(spec)
@@ -418,13 +418,13 @@ def device_functions(spec, lay_cls=None, sfx="", xreg=False):
     b.append(f"x[{i}] = xn_{i};" if kind == 'expr' else f"x[{i}] = {float(val)!r};")
   b.append(normq)
   b.append(f"sl[{lay.OFF_DT}] = dt;")
-  xw = "xin[i]" if xreg else f"sl[{lay.OFF_X} + i]"      # where the new state goes
-  xarg = "double* xin" if xreg else "const double* xin"
+  xw = f"sl[{lay.OFF_X} + i]"      # where the new state goes
+  xarg = "const double* xin"
   b += ["#pragma unroll", f"for (int i = 0; i < {D}; i++) {xw} = x[i];"]
   out.append("\n".join(["__device__ {INL} void scal_predict" + sfx + f"({xarg}, const double dt, double* sl, const int norm_quats) {{"] + _ind(b) + ["}"]))
 
   b = [f"double x[{D}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = xin[i];", normq,
-       "#pragma unroll", f"for (int i = 0; i < {D}; i++) {xw} = x[i];"] + (["(void)sl;"] if xreg else [])
+       "#pragma unroll", f"for (int i = 0; i < {D}; i++) {xw} = x[i];"]
   out.append("\n".join(["__device__ {INL} void scal_keep" + sfx + f"({xarg}, double* sl, const int norm_quats) {{"] + _ind(b) + ["}"]))
 
   # ---- phase 1: scalars of each observation kind ---------------------------------------------------
@@ -433,7 +433,7 @@ def device_functions(spec, lay_cls=None, sfx="", xreg=False):
     Z = k.zdim
     EA = ea_dim(k)
     feat = k.He_sym is not None
-    xr_ = "xr[i]" if xreg else f"sl[{lay.OFF_X} + i]"
+    xr_ = f"sl[{lay.OFF_X} + i]"
     b = [f"double x[{D}], z[{Z}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = {xr_};",
          "#pragma unroll", f"for (int i = 0; i < {Z}; i++) z[i] = zin[i];"]
     if EA:
@@ -467,7 +467,7 @@ def device_functions(spec, lay_cls=None, sfx="", xreg=False):
             f"    for (int c = 0; c < {Zp}; c++) sl[{lay.OFF_RP} + a * {Zp} + c] = Rm[({EADIM} + a) * {Z} + {EADIM} + c];", "  }",
             "} else {", "#pragma unroll", f"  for (int i = 0; i < {Z}; i++) sl[{lay.OFF_Y} + i] = y[i];", "}"]
     tmpl = "template <bool PROJECT>\n" if feat else ""
-    sig = ("const double* xr, " if xreg else "") + "double* sl, const double* zin" + (", const double* eain" if EA else "") + (", const double* gRf" if feat else "")
+    sig = "double* sl, const double* zin" + (", const double* eain" if EA else "") + (", const double* gRf" if feat else "")
     out.append("\n".join([f"{tmpl}__device__ {{INL}} void scal_obs_{k.kind}{sfx}({sig}) {{"] + _ind(b) + ["}"]))
 
   # ---- phase 3: error injection ----------------------------------------------------------------------
@@ -478,7 +478,7 @@ def device_functions(spec, lay_cls=None, sfx="", xreg=False):
   for i in range(D):
     eblk.add(f"xi_{i}", sp.Matrix(spec.err_eqs[0])[i])
   estmts, est = eblk.lower()
-  b = [f"double x[{D}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = " + ("xout[i];" if xreg else f"sl[{lay.OFF_X} + i];")]
+  b = [f"double x[{D}];", "#pragma unroll", f"for (int i = 0; i < {D}; i++) x[i] = sl[{lay.OFF_X} + i];"]
   b += list(estmts)
   for i in range(D):
     kind, val = est[f"xi_{i}"]
@@ -548,7 +548,7 @@ def device_functions(spec, lay_cls=None, sfx="", xreg=False):
       b = _lean_update(k, Hs, lay, E)
     elif k.He_sym is not None:
       b = _lean_update(k, Hs, lay, E, rows_in_regs=True)
-    elif Z >= WIDE_Z_LDS:
+    elif wide_z(k, E):
       b = _wide_obs_update(k, Hs, lay, E)
     else:
       b = [f"double row[{E}], R[{Z * Z}];", "#pragma unroll", f"for (int j = 0; j < {E}; j++) row[j] = sP[cc * {E} + j];"]
@@ -581,7 +581,7 @@ def device_functions(spec, lay_cls=None, sfx="", xreg=False):
       for j in range(E):
         b.append(f"row[{j}] += " + " + ".join(f"Dm_{zi}*sK[{zi * E + j}]" for zi in range(Z)) + ";")
       b += ["if (act) {", "#pragma unroll", f"  for (int j = 0; j < {E}; j++) sP[cc * {E} + j] = row[j];", "}", "rn::wave_lds_sync();"]
-    ss_arg = ", double* sS" if wide_z(k) and lean != 1 and k.He_sym is None else ""
+    ss_arg = ", double* sS" if wide_z(k, E) and lean != 1 and k.He_sym is None else ""
     out.append("\n".join([f"__device__ {INL} void mat_update_{k.kind}(double* sP, const double* __restrict__ gR, const double* sl, double* sw, "
                           f"double* sG, double* sK{ss_arg}, const int cc, const bool act) {{"] + _ind(b) + ["}"]))
   return "\n".join(out).replace("{INL}", INL), lay
@@ -607,7 +607,7 @@ def kernels(spec):
     upd = k is not None
     Z = k.zdim if upd else 1
     ZZ = Z * Z
-    wide_s = upd and wide_z(k) and tune.wide_lean != 1 and k.He_sym is None
+    wide_s = upd and wide_z(k, spec.dim_err) and tune.wide_lean != 1 and k.He_sym is None
     tmpl = "template <bool DO_PREDICT>\n" if upd else ""
     dop = "DO_PREDICT" if upd else "true"
     sig_obs = ("double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const double* __restrict__ gea,\n    "

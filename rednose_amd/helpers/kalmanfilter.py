@@ -3,7 +3,8 @@
 API parity with /root/reference/rednose/helpers/kalmanfilter.py:6-52 -- class-attribute model
 configuration (name, initial_x, initial_P_diag, Q, obs_noise), `x/t/P` properties, `init_state`,
 `get_R`, `predict_and_observe`.  `self.filter` may be an `EKF_sym` (one filter) or a `BatchedEKF`
-(N filters on the GPU); for the latter `data` is (N, Z) and R may be one shared (Z, Z) matrix.
+(N filters on the GPU); for the latter `data` is (N, Z) -- or (N, n, Z): n observations per filter in one call -- and R may be one
+shared (Z, Z) matrix.
 """
 from typing import Any
 
@@ -47,10 +48,12 @@ class KalmanFilter:
     return np.broadcast_to(noise, (n,) + noise.shape).copy()
 
   def predict_and_observe(self, t, kind, data, R=None):
+    """One filter (EKF_sym): data (n, Z), the n observations of this call, R (n, Z, Z) -- the reference's shapes (kalmanfilter.py:45-52).
+    Batched filter: data (N, Z) one observation per filter, or (N, n, Z) n observations per filter (then R defaults to the (n, Z, Z) stack)."""
     if len(data) > 0:
       data = np.atleast_2d(data)
     if R is None:
-      R = self.get_R(kind, len(data))
+      R = self.get_R(kind, data.shape[1] if np.ndim(data) == 3 else len(data))
     return self.filter.predict_and_update_batch(t, kind, data, R)
 
   def predict_and_observe_stream(self, ts, kinds, data, Rs=None, extra_args=None, augment=None):

@@ -101,14 +101,20 @@ __device__ __forceinline__ void wg_barrier() {
 }
 
 // One-way hand-off between two wavefronts of a workgroup through a word of LDS: the producer's earlier LDS accesses are performed before
-// the flag's store (the LDS serves a wavefront's instructions in order), the consumer polls.  Both wavefronts are resident (same
-// workgroup), so the wait cannot deadlock.
+// the flag's store, the consumer polls and its later LDS accesses are performed after the load that saw the flag.  Both wavefronts are
+// resident (same workgroup), so the wait cannot deadlock.  Release / acquire at WORKGROUP scope restricted to the LDS address space (the
+// "local" argument of the fence): under the memory model that is what orders the hand-off for the other wavefront -- a relaxed atomic with
+// wavefront-scope fences, which this was, relied on the in-order LDS queue and on hipcc not moving LDS accesses across the flag -- and it
+// costs what the hardware needs anyway, `s_waitcnt lgkmcnt(0)` in front of the flag's store: a release over ALL address spaces would also
+// wait for vmcnt(0), i.e. drain the covariance trace stores in flight, like __syncthreads() (see wg_barrier).
 __device__ __forceinline__ void flag_set(int* flag, int v) {
   wave_lds_sync();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void flag_wait(int* flag, int v) {
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != v) __builtin_amdgcn_s_sleep(2);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
   wave_lds_sync();
 }
 
@@ -705,6 +711,14 @@ __global__ __launch_bounds__(64) void k_ring_copy(double* __restrict__ ring, con
     } else {
       for (int64_t i = threadIdx.x; i < rec; i += 64) a[i] = r[i];
     }
+  }
+}
+
+// flags[i] = value for the filters with mask[i] != 0 (the orchestrators' "observation too old for this filter's ring, ignored": bits 4 | 5 on top
+// of what the launch wrote), on the stream, without a round trip of the flag bytes through the host
+__global__ void k_flags_set(uint8_t* __restrict__ flags, const uint8_t* __restrict__ mask, const int value, const int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (mask[i] != 0) flags[i] = (uint8_t)value;
   }
 }
 
