@@ -512,7 +512,33 @@ def config4_extra(torch, dev, rank, nb=16384, T=2100, chunk=8192):
   torch.cuda.synchronize()
   full_ms = e0.elapsed_time(e1)
   assert bool(torch.isfinite(tP[0]).all()) and bool(torch.isfinite(tx[0]).all()), "config 4 (all steps dt > 0): non-finite smoothed estimate"
-  del tx, tP
+  del tP
+  # The opt-in packed-triangle trace (batch_run_tri / batch_rts_tri: lower triangles, 253 instead of 484 doubles per covariance): the same sweep of
+  # chunks, second sweep reported.  Same kernels, same arithmetic (the packed results are the full ones' lower triangles bit for bit: tests/test_gpu_tri.py).
+  packed = None
+  if f.has_tri_trace():
+    tT = torch.empty((T, chunk, f.dim_tri), dtype=torch.float64, device=dev)
+    for rep in range(2):
+      f.init_state(x0, np.diag(L.initial_P_diag), None)
+      pf = pb = 0.0
+      for lo in range(0, nb, chunk):
+        hi = min(nb, lo + chunk)
+        bx, bT = (tx, tT) if hi - lo == chunk else (tx[:, :hi - lo].contiguous(), tT[:, :hi - lo].contiguous())
+        zc = zs[:, lo:hi].contiguous()
+        f.filter_time = None
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        f.run(ts, kinds, zc, Rs, flags=True, out=(bx, bT), filters=(lo, hi), packed=True)
+        e1.record()
+        f._rts_on(bx, bT, ts, hi - lo, None, packed=True)      # pylint: disable=protected-access
+        e2.record()
+        torch.cuda.synchronize()
+        pf += e0.elapsed_time(e1)
+        pb += e1.elapsed_time(e2)
+      assert bool(torch.isfinite(bT[0]).all()) and bool(torch.isfinite(bx[0]).all())
+      packed = dict(fwd_ms=pf, bwd_ms=pb)
+    del tT
+  del tx
   def chunk_traffic(label):
     """PMC traffic of the 8 192 x 2 100 chunk launch (profiles/pmc_workload.py), times the chunks swept here (sum over launches, like the bytes)."""
     return traffic_kw(label, "live_maha", gen, scale=nb / chunk) if (chunk == 8192 and T == 2100) else dict(traffic=None)
@@ -544,7 +570,8 @@ def config4_extra(torch, dev, rank, nb=16384, T=2100, chunk=8192):
   rb.update(fp64_fma_per_full_step=fma_full, full_steps_fraction=full_steps_frac, fp64_frac=fma_full * full_steps_frac * bwd_rate / FP64_VALU_LANE_OPS,
             fp64_note="algorithmic FMAs of the steps that take the full path (dt != 0) x steps/s / 39.3 T fp64 lane-instructions/s; the kernel issues ~1.5 x that "
                       "(11 of 16 DPP lanes busy, scalar phase on one lane per filter)")
-  rfull = hbm_roofline(chunk * (T - 1) * 8.0 * 2 * (23 + 484), full_ms * 1e-3, rts_kernel + " (every step dt > 0: full solve on all steps)", traffic=None)
+  rfull = hbm_roofline(chunk * (T - 1) * 8.0 * 2 * (23 + 484), full_ms * 1e-3, rts_kernel + " (every step dt > 0: full solve on all steps)",
+                       **(traffic_kw("config4_backward_dt_gt0", "live_maha", gen) if (chunk == 8192 and T == 2100) else dict(traffic=None)))
   rfull.update(fp64_frac=fma_full * full_rate / FP64_VALU_LANE_OPS, steps_per_s=full_rate, chunk_filters=chunk)
   return {"batch": nb, "T": T, "chunk_filters": chunk,
           "forward_steps_per_s": nb * T / (res["fwd_ms"] * 1e-3), "backward_steps_per_s": nb * (T - 1) / (res["bwd_ms"] * 1e-3),
@@ -554,6 +581,13 @@ def config4_extra(torch, dev, rank, nb=16384, T=2100, chunk=8192):
           "roofline_forward": hbm_roofline(fwd_bytes, res["fwd_ms"] * 1e-3, f"{run_kernel} (trace + gate flags)", **chunk_traffic("config4_forward")),
           "roofline_backward": rb,
           "roofline_backward_dt_gt0": rfull,
+          **({"packed_trace": {
+            "forward_steps_per_s": nb * T / (packed["fwd_ms"] * 1e-3), "backward_steps_per_s": nb * (T - 1) / (packed["bwd_ms"] * 1e-3),
+            "combined_steps_per_s": nb * T / ((packed["fwd_ms"] + packed["bwd_ms"]) * 1e-3), "forward_ms": packed["fwd_ms"], "backward_ms": packed["bwd_ms"],
+            "roofline_forward": hbm_roofline(nb * T * 8.0 * ((23 + 253) + 2 * 3) + nb * T, packed["fwd_ms"] * 1e-3, "k_run2_tri (packed trace + gate flags)", traffic=None),
+            "roofline_backward": hbm_roofline(nb * (T - 1) * 8.0 * 2 * (23 + 253), packed["bwd_ms"] * 1e-3, "k_rts4_tri", traffic=None),
+            "note": "opt-in record layout (run / rts_smooth / smooth(packed=True)): lower triangles only, 2 256 B forward and 4 416 B backward per filter-step "
+                    "actually moved -- the fractions are priced on THOSE bytes, the steps/s compare directly with the full layout above"}} if packed else {}),
           "note": "forward = fused batch_run writing the filtered trace + gate flags; backward = batch_rts recomputing the predicted pairs; "
                   "bytes: forward 4 104 B + 1 flag per filter-step, backward 8 112 B per filter-step (both paths of k_rts4 read the filtered pair and "
                   "write the smoothed pair); roofline_backward_dt_gt0 = the same kernel on one chunk whose steps all advance time"}

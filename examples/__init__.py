@@ -79,6 +79,28 @@ def ensure_generated(names=None, folder=GENERATED_DIR):
 EXACT_DIR = os.path.join(GENERATED_DIR, "exact")      # reference builds with IEEE division / sqrt and the library's sin / cos (tuning knob exact_math)
 
 
+EXACT_NAMES = ("live", "attitude", "rand5", "rand11", "kinematic9")      # models also built with exact_math=1 by __graft_entry__.build()
+
+
+def model_class_of(name):
+  """The model class behind a name of model_table() (the shipped examples and the seeded random filters)."""
+  from examples.kinematic_kf import KinematicKalman
+  from examples.kinematic6_kf import Kinematic6Kalman
+  from examples.kinematic9_kf import Kinematic9Kalman
+  from examples.attitude_kf import AttitudeKalman
+  from examples.feature_kf import FeatureKalman, WideFeatureKalman
+  from examples.live_kf import LiveKalman
+  import examples.random_kf as R
+  table = {"kinematic": KinematicKalman, "kinematic6": Kinematic6Kalman, "kinematic9": Kinematic9Kalman, "attitude": AttitudeKalman,
+           "feature": FeatureKalman, "feature36": WideFeatureKalman, "live": LiveKalman}
+  if name in table:
+    return table[name]
+  for cls in vars(R).values():
+    if isinstance(cls, type) and getattr(cls, "name", None) == name:
+      return cls
+  raise KeyError(name)
+
+
 def ensure_exact(names=("live",)):
   """The named filters built with RN_TUNE=exact_math=1 under generated/exact/ (what the fast elementary functions are measured
   against: tests/test_gpu_live.py).  Part of __graft_entry__.build(), so the GPU box finds them prebuilt."""

@@ -48,6 +48,7 @@ int kinematic9_run_unroll(void);
 int kinematic9_has_batch_run(void);
 int kinematic9_predict_identity_at_dt0(void);
 int kinematic9_batch_run(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts, int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, double *trace_x, double *trace_P, const double *ea, const int32_t *augment, void *stream);
+int kinematic9_has_tri_trace(void);
 int kinematic9_batch_rts(const double *xf, const double *Pf, const double *ts, int64_t T, const double *Q, int64_t n, int norm_quats, double *xs, double *Ps, const double *x_last, const double *P_last, void *stream);
 void kinematic9_predict(double *in_x, double *in_P, double *in_Q, double dt);
 void kinematic9_update_1(double *in_x, double *in_P, double *in_z, double *in_R, double *in_ea);

@@ -117,6 +117,7 @@ extern "C" {
 #define RN_DECLARE_BATCH_RUN(name)                                                                               \
   int RN_FN(name, zmax)(void);                        /* largest Z over the kinds: row stride of z in batch_run  */  \
   int RN_FN(name, run_unroll)(void);                  /* steps per iteration of batch_run's loop (instruction accounting) */ \
+  int RN_FN(name, has_tri_trace)(void);               /* 1: the library has RN_DECLARE_BATCH_TRI's entry points (packed-triangle covariance trace) */ \
   int RN_FN(name, has_batch_run)(void);               /* 0: the fused kernel of this model did not fit the register file -- batch_run \
                                                          returns 4 (unsupported); walk the schedule with batch_predict_update_k */ \
   int RN_FN(name, predict_identity_at_dt0)(void);     /* 1: predict(dt = 0) is the identity on (x, P) for this model (f(x, 0) == x, F(x, 0) == I \
@@ -144,6 +145,23 @@ extern "C" {
   int RN_FN(name, batch_rts)(const double *xf, const double *Pf, const double *ts, int64_t T, const double *Q,     \
                              int64_t n, int norm_quats, double *xs, double *Ps, const double *x_last,             \
                              const double *P_last, void *stream);
+
+/* Packed-triangle trace (libraries with {name}_has_tri_trace() == 1: lane-group models of 13 .. 22 error states, e.g. live): the filtered
+ * covariance trace between the forward and the backward pass as LOWER TRIANGLES packed row-major -- entry (i, j <= i) of a covariance at
+ * i (i + 1) / 2 + j, E (E + 1) / 2 doubles per record instead of E * E.  Nothing is lost against batch_run + batch_rts: the fused run's covariance
+ * is symmetric by contract and batch_rts reads lower triangles only (see "Asymmetric covariances" above).  batch_run_tri: trace_P is
+ * (T, n, E (E + 1) / 2), everything else as batch_run.  batch_rts_tri: Pf, Ps and P_last are packed, everything else as batch_rts (Ps may alias
+ * Pf).  batch_tri_unpack / batch_tri_pack convert `count` records to / from full symmetric matrices (pack takes the lower triangle). */
+#define RN_DECLARE_BATCH_TRI(name)                                                                               \
+  int RN_FN(name, batch_run_tri)(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts,   \
+                                 int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, \
+                                 double *trace_x, double *trace_P, const double *ea, const int32_t *augment,       \
+                                 void *stream);                                                                    \
+  int RN_FN(name, batch_rts_tri)(const double *xf, const double *Pf, const double *ts, int64_t T, const double *Q,  \
+                                 int64_t n, int norm_quats, double *xs, double *Ps, const double *x_last,          \
+                                 const double *P_last, void *stream);                                              \
+  int RN_FN(name, batch_tri_unpack)(const double *tri, double *full, int64_t count, void *stream);                 \
+  int RN_FN(name, batch_tri_pack)(const double *full, double *tri, int64_t count, void *stream);
 
 /* MSCKF models only (gen_code msckf_params): window shift of EKF_sym.augment (ekf_sym.py:365-391) on n filters, in place */
 #define RN_DECLARE_BATCH_MSCKF(name)                                                                             \

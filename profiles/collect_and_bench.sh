@@ -8,10 +8,12 @@ tag=${2:-r3}
 mkdir -p "$d"
 ( time timeout 200 python -m pytest tests/test_gpu_run_blk.py tests/test_gpu_run.py tests/test_gpu_parity.py -q -m gpu -p no:cacheprovider ) > "$d/pytest.log" 2>&1
 tail -5 "$d/pytest.log"
-( time timeout 330 profiles/collect.sh "$tag" ) > "$d/collect.log" 2>&1
+( time timeout 420 profiles/collect.sh "$tag" ) > "$d/collect.log" 2>&1
 tail -3 "$d/collect.log"
-( time timeout 170 python bench.py ) > "$d/bench.json" 2> "$d/bench.err"
+( time timeout 240 python bench.py ) > "$d/bench.json" 2> "$d/bench.err"
 tail -c 600 "$d/bench.err"
+# the driver-style short run (what `--steps 20 --warmup 5` reports: frac from the HIP events, frac_wall from the host's clock)
+( time timeout 120 python bench.py --steps 20 --warmup 5 --no-extras ) > "$d/bench_short.json" 2> "$d/bench_short.err"
 python - "$d/bench.json" <<'PY'
 import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1])

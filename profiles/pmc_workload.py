@@ -95,7 +95,7 @@ def msckf(label, n, reps):
 def config4(n=8192, T=2100):
   """One chunk of config 4 exactly as bench.config4_extra launches it: forward k_run writing trace + gate flags, backward
   smoother (k_rts4) in place on that trace."""
-  if not (want("config4_forward") or want("config4_backward") or want("live_run_notrace")):
+  if not (want("config4_forward") or want("config4_backward") or want("config4_backward_dt_gt0") or want("live_run_notrace")):
     return
   from examples.live_kf import LiveKalman as L
   gen = bench.gen_dir(["live_maha"])
@@ -112,7 +112,7 @@ def config4(n=8192, T=2100):
       if rep == 1:
         section("live_run_notrace", "live_maha", 1, 8.0 * 2 * 3 * n * 252 + 8.0 * 2 * (23 + 484) * n, n * 252, 1)
       f.run(ts[:252], kinds[:252], zs[:252].clone(), Rs)
-  if want("config4_forward") or want("config4_backward"):
+  if want("config4_forward") or want("config4_backward") or want("config4_backward_dt_gt0"):
     tx = torch.empty((T, n, 23), dtype=torch.float64, device=dev)
     tP = torch.empty((T, n, 22, 22), dtype=torch.float64, device=dev)
     f.init_state(x0, np.diag(L.initial_P_diag), None)
@@ -122,6 +122,10 @@ def config4(n=8192, T=2100):
     f.run(ts, kinds, zs.clone(), Rs, flags=True, out=(tx, tP))
     section("config4_backward", "live_maha", 1, n * (T - 1) * 8.0 * 2 * (23 + 484), n * (T - 1), 0)
     f._rts_on(tx, tP, ts, n, None)      # pylint: disable=protected-access
+    # the same kernel with every step advancing time: no step takes the identity-gain path (bench.py: roofline_backward_dt_gt0); in place on the
+    # smoothed trace of the launch above
+    section("config4_backward_dt_gt0", "live_maha", 1, n * (T - 1) * 8.0 * 2 * (23 + 484), n * (T - 1), 0)
+    f._rts_on(tx, tP, 0.01 * np.arange(T), n, None)      # pylint: disable=protected-access
   torch.cuda.synchronize()
 
 

@@ -31,10 +31,11 @@ SMALL_MAX_E = 7    # lane-per-filter register budget: x, P and the update's temp
 #   no_rts4            the smoother with register-broadcast operands (emit_rts4, two wavefronts per SIMD) spilled, or one of its DPP reads follows
 #                      the write of its source too closely (build.dpp_hazards) -> rn::k_rts_group
 #   no_run_blk         the blocked fused run of a lane-per-filter model (emit_small.run_kernel_blk) spilled -> k_run serves untraced runs too
+#   no_tri             one of the packed-triangle trace kernels (k_run2_tri / k_rts4_tri) spilled -> library without batch_run_tri / batch_rts_tri
 #   no_run2            the fused run with a scalar wavefront beside the matrix wavefront (emit_run2, two wavefronts per SIMD) spilled -> k_run (emit_wide3)
 #   no_run             the fused multi-step run of a model above 32 error states touches scratch -> library without batch_run
 #                      (status ERR_UNSUPPORTED, the step-granular entry points cover such models)
-FALLBACKS = ("force_wide", "no_model_defaults", "no_rts4", "rts_one_wave", "no_rts", "no_run2", "no_run", "no_run_blk")
+FALLBACKS = ("force_wide", "no_model_defaults", "no_rts4", "rts_one_wave", "no_rts", "no_run2", "no_run", "no_run_blk", "no_tri")
 _active = frozenset()      # fallbacks of the emit() call in progress
 
 
@@ -113,7 +114,11 @@ def _emit(spec):
   if fam == "wide":
     from rednose_amd.codegen import emit_run2, emit_wide2, emit_wide3
     use_run2 = has_run and tuning.current().run2 and "no_run2" not in _active and emit_run2.applicable(spec)
+    from rednose_amd.codegen import emit_rts4 as _r4
+    # packed-triangle trace: both structures or neither (batch_run_tri writes what batch_rts_tri reads)
+    use_tri = (use_run2 and emit_run2.tri_trace(spec) and tuning.current().rts4 and not ({"no_tri", "no_rts4", "no_rts"} & set(_active)))
     if not has_run:
+      use_tri = False
       fam_mod = types.SimpleNamespace(
         kernels=lambda sp_: emit_wide2.kernels(sp_) + "\n" + emit_wide2.maha_kernels(sp_),
         launch_predict=emit_wide2.launch_predict, launch_step=emit_wide2.launch_step, launch_run=None,
@@ -123,11 +128,12 @@ def _emit(spec):
       # rows of P per lane (emit_wide3)
       fam_mod = types.SimpleNamespace(
         kernels=lambda sp_: emit_wide2.kernels(sp_) + "\n" + emit_wide3.kernels(sp_, with_run=not use_run2) + "\n" +
-                            (emit_run2.kernels(sp_) + "\n" if use_run2 else "") + emit_wide2.maha_kernels(sp_),
+                            (emit_run2.kernels(sp_, tri=use_tri) + "\n" if use_run2 else "") + emit_wide2.maha_kernels(sp_),
         launch_predict=emit_wide2.launch_predict, launch_step=emit_wide2.launch_step,
         launch_run=emit_run2.launch_run if use_run2 else emit_wide3.launch_run,
         launch_maha=emit_wide2.launch_maha)
   else:
+    use_tri = False
     fam_mod = types.SimpleNamespace(
       kernels=lambda sp_: emit_small.kernels(sp_) + "\n" + emit_small.maha_kernels(sp_),
       launch_predict=emit_small.launch_predict, launch_step=emit_small.launch_step, launch_run=lambda: emit_small.launch_run(spec),
@@ -185,8 +191,11 @@ def _emit(spec):
   group_rts = fam == "wide"
   from rednose_amd.codegen import emit_rts4
   use_rts4 = (group_rts and emit_rts4.applicable(spec) and tuning.current().rts4 and "no_rts4" not in _active and "no_rts" not in _active)
+  use_tri = use_tri and use_rts4
   if use_rts4:
     src.append(emit_rts4.kernel(spec))
+    if use_tri:
+      src.append(emit_rts4.kernel(spec, tri=True))
   has_rts = (group_rts or (fam == "small" and spec.dim_main == spec.dim_x and spec.dim_main_err == spec.dim_err)) and "no_rts" not in _active
   if has_rts:
     quat = "".join(f" rn::normalize_quat<{D}>(x, {q});" for q in spec.quaternion_idxs)
@@ -397,6 +406,38 @@ int {name}_batch_predict_update_{k.kind}{sfx}(double *x, double *P, const double
   return rn::OK;
 }}""")
   hdr.append(f"int {name}_batch_run(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts, int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, double *trace_x, double *trace_P, const double *ea, const int32_t *augment, void *stream);")
+  # Packed-triangle trace (opt-in; models with k_run2 AND k_rts4): batch_run_tri writes the lower triangle of every filtered covariance
+  # (row-major, E (E + 1) / 2 doubles) where batch_run writes E^2, batch_rts_tri smooths such a trace into packed smoothed covariances; the fused
+  # run's covariance is symmetric by contract and batch_rts reads lower triangles only (include/rednose_amd_filter.h), so nothing is lost.
+  abi.append(f"int {name}_has_tri_trace(void) {{ return {int(use_tri)}; }}")
+  hdr.append(f"int {name}_has_tri_trace(void);")
+  if use_tri:
+    from rednose_amd.codegen import emit_run2 as _r2
+    abi.append(f"""int {name}_batch_run_tri(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts, int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, double *trace_x, double *trace_P, const double *ea, const int32_t *augment, void *stream) {{
+  RN_REQUIRE(n >= 0 && T >= 0 && x && P && Q && kinds && dts && z && R, rn::ERR_ARG);
+  if (n == 0 || T == 0) return rn::OK;
+  RN_REQUIRE(rn::aligned16(x) && rn::aligned16(P) && rn::aligned16(z) && rn::aligned16(trace_x) && rn::aligned16(trace_P), rn::ERR_ALIGN);
+{_r2.launch_run(tri=True)}
+  RN_HIP(hipGetLastError());
+  return rn::OK;
+}}
+int {name}_batch_tri_unpack(const double *tri, double *full, int64_t count, void *stream) {{
+  RN_REQUIRE(count >= 0 && tri && full, rn::ERR_ARG);
+  if (count == 0) return rn::OK;
+  hipLaunchKernelGGL(rn::k_tri_unpack<{E}>, dim3(8192), dim3(256), 0, (hipStream_t)stream, tri, full, count);
+  RN_HIP(hipGetLastError());
+  return rn::OK;
+}}
+int {name}_batch_tri_pack(const double *full, double *tri, int64_t count, void *stream) {{
+  RN_REQUIRE(count >= 0 && tri && full, rn::ERR_ARG);
+  if (count == 0) return rn::OK;
+  hipLaunchKernelGGL(rn::k_tri_pack<{E}>, dim3(8192), dim3(256), 0, (hipStream_t)stream, full, tri, count);
+  RN_HIP(hipGetLastError());
+  return rn::OK;
+}}""")
+    hdr.append(f"int {name}_batch_run_tri(double *x, double *P, const double *Q, const int32_t *kinds, const double *dts, int64_t T, double *z, const double *R, int64_t n, int norm_quats, uint8_t *flags, double *trace_x, double *trace_P, const double *ea, const int32_t *augment, void *stream);")
+    hdr.append(f"int {name}_batch_tri_unpack(const double *tri, double *full, int64_t count, void *stream);")
+    hdr.append(f"int {name}_batch_tri_pack(const double *full, double *tri, int64_t count, void *stream);")
 
   if has_rts:
     if use_rts4:
@@ -419,6 +460,16 @@ int {name}_batch_predict_update_{k.kind}{sfx}(double *x, double *P, const double
   return rn::OK;
 }}""")
     hdr.append(f"int {name}_batch_rts(const double *xf, const double *Pf, const double *ts, int64_t T, const double *Q, int64_t n, int norm_quats, double *xs, double *Ps, const double *x_last, const double *P_last, void *stream);")
+    if use_tri:
+      abi.append(f"""int {name}_batch_rts_tri(const double *xf, const double *Pf, const double *ts, int64_t T, const double *Q, int64_t n, int norm_quats, double *xs, double *Ps, const double *x_last, const double *P_last, void *stream) {{
+  RN_REQUIRE(n >= 0 && T >= 0 && xf && Pf && ts && Q && xs && Ps, rn::ERR_ARG);
+  if (n == 0 || T == 0) return rn::OK;
+  RN_REQUIRE(rn::aligned16(xf) && rn::aligned16(Pf) && rn::aligned16(xs) && rn::aligned16(Ps) && rn::aligned16(x_last) && rn::aligned16(P_last), rn::ERR_ALIGN);
+{emit_rts4.launch(spec, tri=True)}
+  RN_HIP(hipGetLastError());
+  return rn::OK;
+}}""")
+      hdr.append(f"int {name}_batch_rts_tri(const double *xf, const double *Pf, const double *ts, int64_t T, const double *Q, int64_t n, int norm_quats, double *xs, double *Ps, const double *x_last, const double *P_last, void *stream);")
 
   # the reference's scalar host-pointer ABI, executed as a batch of one on the GPU
   xo, Po, Qo = 0, _align2(D), _align2(D) + _align2(EE)

@@ -76,9 +76,18 @@ def rows_per_lane(spec):
   return -(-spec.dim_err // GL)
 
 
-def lds_bytes(spec, slot):
+def lds_bytes(spec, slot, tri=False):
   D, E = spec.dim_x, spec.dim_err
-  return 8 * (FPW * E * E + 2 + FPW * slot + 2 * (FPW * D + 2) + FPW * E + 2 + E + 2 * FPW * (GL - -(-E // rows_per_lane(spec))) + 2)
+  base = 8 * (FPW * E * E + 2 + FPW * slot + 2 * (FPW * D + 2) + FPW * E + 2 + E + 2 * FPW * (GL - -(-E // rows_per_lane(spec))) + 2)
+  return base + (8 * -(-(E * (E + 1) // 2) // 8) if tri else 0)      # k_rts4_tri: the row of every packed index, one byte each
+
+
+def tri_applicable(spec):
+  """k_rts4_tri (the packed-triangle trace, see kernel()) needs E (E + 1) / 2 more bytes of LDS under the same budget."""
+  if not applicable(spec):
+    return False
+  lay, _ = _tables(spec)
+  return lds_bytes(spec, lay.SLOT, tri=True) <= LDS_BUDGET
 
 
 class RtsLayout:
@@ -137,9 +146,17 @@ def applicable(spec):
   return lds_bytes(spec, lay.SLOT) <= LDS_BUDGET
 
 
-def kernel(spec):
+def kernel(spec, tri=False):
+  """tri=True: `k_rts4_tri` -- the same recursion on a trace whose covariances are PACKED lower triangles (row-major, E (E + 1) / 2 doubles:
+  what batch_run_tri writes): Pf, Ps and Pl are (.., E (E + 1) / 2) arrays.  The kernel's matrix image stays E x E; a packed element goes to /
+  comes from the image's LOWER position (row of a packed index: a byte table in LDS, filled once per launch), which is all the kernel reads
+  of a covariance anyway (the contract of batch_rts) -- the upper-right exchange of the identity-gain step and the mirroring of U drop out."""
   D, E = spec.dim_x, spec.dim_err
   EE = E * E
+  TRI = E * (E + 1) // 2
+  REC = TRI if tri else EE          # doubles per covariance record in memory
+  ITT = -(-(FPW * TRI) // 64)       # packed elements per lane of a tile
+  kname = "k_rts4_tri" if tri else "k_rts4"
   R = rows_per_lane(spec)
   S = range(R)
   RS = -(-E // R)        # rows per slot: row r lives in slot r // RS of lane r % RS (22 states: 2 x 11 -- balanced slots keep the block lower
@@ -200,13 +217,22 @@ def kernel(spec):
         A("#pragma unroll")
         A(f"{ind}for (int j = {hi}; j < {E}; j++) {name}{s}[j] = {src}[j * {E} + {rc}{s}];")
 
-  A(f"// ---- smoother, operands by row_newbcast: {GL} lanes x {R} rows per filter, {FPW} filters per wavefront (emit_rts4.py) ----")
-  A(MACROS)
-  A(f"constexpr int RTS4_SLOT = {lay.SLOT};")
-  A(scal)
+  A(f"// ---- smoother, operands by row_newbcast: {GL} lanes x {R} rows per filter, {FPW} filters per wavefront (emit_rts4.py){' -- covariances as packed lower triangles' if tri else ''} ----")
+  if not tri:
+    A(MACROS)
+    A(f"constexpr int RTS4_SLOT = {lay.SLOT};")
+    A(scal)
+
+  def tri_off(idx, ind):
+    """C lines: image offset `o_` (filter f_, lower position of packed index p_) of the tile's packed element `idx`"""
+    return [f"{ind}const int f_ = ({idx}) / {TRI}; const int p_ = ({idx}) - f_ * {TRI}; const int r_ = s_tr[p_]; const int o_ = f_ * {EE} + r_ * {E} + p_ - (r_ * (r_ + 1)) / 2;"]
+  tri_table = (f"""  __shared__ unsigned char s_tr[{-(-TRI // 8) * 8}];      // row of every packed index (p = r (r + 1) / 2 + j, j <= r)
+  for (int p = lane; p < {TRI}; p += 64) {{ int r = 0; while ((r + 1) * (r + 2) / 2 <= p) r++; s_tr[p] = (unsigned char)r; }}
+  rn::wave_lds_sync();
+""" if tri else "")
   qd_decl = "\n".join(f"  const double qd{s} = gQ[((c < {RS} && (c + {RS * s}) < {E}) ? (c + {RS * s}) : 0) * {E + 1}];" for s in S)
   A(f"""
-__global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, const double* __restrict__ Pf, const double* __restrict__ ts,
+__global__ __launch_bounds__(64, 2) void {kname}(const double* __restrict__ xf, const double* __restrict__ Pf, const double* __restrict__ ts,
     const int64_t T, const double* __restrict__ gQ, const int64_t n, const int norm_quats, double* __restrict__ xs,
     double* __restrict__ Ps, const double* __restrict__ xl, const double* __restrict__ Pl) {{
   __shared__ __attribute__((aligned(16))) double s_I[{FPW} * {EE} + 2];          // the one matrix image per filter (see emit_rts4.py)
@@ -216,7 +242,7 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   __shared__ __attribute__((aligned(16))) double s_dv[{FPW} * {E} + 2];          // inv_err(xk1_k, xk1_n), then Ck delta
   __shared__ __attribute__((aligned(16))) double s_trash[{E} + 2 * {FPW * (GL - RS)} + 2];      // where the idle lanes' row stores go (no predicated regions around LDS stores): overlapping rows, 16 bytes apart
   const int lane = threadIdx.x;
-  int qoff = 0;
+{tri_table}  int qoff = 0;
   for (int i = lane; i < {EE}; i += 64) qoff |= (i / {E} != i % {E}) && (gQ[i] != 0.0);
   const bool qdiag = !__any(qoff);      // a diagonal process noise (the usual case): its row entry is requested at the head of every step
   const int64_t tiles = (n + {FPW} - 1) / {FPW};
@@ -240,7 +266,7 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   for s in S:
     A(f"    const int rr{s} = ct + {RS * s}; const bool ok{s} = live && ct < {RS} && rr{s} < {E}; const int rc{s} = (ct < {RS} && rr{s} < {E}) ? rr{s} : 0;")
   A("    if (T == 1) {      // nothing to smooth, the single estimate's predicted pair is not available: the filtered pair passes through")
-  A(f"      if (Ps != Pf) {{ for (int i = lt; i < cnt * {EE}; i += 64) Ps[base * {EE} + i] = Pf[base * {EE} + i]; }}")
+  A(f"      if (Ps != Pf) {{ for (int i = lt; i < cnt * {REC}; i += 64) Ps[base * {REC} + i] = Pf[base * {REC} + i]; }}")
   A(f"      if (xs != xf) {{ for (int i = lt; i < cnt * {D}; i += 64) xs[base * {D} + i] = xf[base * {D} + i]; }}")
   A("      continue;")
   A("    }")
@@ -256,9 +282,17 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
     A(f"    for (int j = 0; j < {ncol(s)}; j++) ps{s}[j] = 0.0;")
   A("    if (Pl != nullptr) {      // newest smoothed covariance := the predicted one of the last step as passed in (ekf_sym.py:658-659): through the image,")
   A("      // like every later step's (lower triangle mirrored), and out to Ps[T - 1]")
-  A(f"      rn::async_copy_g2l<{FPW} * {EE}>(Pl + base * {EE}, cnt * {EE}, s_I, lt);")
-  A(f"      for (int i = lt; i < cnt * {EE}; i += 64) Ps[((T - 1) * n + base) * {EE} + i] = Pl[base * {EE} + i];")
-  A("      rn::async_wait();")
+  if tri:
+    A(f"      for (int i = lt; i < cnt * {TRI}; i += 64) {{")
+    A(f"        const double v_ = Pl[base * {TRI} + i];")
+    A(f"        Ps[((T - 1) * n + base) * {TRI} + i] = v_;")
+    b.extend(tri_off("i", "        "))
+    A("        s_I[o_] = v_;")
+    A("      }")
+  else:
+    A(f"      rn::async_copy_g2l<{FPW} * {EE}>(Pl + base * {EE}, cnt * {EE}, s_I, lt);")
+    A(f"      for (int i = lt; i < cnt * {EE}; i += 64) Ps[((T - 1) * n + base) * {EE} + i] = Pl[base * {EE} + i];")
+    A("      rn::async_wait();")
   A("      rn::wave_lds_sync();")
   lower_rows("ps", ind="      ", rc="rc", full=False)
   A("      rn::wave_lds_sync();")
@@ -279,7 +313,13 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
     A(f"      const double qd{s} = gQ[rq{s} * {E + 1}];      // (not kept across steps: four registers of a kernel that has none to spare)")
   A("      RN_RTS_STAMP(0);")
   A("      // ---- A. filtered pair of step k: Pk_k -> image in one coalesced burst, xk_k -> LDS ----")
-  if EE % 2:
+  if tri:
+    A(f"      double wt[{ITT}];      // the tile's packed triangles, requested now, scattered to the lower positions of the images after the scalar phase")
+    A(f"      const double* __restrict__ gpt = Pf + (k * n + base) * {TRI};")
+    A("#pragma unroll")
+    A(f"      for (int it = 0; it < {ITT}; it++) {{ const int idx = lb + 64 * it; wt[it] = gpt[idx < cnt * {TRI} ? idx : cnt * {TRI} - 1]; }}")
+    A("      if (false) {")
+  elif EE % 2:
     # Records of an odd number of doubles: the tile of step k starts at (k n + base) E^2 doubles, 16-byte aligned only when k n is even.  The
     # direct HBM -> LDS transfer wants 16-byte aligned global addresses; ordinary 16-byte vector loads do not (dword alignment is enough on the
     # device), so these models stage the tile through registers -- the copy is not hidden under the scalar phase (the test models and kinematic9).
@@ -296,9 +336,20 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   A("      } else {")
   A(f"        rn::async_copy_g2l<{FPW} * {EE}>(Pf + (k * n + base) * {EE}, cnt * {EE}, s_I, lb);      // no register staging: lands under the scalar phase")
   A("      }")
-  if EE % 2:      # (the two branches above are dead text for these models; dropped from the output)
+  if EE % 2 or tri:      # (the two branches above are dead text for these models; dropped from the output)
     i_ = max(i for i, ln in enumerate(b) if ln.strip() == "if (false) {")
     del b[i_:]
+
+  def tri_land(ind):
+    """the packed tile requested at A lands in the images (lower positions)"""
+    A("#pragma unroll")
+    A(f"{ind}for (int it = 0; it < {ITT}; it++) {{")
+    A(f"{ind}  const int idx = lb + 64 * it;")
+    A(f"{ind}  if (idx < cnt * {TRI}) {{")
+    b.extend(tri_off("idx", ind + "    "))
+    A(f"{ind}    s_I[o_] = wt[it];")
+    A(f"{ind}  }}")
+    A(f"{ind}}}")
   A("      const double dt = dtc;")
   A("      rn::wave_lds_sync();")
   A("      RN_RTS_STAMP(1);")
@@ -338,10 +389,52 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
     A("#pragma unroll")
     A(f"          for (int i = 0; i < {D}; i++) sxn[i] = xnew[i];       // xk_n: becomes xk1_n of the next (older) step")
     A("        }")
-    A("        rn::async_wait();")
+    if tri:
+      tri_land("        ")
+    else:
+      A("        rn::async_wait();")
     A("        rn::wave_lds_sync();      // Pk_k has landed; the lead lanes have read xk_k: the buffer takes the next step's")
     A("#pragma unroll")
     A(f"        for (int it = 0; it < {XT}; it++) {{ const int i = lo + 64 * it; if (i < cnt * {D}) s_xk[i] = xnext[it]; }}")
+    if tri:
+      # Packed trace: only lower triangles exist.  Row by row on the block lower triangle: pk = the entry of Pk_k (mirrored inside the diagonal
+      # block), Pk_n = pk + (Pk1_n - pk) as written -- which IS the carried row of the next step, so nothing is read back.  The rows go to the
+      # image (lower positions) for the coalesced packed store; every read of another row's entry precedes every write (fence).
+      for s in S:
+        lo_, hi_ = RS * s, min(E, RS * s + RS)
+        A("        {")
+        A(f"          double pk_[{ncol(s)}];")
+        if lo_:
+          A("#pragma unroll")
+          A(f"          for (int j = 0; j < {lo_}; j++) pk_[j] = sI[rq{s} * {E} + j];")
+        A("#pragma unroll")
+        A(f"          for (int j = {lo_}; j < {hi_}; j++) pk_[j] = sI[{E} * max(rq{s}, j) + min(rq{s}, j)];")
+        A("#pragma unroll")
+        A(f"          for (int j = 0; j < {ncol(s)}; j++) {{ ps{s}[j] -= pk_[j]; ps{s}[j] = pk_[j] + ps{s}[j]; }}      // D = Pk1_n - Pk1_k, then Pk_n = Pk_k + D (Ck = I)")
+        A("        }")
+        A("        __builtin_amdgcn_sched_barrier(0);")
+      A("        rn::wave_lds_sync();")
+      for s in S:
+        A("#pragma unroll")
+        A(f"        for (int j = 0; j < {ncol(s)}; j++) sw{s}[j] = ps{s}[j];")
+      A("        rn::wave_lds_sync();")
+      A(f"        double* __restrict__ gpo = Ps + (k * n + base) * {TRI};")
+      A("#pragma unroll")
+      A(f"        for (int it = 0; it < {ITT}; it++) {{")
+      A("          const int idx = lo + 64 * it;")
+      A(f"          if (idx < cnt * {TRI}) {{")
+      b.extend(tri_off("idx", "            "))
+      A("            gpo[idx] = s_I[o_];")
+      A("          }")
+      A("        }")
+      A("        rn::wave_lds_sync();      // the image is free for the next step's tile")
+      A("        RN_RTS_STAMP(10);")
+      A("        continue;")
+      A("      }")
+      A("      if (false) {      // (the full-matrix form of the identity-gain step follows in the emitter; dropped from this kernel's text)")
+      tri_cut = len(b) - 1
+    else:
+      tri_cut = None
     # Covariance.  U = D = Pk1_n - Pk1_k with Pk1_k = the LOWER triangle of Pk_k mirrored (the contract of batch_rts); a lane holds D on the block
     # lower triangle of its rows (in place of the carried rows); what a row needs of D beyond its slot's last row belongs to the lanes of the later
     # slots, which put it where the row's own entries of that block were (the upper-right block of the image, read into registers first).  The sum
@@ -402,8 +495,12 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
     A("        RN_RTS_STAMP(10);")
     A("        continue;")
     A("      }")
+    if tri_cut is not None:
+      del b[tri_cut:]
   A("      // ---- B. f(xk_k) [renormalised like the forward pass], non-zeros of Fk: once per filter -> slot ----")
   A("      if (lead) scal_predict_s4(sxk, dt, sl, norm_quats & 1);")
+  if tri:
+    tri_land("      ")
   A("      rn::async_wait();")
   A("      rn::wave_lds_sync();")
   A("      RN_RTS_STAMP(2);")
@@ -498,13 +595,19 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   A(f"          else {{ for (int i = cf; i < {D}; i += {GL}) sxn[i] = sl[{lay.OFF_X} + i]; }}")
   A("        }")
   A("        if (Pl == nullptr) {      // (a covariance that was passed in went into ps* before the loop)")
-  A(f"          double* __restrict__ po = Ps + ((k + 1) * n + base + gg) * {EE};      // the recomputed Pk1_k leaves mirrored from the block lower triangle the lanes hold")
-  for s in S:
-    A("#pragma unroll")
-    A(f"          for (int j = 0; j < {ncol(s)}; j++) {{ if (ok{s}) po[rr{s} * {E} + j] = a{s}[j]; }}")
-    if RS * s:
+  if tri:
+    A(f"          double* __restrict__ po = Ps + ((k + 1) * n + base + gg) * {TRI};      // the recomputed Pk1_k leaves as its packed lower triangle (once per tile: predicated stores)")
+    for s in S:
       A("#pragma unroll")
-      A(f"          for (int j = 0; j < {RS * s}; j++) {{ if (ok{s}) po[j * {E} + rr{s}] = a{s}[j]; }}")
+      A(f"          for (int j = 0; j < {ncol(s)}; j++) {{ if (ok{s} && j <= rr{s}) po[(rr{s} * (rr{s} + 1)) / 2 + j] = a{s}[j]; }}")
+  else:
+    A(f"          double* __restrict__ po = Ps + ((k + 1) * n + base + gg) * {EE};      // the recomputed Pk1_k leaves mirrored from the block lower triangle the lanes hold")
+    for s in S:
+      A("#pragma unroll")
+      A(f"          for (int j = 0; j < {ncol(s)}; j++) {{ if (ok{s}) po[rr{s} * {E} + j] = a{s}[j]; }}")
+      if RS * s:
+        A("#pragma unroll")
+        A(f"          for (int j = 0; j < {RS * s}; j++) {{ if (ok{s}) po[j * {E} + rr{s}] = a{s}[j]; }}")
   A("        }")
   A("      }")
   A("      rn::wave_lds_sync();")
@@ -635,10 +738,15 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   A("      typedef double rts4_d2 __attribute__((ext_vector_type(2)));")
   A("      int le = lb;")
   A('      asm volatile("" : "+v"(le));')
-  A(f"      const rts4_d2* __restrict__ in2 = reinterpret_cast<const rts4_d2*>(Pf + (k * n + base) * {EE});")
-  A(f"      rts4_d2* __restrict__ out2 = reinterpret_cast<rts4_d2*>(Ps + (k * n + base) * {EE});")
-  A(f"      const int nv = (cnt * {EE}) / 2;")
-  A(f"      rts4_d2 v[{IT}];")
+  if tri:
+    A(f"      const double* __restrict__ in1 = Pf + (k * n + base) * {TRI};")
+    A(f"      double* __restrict__ out1 = Ps + (k * n + base) * {TRI};")
+    A(f"      double v[{ITT}];")
+  else:
+    A(f"      const rts4_d2* __restrict__ in2 = reinterpret_cast<const rts4_d2*>(Pf + (k * n + base) * {EE});")
+    A(f"      rts4_d2* __restrict__ out2 = reinterpret_cast<rts4_d2*>(Ps + (k * n + base) * {EE});")
+    A(f"      const int nv = (cnt * {EE}) / 2;")
+    A(f"      rts4_d2 v[{IT}];")
   A(f"      double xnext[{XT}];      // filtered state of the next (older) step")
   # U in column blocks of one slot's rows each, ordered so that row sets die early: a block of columns [RS q, RS q + RS) broadcasts only
   # slot q's rows of Ck.  Last slot first, its own (diagonal) block first: after it slot R - 1's rows of Ck are dead; the last block of
@@ -650,13 +758,17 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
       # The tile's filtered records for the final read-add-write are requested HERE, in front of the last product block: the other
       # slots' rows of T and of Ck are dead, their registers take the loads, and the HBM / Infinity Cache round trip passes under the
       # block's FMAs instead of being waited for after them.
-      A(f"      if (cnt == {FPW}) {{")
-      A("#pragma unroll")
-      A(f"        for (int it = 0; it < {IT}; it++) {{ const int idx = le + 64 * it; v[it] = in2[(it < {ITF} || idx < {FPW * EE // 2}) ? idx : {FPW * EE // 2 - 1}]; }}")
-      A("      } else {")
-      A("#pragma unroll")
-      A(f"        for (int it = 0; it < {IT}; it++) {{ const int idx = le + 64 * it; v[it] = in2[idx < nv ? idx : nv - 1]; }}")
-      A("      }")
+      if tri:
+        A("#pragma unroll")
+        A(f"      for (int it = 0; it < {ITT}; it++) {{ const int idx = le + 64 * it; v[it] = in1[idx < cnt * {TRI} ? idx : cnt * {TRI} - 1]; }}")
+      else:
+        A(f"      if (cnt == {FPW}) {{")
+        A("#pragma unroll")
+        A(f"        for (int it = 0; it < {IT}; it++) {{ const int idx = le + 64 * it; v[it] = in2[(it < {ITF} || idx < {FPW * EE // 2}) ? idx : {FPW * EE // 2 - 1}]; }}")
+        A("      } else {")
+        A("#pragma unroll")
+        A(f"        for (int it = 0; it < {IT}; it++) {{ const int idx = le + 64 * it; v[it] = in2[idx < nv ? idx : nv - 1]; }}")
+        A("      }")
       A("#pragma unroll")
       A(f"      for (int it = 0; it < {XT}; it++) {{ const int i = le + 64 * it; xnext[it] = xf[((k > 0 ? k - 1 : 0) * n + base) * {D} + (i < cnt * {D} ? i : 0)]; }}")
       A("      __builtin_amdgcn_sched_barrier(0);")
@@ -675,7 +787,7 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   A("      RN_RTS_STAMP(9);")
   A("      // ---- J. Pk_n = Pk_k + U leaves: one coalesced read-add-write over the tile's records; the sum also returns to the image,")
   A("      // from which every lane takes its rows of the smoothed covariance for the next (older) step ----")
-  if any(last_row(s) + 1 < E for s in S):
+  if any(last_row(s) + 1 < E for s in S) and not tri:      # (packed output: only lower positions are read)
     A("      {      // upper-right blocks: U[r][j] = U[j][r] for the columns beyond a slot's last row")
     for s in S:
       nc_ = last_row(s) + 1
@@ -703,6 +815,21 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   A("      rn::wave_lds_sync();      // the lead lanes have read xk_k: the buffer takes the next step's")
   A("#pragma unroll")
   A(f"      for (int it = 0; it < {XT}; it++) {{ const int i = le + 64 * it; if (i < cnt * {D}) s_xk[i] = xnext[it]; }}")
+  if tri:
+    A("#pragma unroll")
+    A(f"      for (int it = 0; it < {ITT}; it++) {{")
+    A("        const int idx = le + 64 * it;")
+    A(f"        if (idx < cnt * {TRI}) {{")
+    b.extend(tri_off("idx", "          "))
+    A("          const double w_ = v[it] + s_I[o_];")
+    A("          out1[idx] = w_;")
+    A("          s_I[o_] = w_;")
+    A("        }")
+    A("      }")
+    A("      if (false) {")
+    tri_cut2 = len(b) - 1
+  else:
+    tri_cut2 = None
   A(f"      if (cnt == {FPW}) {{      // full tile: the first {ITF} passes of the wavefront are whole")
   A("#pragma unroll")
   A(f"        for (int it = 0; it < {IT}; it++) {{")
@@ -733,6 +860,8 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
     A("          s_I[e_] = w_;")
     A("        }")
   A("      }")
+  if tri_cut2 is not None:      # (the full-matrix read-add-write above is dead text for the packed kernel)
+    del b[tri_cut2:]
   A("      rn::wave_lds_sync();")
   A('      asm volatile("" : ' + ", ".join(f'"+v"(rq{s})' for s in S) + ");      // (fresh addresses: those of the step's first row read are not worth registers across the step)")
   lower_rows("ps", full=False)
@@ -751,7 +880,7 @@ __global__ __launch_bounds__(64, 2) void k_rts4(const double* __restrict__ xf, c
   return "\n".join(b)
 
 
-def launch(spec):
+def launch(spec, tri=False):
   return f"""  const int64_t tiles = (n + {FPW - 1}) / {FPW};
-  hipLaunchKernelGGL(k_rts4, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL({'k_rts4_tri' if tri else 'k_rts4'}, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
                      xf, Pf, ts, T, Q, n, norm_quats, xs, Ps, x_last, P_last);"""

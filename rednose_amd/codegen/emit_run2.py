@@ -285,18 +285,42 @@ def update_fn(spec):
   return "\n".join([head] + _ind(b) + ["}"])
 
 
-def kernels(spec):
-  """Scalar phase functions against Run2Layout (suffix _r2; the state lives in the filter's slot), the matrix functions, k_run2."""
+def kernels(spec, tri=False):
+  """Scalar phase functions against Run2Layout (suffix _r2; the state lives in the filter's slot), the matrix functions, k_run2
+  (tri: and k_run2_tri, the same kernel writing its covariance trace as packed lower triangles)."""
   from rednose_amd.codegen import emit_wide2 as w2
   scal_text, lay = w2.device_functions(spec, lay_cls=Run2Layout, sfx="_r2")
   return "\n".join([f"constexpr int SLOT_R2 = {lay.SLOT};   // two-wavefront fused run: doubles per scalar slot", "", scal_text, "",
-                    predict_fn(spec), update_fn(spec), run_kernel(spec)])
+                    predict_fn(spec), update_fn(spec), run_kernel(spec)] + ([run_kernel(spec, tri=True)] if tri else []))
 
 
-def run_kernel(spec):
+def tri_trace(spec):
+  """The packed covariance trace (k_run2_tri / k_rts4_tri: the lower triangle of every filtered covariance, E (E + 1) / 2 doubles instead of
+  E^2, between batch_run_tri and batch_rts_tri) is generated for the models that have BOTH kernels."""
+  from rednose_amd.codegen import emit_rts4, tuning
+  return bool(tuning.current().tri_trace) and applicable(spec) and emit_rts4.tri_applicable(spec)
+
+
+TRI_MACRO = r"""
+// Row r of a lower triangle packed row-major starts at r (r + 1) / 2 and has r + 1 entries.  A lane stores ALL E entries of its row at that
+// offset, in DESCENDING order of the column: entry j > r lands on entry j - (r' (r' + 1) - r (r + 1)) / 2 < j of a later row r' -- which that
+// row's own lane writes afterwards (same instruction stream, lower column = later instruction; a later row slot = a later loop), so every
+// valid entry is written last and nothing is predicated.  The last valid index of row r is the triangle's last for r = E - 1: nothing leaves
+// the filter's E (E + 1) / 2 doubles.  Needs the wavefront's lockstep; the host emulation (a thread per lane) defines the guarded form.
+// The compiler fence after every store is part of the scheme: to ONE lane its stores go to distinct addresses, so hipcc may reorder or pair
+// them (ds_write2) -- the order only matters across lanes, which it cannot see.  (The first build without the fence wrote wrong triangles.)
+#ifndef RN_TRI_ST
+#define RN_TRI_ST(p, j, r, v) do { (p)[j] = (v); asm volatile("" ::: "memory"); } while (0)
+#endif
+"""
+
+
+def run_kernel(spec, tri=False):
+  """tri=True: `k_run2_tri`, the same kernel whose covariance trace is the packed lower triangle (trace_P: (T, n, E (E + 1) / 2))."""
   from rednose_amd.codegen import tuning
   D, E = spec.dim_x, spec.dim_err
   EE = E * E
+  TRI = E * (E + 1) // 2
   GL, R, FPW, ND = layout2(spec)
   lay, _, _ = w3._tables(spec, Run2Layout)      # pylint: disable=protected-access
   zmax = max(k.zdim for k in spec.kinds)
@@ -322,13 +346,30 @@ def run_kernel(spec):
     return "".join(ind + x + nlc for x in _tl(ph))
   tlb_decl = "        const int tlb = (int)(t % 3) * 20;\n" if _tl_on() else ""
   tl_arg = ", tlb" if _tl_on() else ""
-  return f"""
-// ---- fused multi-step run, {ND} matrix wavefront(s) + a scalar wavefront per tile of {FPG} filters (emit_run2.py): same interface as k_run ----
+  kname = "k_run2_tri" if tri else "k_run2"
+  if tri:
+    # rows -> the filter's packed triangle (at s_P + g * TRI: the tile's triangles are contiguous, like its records in the trace) -> one flat copy
+    pk = []
+    for s_ in range(R):
+      pk.append(f"          if (ok{s_}) {{\n            double* pr_ = s_P + gg * {TRI} + (rr{s_} * (rr{s_} + 1)) / 2;")
+      for j in range(E - 1, -1, -1):
+        pk.append(f"            RN_TRI_ST(pr_, {j}, rr{s_}, row{s_}[{j}]);")
+      pk.append("          }")
+      pk.append("          rn::wave_lds_sync();      // (the next row slot's stores come after this one's)")
+    trace_block = (nlc.join(pk) + nlc +
+                   f"          rn::copy_l2g<R2_FPW * {TRI}, {nt_trace}>(tP + (t * n + base + wave * R2_FPW) * {TRI}, cntw * {TRI}, s_P + wave * (R2_FPW * {TRI}), lz);")
+  else:
+    trace_block = (f"{img}" + nlc + "          rn::wave_lds_sync();" + nlc +
+                   f"          rn::copy_l2g<R2_FPW * {EE}, {nt_trace}>(tP + (t * n + base + wave * R2_FPW) * {EE}, cntw * {EE}, sPw, lz);")
+  head = (TRI_MACRO if tri else "") + f"""
+// ---- fused multi-step run, {ND} matrix wavefront(s) + a scalar wavefront per tile of {FPG} filters (emit_run2.py): same interface as k_run{' -- covariance trace as packed lower triangles' if tri else ''} ----"""
+  consts = "" if tri else f"""
 constexpr int R2_FPG = {FPG};      // filters per workgroup
 constexpr int R2_FPW = {FPW};      // filters per matrix wavefront
 constexpr int R2_GL = {GL};       // lanes per filter in a matrix wavefront
-constexpr int R2_THREADS = {64 * (ND + 1)};
-__global__ __launch_bounds__({64 * (ND + 1)}, {ND + 1}) void k_run2(double* __restrict__ gx, double* __restrict__ gP, const double* __restrict__ gQ,
+constexpr int R2_THREADS = {64 * (ND + 1)};"""
+  return head + consts + f"""
+__global__ __launch_bounds__({64 * (ND + 1)}, {ND + 1}) void {kname}(double* __restrict__ gx, double* __restrict__ gP, const double* __restrict__ gQ,
     const int32_t* __restrict__ kinds, const double* __restrict__ dts, const int64_t T, double* __restrict__ gz,
     const double* __restrict__ gR, const int64_t n, const int norm_quats, uint8_t* __restrict__ flags,
     double* __restrict__ tx, double* __restrict__ tP, const double* __restrict__ gea, const int32_t* __restrict__ augs) {{
@@ -389,9 +430,7 @@ __global__ __launch_bounds__({64 * (ND + 1)}, {ND + 1}) void k_run2(double* __re
 {TL(8)}        if (tP != nullptr) {{
           int lz = lane;
           asm volatile("" : "+v"(lz));
-{img}
-          rn::wave_lds_sync();
-          rn::copy_l2g<R2_FPW * {EE}, {nt_trace}>(tP + (t * n + base + wave * R2_FPW) * {EE}, cntw * {EE}, sPw, lz);
+{trace_block}
           rn::wave_lds_sync();
         }}
 {TL(9)}        rn::wg_barrier();                                 // B1 of step t + 1
@@ -508,7 +547,7 @@ __global__ __launch_bounds__({64 * (ND + 1)}, {ND + 1}) void k_run2(double* __re
 """
 
 
-def launch_run():
-  return """  const int64_t tiles = (n + R2_FPG - 1) / R2_FPG;
-  hipLaunchKernelGGL(k_run2, dim3(rn::grid_for_tiles(tiles)), dim3(R2_THREADS), 0, (hipStream_t)stream,
+def launch_run(tri=False):
+  return f"""  const int64_t tiles = (n + R2_FPG - 1) / R2_FPG;
+  hipLaunchKernelGGL({'k_run2_tri' if tri else 'k_run2'}, dim3(rn::grid_for_tiles(tiles)), dim3(R2_THREADS), 0, (hipStream_t)stream,
                      x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, trace_x, trace_P, ea, augment);"""

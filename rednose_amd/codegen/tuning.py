@@ -19,6 +19,8 @@ variants do not overwrite generated/).  What each alternative measured: profiles
   run2         1 = fused run of lane-group models up to 22 error states as TWO wavefronts per tile, matrix + scalar (emit_run2), 0 = k_run (emit_wide3)
   run2_prio    s_setprio level of emit_run2's scalar wavefront (its chain of dependent instructions issues ahead of the co-resident matrix wavefront's FMAs); 0 = none
   rts4         1 = smoother of lane-group models with register-broadcast operands (emit_rts4: 16 lanes x 2 rows, 4 filters per wavefront, two wavefronts per SIMD), 0 = rn::k_rts_group
+  tri_trace    1 = models with both k_run2 and k_rts4 also get k_run2_tri / k_rts4_tri: the filtered trace between batch_run_tri and batch_rts_tri as packed
+               lower triangles (E (E + 1) / 2 doubles per covariance); 0 = not generated
   rts_dt0      1 = backward steps with dt == 0 of a model whose predict(dt = 0) is the identity take the identity-gain path of k_rts4 (Ck = I: no
                factorisation, no products); 0 = the full solve on every step
 """
@@ -41,6 +43,7 @@ class Tuning:
   run2_prio: int = 0              # (measured: 20.5-20.9 ms per config-4 chunk at 3 against 20.4 at 0 -- the scalar wavefront is not on the critical path)
   run2: int = 1              # fused run with a scalar wavefront beside the matrix wavefront (emit_run2: two wavefronts per SIMD); 0 = emit_wide3's k_run
   rts4: int = 1              # smoother with every cross-lane operand by row_newbcast, two wavefronts per SIMD (emit_rts4: 8 .. 22 error states); 0 = rn::k_rts_group
+  tri_trace: int = 1         # packed-triangle trace kernels (k_run2_tri, k_rts4_tri) for the models that have both structures
   rts_dt0: int = 1           # identity-gain path for dt == 0 steps in k_rts4 (models with identity_at_dt0 only); 0 = full solve on every step
   exact_math: int = 0        # 1 = IEEE division / sqrt and the library's sin / cos instead of the hardware-seed + Newton primitives and rn::sincos_fast (a reference build for tests: tests/test_gpu_live.py)
   nt_trace: int = 1          # the fused run's covariance trace leaves with nontemporal stores (config 4 forward: 23.5 vs 24.5 ms per chunk, same call)

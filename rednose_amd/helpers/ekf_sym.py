@@ -78,6 +78,8 @@ def gen_code(folder, name, f_sym, dt_sym, x_sym, obs_eqs, dim_x, dim_err, eskf_p
       if "k_rts4" in bad:
         usage, bad = fall_back("no_rts4", "the register-broadcast smoother spills under its two-wavefronts-per-SIMD budget (or a DPP read follows the write of its "
                                           "source too closely): lane-group smoother instead")
+      if "k_run2_tri" in bad or "k_rts4_tri" in bad:
+        usage, bad = fall_back("no_tri", "a packed-triangle trace kernel spills registers: library without batch_run_tri / batch_rts_tri")
       if "k_run2" in bad:
         usage, bad = fall_back("no_run2", "the two-wavefront fused run spills under its 256-register budget: the single-wavefront k_run instead")
       if "k_run" in bad and usage["k_run"]["scratch"] > 0 and rn_emit.family(spec, tuple(fallbacks)) == "wide":
@@ -1135,7 +1137,34 @@ class BatchedEKF:
     return ~(self.maha_dist(kind, z, R, extra_args) > chi2_ppf(maha_thresh, self.zdims[kind]))
 
   # -- fused multi-step run -------------------------------------------------------------------------
-  def run(self, ts, kinds, zs, Rs=None, trace=False, flags=False, out=None, filters=None, extra_args=None, augment=None, exact=False):
+  # -- packed-triangle covariance records (libraries with {name}_has_tri_trace()) ---------------------------------------------
+  def has_tri_trace(self):
+    fn = getattr(self._lib, f"{self.name}_has_tri_trace", None)
+    return bool(fn()) if fn is not None else False
+
+  @property
+  def dim_tri(self):
+    return self.dim_err * (self.dim_err + 1) // 2
+
+  def unpack_tri(self, tri, out=None):
+    """(..., E (E + 1) / 2) packed lower triangles (row-major: entry (i, j <= i) at i (i + 1) / 2 + j) -> (..., E, E) symmetric matrices."""
+    torch = self._torch
+    tri = tri.contiguous()
+    lead = tuple(tri.shape[:-1])
+    full = out if out is not None else torch.empty(lead + (self.dim_err, self.dim_err), dtype=torch.float64, device=self.device)
+    self._call("batch_tri_unpack", self._p(tri), self._p(full), int(np.prod(lead)) if lead else 1, self._stream())
+    return full
+
+  def pack_tri(self, full):
+    """(..., E, E) -> (..., E (E + 1) / 2): the LOWER triangles (what batch_rts reads of a covariance)."""
+    torch = self._torch
+    full = self._dev(full).contiguous()
+    lead = tuple(full.shape[:-2])
+    tri = torch.empty(lead + (self.dim_tri,), dtype=torch.float64, device=self.device)
+    self._call("batch_tri_pack", self._p(full), self._p(tri), int(np.prod(lead)) if lead else 1, self._stream())
+    return tri
+
+  def run(self, ts, kinds, zs, Rs=None, trace=False, flags=False, out=None, filters=None, extra_args=None, augment=None, exact=False, packed=False):
     """T predict+update steps in ONE launch; x and P stay on chip between steps.
 
     ts (T,) observation times, kinds (T,) observation kinds -- the schedule is shared by all filters;
@@ -1153,6 +1182,8 @@ class BatchedEKF:
     (one launch per step: the state crosses HBM every step).  The default (fused launch) computes on (P + P^T) / 2, which is the
     same thing for the covariances a filter produces itself and differs at first order in a caller-supplied skew part
     (include/rednose_amd_filter.h).
+    packed=True (libraries with has_tri_trace(): lane-group models of 13 .. 22 error states): the covariance trace is written as packed
+    lower triangles, trace_P (T, N, E (E + 1) / 2) -- half the bytes; rts_smooth(..., packed=True) consumes it (unpack_tri() gives matrices).
     Returns (ys, trace_x, trace_P, flags) with None for outputs not requested.
     """
     torch = self._torch
@@ -1186,13 +1217,16 @@ class BatchedEKF:
     Rd = self._dev(table)
     kd = torch.as_tensor(kinds, device=self.device)
     dd = self._dev(dts)
+    if packed and (exact or not self.has_tri_trace()):
+      raise KalmanError(f"run(packed=True): lib{self.name}.so has no packed-triangle trace kernels ({self.name}_has_tri_trace), or exact=True was asked for")
+    pshape = (T, nb, self.dim_tri) if packed else (T, nb, self.dim_err, self.dim_err)
     if out is not None:
       tx, tP = out
-      for t_, shp in ((tx, (T, nb, self.dim_x)), (tP, (T, nb, self.dim_err, self.dim_err))):
+      for t_, shp in ((tx, (T, nb, self.dim_x)), (tP, pshape)):
         assert t_.is_contiguous() and t_.dtype == torch.float64 and tuple(t_.shape) == shp and t_.device == self.device, "out: wrong trace buffer"
     else:
       tx = torch.empty((T, nb, self.dim_x), dtype=torch.float64, device=self.device) if trace else None
-      tP = torch.empty((T, nb, self.dim_err, self.dim_err), dtype=torch.float64, device=self.device) if trace else None
+      tP = torch.empty(pshape, dtype=torch.float64, device=self.device) if trace else None
     fl = torch.zeros((T, nb), dtype=torch.uint8, device=self.device) if flags else None
     if nb == 0:
       return zs, tx, tP, fl
@@ -1209,7 +1243,7 @@ class BatchedEKF:
       assert self.msckf, "augment: MSCKF models only"
       ag = torch.as_tensor(np.asarray(augment, dtype=np.int32).reshape(T), device=self.device)
     if self._has_batch_run() and not exact:
-      self._call("batch_run", self._p(xv), self._p(Pv), self._p(self.Q), self._p(kd), self._p(dd), T, self._p(zs),
+      self._call("batch_run_tri" if packed else "batch_run", self._p(xv), self._p(Pv), self._p(self.Q), self._p(kd), self._p(dd), T, self._p(zs),
                  self._p(Rd), nb, self.norm_quats, self._p(fl), self._p(tx), self._p(tP), self._p(ea), self._p(ag), self._stream())
     else:
       self._run_stepwise(xv, Pv, kinds, dts, zs, Rd, nb, fl, tx, tP, ea, None if augment is None else np.asarray(augment).reshape(T),
@@ -1257,7 +1291,7 @@ class BatchedEKF:
       self._keepalive_step = (zt, Rt, eat)
 
   # -- offline smoothing ----------------------------------------------------------------------------
-  def smooth(self, ts, kinds, zs, Rs, passes=1, chunk=None, norm_quats=None, on_chunk=None, flags=False, extra_args=None, augment=None):
+  def smooth(self, ts, kinds, zs, Rs, passes=1, chunk=None, norm_quats=None, on_chunk=None, flags=False, extra_args=None, augment=None, packed=False):
     """Offline estimation over a whole observation stream: forward filter keeping the filtered trace, then the RTS
     backward pass -- `passes` times, each pass restarting the filter from the oldest smoothed estimate of the previous
     one ("multiple forward and backwards passes of the data", /root/reference/README.md:41-45, built on rts_smooth,
@@ -1274,6 +1308,9 @@ class BatchedEKF:
     to one sweep.  on_chunk(lo, hi, xs, Ps, ys, flags) receives each chunk's smoothed trajectory (device tensors, valid
     only during the call: the buffers are reused); without it the whole smoothed trajectory is returned, which needs the
     trace of the full batch to fit.  On return x / P hold the FILTERED state after the last pass and filter_time = ts[-1].
+    packed=True (has_tri_trace() libraries): the trace between the two passes holds packed lower triangles -- 2 208 B instead of 4 056 B per
+    live filter-step written by the forward pass and read AND written by the backward pass; on_chunk then receives Ps as (T, m, E (E + 1) / 2)
+    (unpack_tri() turns what it needs into matrices), the returned trajectory (no on_chunk) is unpacked to (T, N, E, E) as always.
     Returns (xs (T, N, D), Ps (T, N, E, E)) or None when on_chunk is given.
     """
     torch = self._torch
@@ -1287,8 +1324,10 @@ class BatchedEKF:
       raise KalmanError("smooth(chunk=...) hands the smoothed trajectory out chunk by chunk: pass on_chunk")
     t_init = self.filter_time
     aug0 = list(self.augment_times) if self.msckf else None      # run() shifts them when it covers the whole batch: once per pass
+    if packed and not self.has_tri_trace():
+      raise KalmanError(f"smooth(packed=True): lib{self.name}.so has no packed-triangle trace kernels ({self.name}_has_tri_trace)")
     tx = torch.empty((T, step, self.dim_x), dtype=torch.float64, device=self.device)
-    tP = torch.empty((T, step, self.dim_err, self.dim_err), dtype=torch.float64, device=self.device)
+    tP = torch.empty((T, step, self.dim_tri) if packed else (T, step, self.dim_err, self.dim_err), dtype=torch.float64, device=self.device)
     for lo in range(0, self.batch, step):
       hi = min(self.batch, lo + step)
       m = hi - lo
@@ -1297,12 +1336,12 @@ class BatchedEKF:
       for p in range(passes):
         self.filter_time = t_init if p == 0 else float(ts[0])
         zc = zs[:, lo:hi].clone()               # run() consumes its observations (overwrites them with the residuals)
-        ys, _, _, fl = self.run(ts, kinds, zc, Rs, flags=flags, out=(bx, bP), filters=(lo, hi), extra_args=ea, augment=augment)
+        ys, _, _, fl = self.run(ts, kinds, zc, Rs, flags=flags, out=(bx, bP), filters=(lo, hi), extra_args=ea, augment=augment, packed=packed)
         # the smoother works on the trace of this chunk only: a view of the orchestrator restricted to its filters
-        xs, Ps = self._rts_on(bx, bP, ts, m, norm_quats)
+        xs, Ps = self._rts_on(bx, bP, ts, m, norm_quats, packed=packed)
         if p + 1 < passes:
           self.x[lo:hi].copy_(xs[0])
-          self.P[lo:hi].copy_(Ps[0])
+          self.P[lo:hi].copy_(self.unpack_tri(Ps[0]) if packed else Ps[0])
       if on_chunk is not None:
         on_chunk(lo, hi, xs, Ps, ys, fl)
     self.filter_time = float(ts[-1])
@@ -1313,23 +1352,23 @@ class BatchedEKF:
         if a_:
           self.augment_times = self.augment_times[1:] + [float(t_)]
     if on_chunk is None:
-      return xs, Ps
+      return xs, (self.unpack_tri(Ps) if packed else Ps)
     return None
 
-  def _rts_on(self, tx, tP, ts, m, norm_quats):
-    """In-place backward pass over a trace of m filters (m <= batch)."""
+  def _rts_on(self, tx, tP, ts, m, norm_quats, packed=False):
+    """In-place backward pass over a trace of m filters (m <= batch); packed: tP holds packed lower triangles (batch_rts_tri)."""
     torch = self._torch
     if not hasattr(self._lib, f"{self.name}_batch_rts"):
       raise KalmanError(f"lib{self.name}.so has no batch_rts entry point")
     T = int(tx.shape[0])
     td = self._dev(np.asarray(ts, dtype=np.float64) if not isinstance(ts, torch.Tensor) else ts, (T,))
     nq = self.norm_quats | ((self.norm_quats if norm_quats is None else int(bool(norm_quats))) << 1)
-    self._call("batch_rts", self._p(tx), self._p(tP), self._p(td), T, self._p(self.Q), m, nq, self._p(tx), self._p(tP),
+    self._call("batch_rts_tri" if packed else "batch_rts", self._p(tx), self._p(tP), self._p(td), T, self._p(self.Q), m, nq, self._p(tx), self._p(tP),
                None, None, self._stream())
     self._keepalive_rts = (tx, tP, td)
     return tx, tP
 
-  def rts_smooth(self, trace_x, trace_P, ts, norm_quats=None, inplace=False, last_predicted=None):
+  def rts_smooth(self, trace_x, trace_P, ts, norm_quats=None, inplace=False, last_predicted=None, packed=False):
     """Batched Rauch-Tung-Striebel backward pass over the filtered trace returned by run(trace=True).
 
     trace_x (T, N, D), trace_P (T, N, E, E) filtered states/covariances, ts (T,) their times.  Semantics are the
@@ -1343,14 +1382,18 @@ class BatchedEKF:
     cross-covariance blocks of that ONE estimate (index T - 1) are then the filtered ones of the trace, not the predicted
     ones (F_main P[main, window] is not formed), so pass last_predicted when the newest estimate's window blocks matter.
     Every older estimate is unaffected: the reference smooths the main block only (:675-686).
+    packed=True (has_tri_trace() libraries): trace_P is a packed-triangle trace (T, N, E (E + 1) / 2) as run(packed=True) writes it and the
+    smoothed covariances come back packed too (unpack_tri() gives matrices); last_predicted still takes a full (N, E, E) covariance.
     Returns (states (T, N, D), covs (T, N, E, E)) device tensors, oldest first.
     """
     torch = self._torch
     if not hasattr(self._lib, f"{self.name}_batch_rts"):
       raise KalmanError(f"lib{self.name}.so has no batch_rts entry point")
+    if packed and not self.has_tri_trace():
+      raise KalmanError(f"rts_smooth(packed=True): lib{self.name}.so has no packed-triangle trace kernels ({self.name}_has_tri_trace)")
     T = int(trace_x.shape[0])
     xf = self._dev(trace_x, (T, self.batch, self.dim_x))
-    Pf = self._dev(trace_P, (T, self.batch, self.dim_err, self.dim_err))
+    Pf = self._dev(trace_P, (T, self.batch, self.dim_tri) if packed else (T, self.batch, self.dim_err, self.dim_err))
     td = self._dev(np.asarray(ts, dtype=np.float64) if not isinstance(ts, torch.Tensor) else ts, (T,))
     xs = xf if inplace else torch.empty_like(xf)
     Ps = Pf if inplace else torch.empty_like(Pf)
@@ -1358,10 +1401,12 @@ class BatchedEKF:
     if last_predicted is not None:
       xl = self._dev(last_predicted[0], (self.batch, self.dim_x))
       Pl = self._dev(last_predicted[1], (self.batch, self.dim_err, self.dim_err))
+      if packed:
+        Pl = self.pack_tri(Pl)
     # bit 0: the recomputed predicted states are renormalised like the forward pass did (a property of the filter);
     # bit 1: the reference's norm_quats argument (smoothed states)
     nq = self.norm_quats | ((self.norm_quats if norm_quats is None else int(bool(norm_quats))) << 1)
-    self._call("batch_rts", self._p(xf), self._p(Pf), self._p(td), T, self._p(self.Q), self.batch, nq, self._p(xs), self._p(Ps),
+    self._call("batch_rts_tri" if packed else "batch_rts", self._p(xf), self._p(Pf), self._p(td), T, self._p(self.Q), self.batch, nq, self._p(xs), self._p(Ps),
                self._p(xl), self._p(Pl), self._stream())
     self._keepalive_rts = (xf, Pf, td, xl, Pl)
     return xs, Ps

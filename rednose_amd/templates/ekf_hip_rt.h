@@ -714,6 +714,32 @@ __global__ __launch_bounds__(64) void k_ring_copy(double* __restrict__ ring, con
   }
 }
 
+// Packed lower triangles <-> full symmetric matrices, `count` records of E (E + 1) / 2 / E * E doubles (the packed-triangle trace of
+// batch_run_tri / batch_rts_tri against the full-matrix interfaces).  One thread per entry of the full matrix.
+template <int E>
+__global__ void k_tri_unpack(const double* __restrict__ tri, double* __restrict__ full, const int64_t count) {
+  constexpr int TRI = E * (E + 1) / 2;
+  const int64_t total = count * E * E;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t rec = i / (E * E);
+    const int e = (int)(i - rec * (E * E)), r = e / E, c = e - r * E;
+    const int hi = r > c ? r : c, lo = r > c ? c : r;
+    full[i] = tri[rec * TRI + (hi * (hi + 1)) / 2 + lo];
+  }
+}
+template <int E>
+__global__ void k_tri_pack(const double* __restrict__ full, double* __restrict__ tri, const int64_t count) {
+  constexpr int TRI = E * (E + 1) / 2;
+  const int64_t total = count * TRI;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t rec = i / TRI;
+    const int p = (int)(i - rec * TRI);
+    int r = 0;
+    while ((r + 1) * (r + 2) / 2 <= p) r++;
+    tri[i] = full[rec * (E * E) + r * E + (p - (r * (r + 1)) / 2)];      // the LOWER triangle, like batch_rts reads it
+  }
+}
+
 // flags[i] = value for the filters with mask[i] != 0 (the orchestrators' "observation too old for this filter's ring, ignored": bits 4 | 5 on top
 // of what the launch wrote), on the stream, without a round trip of the flag bytes through the host
 __global__ void k_flags_set(uint8_t* __restrict__ flags, const uint8_t* __restrict__ mask, const int value, const int64_t n) {

@@ -658,20 +658,26 @@ __global__ __launch_bounds__(64, Model::WAVES) void k_rts_group(const double* __
         // ---- identity-gain step (see the head of this file): Ck = I on the main block.  The difference buffer holds D = Pk1_n - Pk1_k,
         // symmetric; the filtered row enters the sum as stored.  dt is a scalar of the launch: the branch is uniform. ----
         wave_lds_sync();           // the group has written xk1_n out: the buffer takes xk_n
+        // (straight from / to LDS, one lane per filter: staged through register arrays like the full path's state phase, the five state-sized
+        // arrays of this body put the 56-state model's one-wavefront build 53 registers over the file)
+        if (lead) Model::inv_err(sl + Model::OFF_X, sxn, sde);
+        wave_lds_sync();
         if (lead) {
-          double xb[D], xn1[D], xa[D], xnew[D], delta[E];
+          Model::err(sxk, sde, sxn);                                               // xk_n: becomes xk1_n of the next (older) step
+          if constexpr (DM < D) {
 #pragma unroll
-          for (int i = 0; i < D; i++) { xb[i] = sl[Model::OFF_X + i]; xn1[i] = sxn[i]; xa[i] = sxk[i]; }
-          Model::inv_err(xb, xn1, delta);
-          Model::err(xa, delta, xnew);
-#pragma unroll
-          for (int i = 0; i < D; i++) sxn[i] = (i < DM) ? xnew[i] : xa[i];       // xk_n: becomes xk1_n of the next (older) step
+            for (int i = DM; i < D; i++) sxn[i] = sxk[i];                          // (MSCKF: only the main states are smoothed)
+          }
         }
-        if (on) {
-          double pr[EM];
-          rts_load_row<E, EM>(Pk, pr);
+        if (on) {                  // row c of Pk_n = Pk_k + D, eight entries at a time: Pk1_n of the next (older) step
 #pragma unroll
-          for (int j = 0; j < EM; j++) C[c * EM + j] += pr[j];                   // row c of Pk_n = Pk_k + D: Pk1_n of the next (older) step
+          for (int j0 = 0; j0 < EM; j0 += 8) {
+            double pr[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) pr[j] = (j0 + j < EM) ? Pk[j0 + j] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { if (j0 + j < EM) C[c * EM + j0 + j] += pr[j]; }
+          }
         }
         wave_lds_sync();
         continue;

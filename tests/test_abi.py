@@ -54,7 +54,8 @@ def test_generic_header_macros_cover_generated_symbols(gen_dir):
   """Every symbol family documented in rednose_amd_filter.h exists in a generated library, and vice versa."""
   with open(os.path.join(INCLUDE, "rednose_amd_filter.h"), encoding="utf-8") as f:
     text = f.read()
-  documented = {a + b for a, b in re.findall(r"RN_FN\(name, (\w+?)(?:##k(?:##(\w+))?)?\)", text)} - {"sym", "batch_augment"}   # augment: MSCKF models only
+  tri = {"batch_run_tri", "batch_rts_tri", "batch_tri_unpack", "batch_tri_pack"}      # packed-triangle trace: libraries with has_tri_trace() == 1 (live below)
+  documented = {a + b for a, b in re.findall(r"RN_FN\(name, (\w+?)(?:##k(?:##(\w+))?)?\)", text)} - {"sym", "batch_augment"} - tri   # augment: MSCKF models only
   from rednose_amd.helpers import parse_prototypes
   with open(os.path.join(gen_dir, "kinematic6.h"), encoding="utf-8") as f:
     protos = parse_prototypes(f.read())
@@ -63,6 +64,11 @@ def test_generic_header_macros_cover_generated_symbols(gen_dir):
     s = sym[len("kinematic6_"):]
     generated.add(re.sub(r"_\d+(_masked)?$", lambda m: "_" + (m.group(1) or ""), s))      # the kind number is part of the symbol
   assert generated == documented, (sorted(generated - documented), sorted(documented - generated))
+  with open(os.path.join(gen_dir, "live.h"), encoding="utf-8") as f:
+    live = parse_prototypes(f.read())
+  assert all(f"live_{t}" in live for t in tri) and not any(f"kinematic6_{t}" in protos for t in tri)
+  dll = ctypes.CDLL(os.path.join(gen_dir, "liblive.so"))
+  assert dll.live_has_tri_trace() == 1 and ctypes.CDLL(os.path.join(gen_dir, "libkinematic6.so")).kinematic6_has_tri_trace() == 0
 
 
 def test_compute_without_device_fails_loudly(gen_dir):
@@ -163,6 +169,30 @@ def test_dpp_hazard_detector_on_a_synthetic_listing():
   assert not rb.dpp_hazards(ok_nop) and not rb.dpp_hazards(ok_two) and not rb.dpp_hazards(ok_other) and not rb.dpp_hazards(ok_load)
   other_kernel = bad0.replace("k_rts4", "k_step")
   assert not rb.dpp_hazards(other_kernel)
+
+
+def test_every_generated_library_has_its_smoother_and_fused_run_as_documented(gen_dir):
+  """gen_code ships a library WITHOUT batch_rts (a warning, not an error) when no smoother variant fits the register file, and without the fused
+  run for the dense 32- / 56-state test models (README "Limits").  Which libraries those are is pinned here, so that a change that pushes a
+  smoother over the register file (the identity-gain body did that to the 56-state model's one-wavefront build until its state phase went
+  through LDS) shows up on the CPU, not as a KalmanError on the GPU box."""
+  import glob
+  libs = sorted(glob.glob(os.path.join(gen_dir, "lib*.so")))
+  assert len(libs) >= 20
+  no_run = set()
+  for lib in libs:
+    name = os.path.basename(lib)[3:-3]
+    if name.startswith("gv_"):          # (libraries of tests/test_global_vars.py: whatever that test generated)
+      continue
+    dll = ctypes.CDLL(lib)
+    assert hasattr(dll, f"{name}_batch_rts"), f"lib{name}.so was built without batch_rts (see {name}.kernels.txt)"
+    with open(os.path.join(gen_dir, f"{name}.kernels.txt"), encoding="utf-8") as f:
+      assert any(ln.startswith("k_rts") for ln in f), name
+    fn = getattr(dll, f"{name}_has_batch_run")
+    fn.restype = ctypes.c_int
+    if not fn():
+      no_run.add(name)
+  assert no_run == {"rand32", "rand56"}, no_run
 
 
 def test_compiled_python_binding_builds_and_fails_loudly_without_a_device(gen_dir):

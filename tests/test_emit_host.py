@@ -853,7 +853,11 @@ def _wide_run_kernel_host_library(tmp_path, spec, variant="k_run"):
     if variant == "k_run2":
       assert emit_run2.applicable(spec)
       nw = emit_run2.layout2(spec)[3] + 1
-      text = f"constexpr int GLR = {GL}; constexpr int RPL = {R}; constexpr int FPWR = {FPW};\n" + re.sub(r"__builtin_amdgcn_s_setprio\(\d+\);", ";", emit_run2.kernels(spec))
+      # (k_run2_tri, the packed-triangle trace variant, rides along where the model has it: its row stores lean on the wavefront's lockstep --
+      # every lane stores ALL E entries of its row at the row's packed offset, later stores repair the overlap -- which threads do not have:
+      # the macro takes its guarded form here, entry j of row r is stored only for j <= r)
+      text = (f"constexpr int GLR = {GL}; constexpr int RPL = {R}; constexpr int FPWR = {FPW};\n#define RN_TRI_ST(p, j, r, v) do {{ if ((j) <= (r)) (p)[j] = (v); }} while (0)\n" +
+              re.sub(r"__builtin_amdgcn_s_setprio\(\d+\);", ";", emit_run2.kernels(spec, tri=emit_run2.tri_trace(spec))))
     else:
       text = emit_wide3.kernels(spec)
   text = re.sub(r'asm volatile\("" : "\+v"\((\w+)\)( :: "memory")?\);', ";", text)
@@ -864,6 +868,8 @@ extern "C" __attribute__((visibility("default"))) void host_wide_run(int grid, d
     int64_t T, double* z, const double* R, int64_t n, int norm_quats, uint8_t* flags, double* tx, double* tP) {
   run_grid(grid, [&] { KERNEL(x, P, Q, kinds, dts, T, z, R, n, norm_quats, flags, tx, tP, nullptr, nullptr); });
 }""".replace("KERNEL", variant)
+  if "void k_run2_tri(" in text:
+    entry += entry.replace("host_wide_run", "host_wide_run_tri").replace("k_run2(", "k_run2_tri(")
   prelude = _KERNEL_PRELUDE.replace("inline void pin(double&) {}", "inline void pin(double&) {}\n" + _WIDE_COPIES).replace("namespace rn {", _WAVE_VOTES + "namespace rn {", 1)
   grid_text = _RUN_GRID
   if variant == "k_run2":
@@ -955,6 +961,18 @@ def _fused_run_host_case(tmp_path, name, variant):
   tx1, tP1 = np.zeros((T, n, D)), np.zeros((T, n, E, E))
   lib.host_wide_run(grid, ptr(xh1), ptr(Ph1), ptr(Q), ptr(sched, ip), ptr(dts), T, ptr(zh1), ptr(Rt), n, int(quat_idx >= 0), ptr(fl, bp), ptr(tx1), ptr(tP1))
   assert np.array_equal(xh1, xh) and np.array_equal(Ph1, Ph) and np.array_equal(zh1, zh) and np.array_equal(tP1, tP)
+  if hasattr(lib, "host_wide_run_tri"):
+    # the packed-triangle trace of the same launch (k_run2_tri): the lower triangles of the full trace, bit for bit; nothing else changes
+    TRI = E * (E + 1) // 2
+    il = np.tril_indices(E)
+    lib.host_wide_run_tri.argtypes = lib.host_wide_run.argtypes
+    xh3, Ph3, zh3 = x0.copy(), P0.copy(), zs.copy()
+    tx3, tP3 = np.zeros((T, n, D)), np.full((T + 1, n, TRI), 7.0)
+    lib.host_wide_run_tri(grid, ptr(xh3), ptr(Ph3), ptr(Q), ptr(sched, ip), ptr(dts), T, ptr(zh3), ptr(Rt), n, int(quat_idx >= 0), ptr(fl, bp), ptr(tx3), ptr(tP3))
+    assert np.array_equal(tP3[:T], tP[:, :, il[0], il[1]]) and (tP3[T] == 7.0).all(), f"{name}: packed trace"
+    assert np.array_equal(xh3, xh) and np.array_equal(Ph3, Ph) and np.array_equal(zh3, zh) and np.array_equal(tx3, tx)
+  else:
+    assert variant != "k_run2" or name != "live_maha"
   # an unknown kind: flag 8, state and observation untouched for that step
   sched2 = sched.copy(); sched2[1] = 77
   xh2, Ph2, zh2 = x0.copy(), P0.copy(), zs.copy()
@@ -1004,6 +1022,9 @@ def _rts4_host_library(tmp_path, spec):
   with tuning.using_model(spec):
     assert emit_rts4.applicable(spec)
     text = emit_rts4.kernel(spec)
+    has_tri = emit_rts4.tri_applicable(spec)
+    if has_tri:
+      text += "\n" + emit_rts4.kernel(spec, tri=True)
   routines = "\n".join(routine_device_function(r)[0] for r in spec.routines() if r.name in ("err_fun", "inv_err_fun"))
   text = re.sub(r'asm volatile\("" : ((?:"\+v"\(\w+\)(?:, )?)+)\);', ";", text)
   text = text.replace("__builtin_amdgcn_sched_barrier", "rn::sched_barrier_")
@@ -1015,6 +1036,8 @@ extern "C" __attribute__((visibility("default"))) void host_rts4(int grid, const
     int norm_quats, double* xs, double* Ps, const double* xl, const double* Pl) {
   run_grid(grid, [&] { k_rts4(xf, Pf, ts, T, Q, n, norm_quats, xs, Ps, xl, Pl); });
 }"""
+  if has_tri:
+    entry += entry.replace("host_rts4(", "host_rts4_tri(").replace("k_rts4(", "k_rts4_tri(")
   prelude = _KERNEL_PRELUDE.replace("inline void pin(double&) {}", "inline void pin(double&) {}\n" + _WIDE_COPIES + "inline void* lds_offset_ptr(double* p) { return p; }\n")
   prelude = prelude.replace("namespace rn {", _WAVE_VOTES + _RTS4_HOST + "namespace rn {", 1)
   src = "\n".join([prelude, helpers, "}  // namespace rn", routines, text, _RUN_GRID, entry])
@@ -1023,9 +1046,14 @@ extern "C" __attribute__((visibility("default"))) void host_rts4(int grid, const
   res = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fno-gnu-unique", "-fvisibility=hidden", "-Wno-unknown-pragmas", "-Wno-attributes",
                         "-ffp-contract=off", str(cpp), "-o", str(lib)], capture_output=True, text=True)
   assert res.returncode == 0, res.stderr[-4000:]
-  fn = ctypes.CDLL(str(lib)).host_rts4
+  dll = ctypes.CDLL(str(lib))
+  fn = dll.host_rts4
   dp = ctypes.POINTER(ctypes.c_double)
   fn.argtypes = [ctypes.c_int, dp, dp, dp, ctypes.c_int64, dp, ctypes.c_int64, ctypes.c_int, dp, dp, dp, dp]
+  fn.tri = None
+  if has_tri:
+    fn.tri = dll.host_rts4_tri
+    fn.tri.argtypes = fn.argtypes
   return fn
 
 
@@ -1067,6 +1095,26 @@ def test_register_broadcast_smoother_on_the_host_live(tmp_path):
   assert_close(P[:T - 1, 1][:, il[0], il[1]], P[:T - 1, 0][:, il[0], il[1]], rtol=1e-12, floor=1e-14, what="lower triangle of the filter with garbage above the diagonal")
   qn = np.linalg.norm(X[1:, 0, 3:7], axis=1)
   assert np.abs(qn - 1).max() < 1e-14
+  # k_rts4_tri: the same recursion on PACKED lower triangles (what batch_run_tri writes) -- the lower triangles of the result above, and the
+  # same states; also in place, and with the newest pair passed in
+  assert fn.tri is not None
+  il = np.tril_indices(22)
+  Pt = np.ascontiguousarray(Pf[:, :, il[0], il[1]])
+  xs3, Ps3 = np.full((T + 2, n, 23), 7.0), np.full((T + 2, n, 253), 7.0)
+  fn.tri(1, ptr(xf), ptr(Pt), ptr(ts), T, ptr(Q), n, 3, ptr(xs3[1:]), ptr(Ps3[1:]), None, None)
+  assert (Ps3[0] == 7.0).all() and (Ps3[T + 1] == 7.0).all() and (xs3[0] == 7.0).all() and (xs3[T + 1] == 7.0).all()
+  assert_close(Ps3[1:T + 1].reshape(T * n, -1), P[:, :, il[0], il[1]].reshape(T * n, -1), rtol=1e-13, floor=1e-15, what="packed smoothed covariances vs the full kernel's lower triangles")
+  assert_close(xs3[1:T + 1].reshape(T * n, -1), X.reshape(T * n, -1), rtol=1e-13, floor=1e-15, what="packed kernel: smoothed states")
+  xl = np.ascontiguousarray(xf[T - 1] + 1e-3)
+  Pl = np.ascontiguousarray(Pf[T - 1] * 1.01)
+  Pl[1][np.triu_indices(22, 1)] = 0.0      # (the full kernel reads lower triangles: whatever is above is irrelevant)
+  xs4, Ps4 = np.zeros((T, n, 23)), np.zeros((T, n, 22, 22))
+  fn(1, ptr(xf), ptr(Pf), ptr(ts), T, ptr(Q), n, 3, ptr(xs4), ptr(Ps4), ptr(xl), ptr(Pl))
+  Xi, Pi = np.ascontiguousarray(xf.copy()), Pt.copy()
+  fn.tri(1, ptr(Xi), ptr(Pi), ptr(ts), T, ptr(Q), n, 3, ptr(Xi), ptr(Pi), ptr(xl), ptr(np.ascontiguousarray(Pl[:, il[0], il[1]])))
+  keep = [j for j in range(n) if j != 1]
+  assert_close(Pi[:, keep].reshape(T * len(keep), -1), Ps4[:, keep][:, :, il[0], il[1]].reshape(T * len(keep), -1), rtol=1e-13, floor=1e-15, what="packed, in place, newest pair passed in")
+  assert_close(Xi.reshape(T * n, -1), xs4.reshape(T * n, -1), rtol=1e-13, floor=1e-15, what="packed, in place: states")
 
 
 @pytest.mark.timeout(900, method="thread")

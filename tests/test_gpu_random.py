@@ -335,3 +335,61 @@ def test_predict_with_zero_dt_is_not_skipped_for_affine_models(dim):
   for name, got in (("fused run", f), ("step path", s)):
     assert_close(got.state(), xr, rtol=1e-9, floor=1e-11, what=f"{M.name} {name} x")
     assert_close(got.covs().reshape(n, -1), Pr.reshape(n, -1), rtol=1e-9, floor=1e-11, what=f"{M.name} {name} P")
+
+
+EXACT_MODELS = ("attitude", "rand5", "rand11", "kinematic9")      # (examples.EXACT_NAMES: built with IEEE arithmetic by __graft_entry__.build())
+
+
+@pytest.mark.parametrize("name", EXACT_MODELS)
+def test_fast_elementary_functions_against_the_ieee_build_other_models(name):
+  """The non-IEEE primitives of the default build (hardware-seed reciprocals / reciprocal square roots + Newton steps, the in-line sincos:
+  include/rednose_amd_filter.h) against the RN_TUNE=exact_math=1 build of the same model, beyond live (tests/test_gpu_live.py): a quaternion
+  ESKF and a random 5-state model of the lane-per-filter family, a random 11-state model with trigonometric terms and the 9-state kinematic
+  model of the lane-group family.  Same inputs through both libraries: single fused predict + update calls of every kind agree to 2e-13 (x) / 1e-14 (P) of
+  the row maximum, a 20-step fused run to 1e-11, the smoother over its trace to 1e-9."""
+  import torch
+  from examples import ensure_generated, ensure_exact, model_class_of
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  M = model_class_of(name)
+  gen, gex = ensure_generated([name]), ensure_exact([name])
+  D, E = int(M.initial_x.shape[0]), int(M.initial_P_diag.shape[0])
+  quat = list(getattr(M, "quaternion_idxs", [0] if name == "attitude" else []))
+  mk = lambda folder, n: BatchedEKF(folder, name, M.Q, M.initial_x, np.diag(M.initial_P_diag), D, E, batch=n, quaternion_idxs=quat)      # noqa: E731
+  rng = np.random.default_rng(17)
+  n = 130
+  x0 = M.initial_x[None] + rng.normal(size=(n, D)) * 0.2
+  for q0 in quat:
+    x0[:, q0:q0 + 4] /= np.linalg.norm(x0[:, q0:q0 + 4], axis=1, keepdims=True)
+  A = rng.normal(size=(n, E, E)) * 0.2
+  P0 = np.diag(M.initial_P_diag)[None] + A @ A.transpose(0, 2, 1)
+  fa, fe = mk(gen, n), mk(gex, n)
+
+  def rel(a, b):
+    a, b = np.asarray(a).reshape(n, -1), np.asarray(b).reshape(n, -1)
+    return float((np.abs(a - b) / np.maximum(np.abs(b).max(axis=1, keepdims=True), 1e-300)).max())
+  kinds = sorted(M.obs_noise)
+  for k in kinds:
+    R = np.atleast_2d(M.obs_noise[k])
+    z = rng.normal(size=(n, R.shape[0])) * 0.3
+    for f in (fa, fe):
+      f.init_state(x0, P0, 0.0)
+      f.predict_and_update_batch(0.02, k, z.copy(), R)
+    torch.cuda.synchronize()
+    ex, eP = rel(fa.state(), fe.state()), rel(fa.covs(), fe.covs())
+    assert ex < 2e-13 and eP < 1e-14, f"{name} kind {k}: fast vs IEEE build {ex:.2e} (x) {eP:.2e} (P) of the row maximum"      # measured: 4.8e-14 (attitude, kind 2) / 3.4e-16
+  T = 20
+  ks = rng.choice(kinds, size=T).astype(np.int32)
+  ts = np.cumsum(rng.uniform(0.0, 0.02, size=T))
+  zmax = max(np.atleast_2d(M.obs_noise[k]).shape[0] for k in kinds)
+  zs = rng.normal(size=(T, n, zmax)) * 0.3
+  Rs = {k: np.atleast_2d(M.obs_noise[k]) for k in kinds}
+  out = []
+  for f in (fa, fe):
+    f.init_state(x0, P0, 0.0)
+    _, tx, tP, _ = f.run(ts, ks, zs.copy(), Rs, trace=True)
+    xs, Ps = f.rts_smooth(tx, tP, ts)
+    torch.cuda.synchronize()
+    out.append((f.state(), f.covs(), xs.cpu().numpy()[0], Ps.cpu().numpy()[0]))
+  assert rel(out[0][0], out[1][0]) < 1e-11 and rel(out[0][1], out[1][1]) < 1e-11, f"{name}: 20-step fused run, fast vs IEEE build"
+  assert rel(out[0][2], out[1][2]) < 1e-9 and rel(out[0][3], out[1][3]) < 1e-9, f"{name}: oldest smoothed estimate, fast vs IEEE build"
+

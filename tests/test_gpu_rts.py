@@ -7,6 +7,8 @@ from conftest import assert_close, golden
 
 pytestmark = pytest.mark.gpu
 
+RTS_ENTRYWISE_BOUND = 1e-6      # |dP_ij| / sqrt(P_ii P_jj) of the live smoother against the reference's rts_smooth: measured 1.5e-8 (gpurun_out/rts_error_budget.json); cond(Pk1_k) * eps is 2.4e-4
+
 
 @pytest.fixture(scope="module")
 def env():
@@ -111,8 +113,15 @@ def test_rts_error_budget(env):
   idx = g["Ps_smooth_idx"]
   Pr = g["Ps_smooth"].reshape(len(idx), -1)
   eP = (np.abs(P[idx].reshape(len(idx), -1) - Pr) / np.abs(Pr).max(axis=1, keepdims=True)).max()
+  # ... and entry by entry on each entry's OWN scale: |dP_ij| against sqrt(P_ii P_jj) (the row maximum above lets small off-diagonal entries
+  # of a covariance whose diagonal spans 1e-4 .. 1e8 pass unchecked; this does not)
+  Pg = g["Ps_smooth"]
+  sd = np.sqrt(np.abs(np.einsum("kii->ki", Pg)))
+  eC = (np.abs(P[idx] - Pg) / (sd[:, :, None] * sd[:, None, :])).max()
   out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
   if os.path.isdir(out):
     with open(os.path.join(out, "rts_error_budget.json"), "w", encoding="utf-8") as fh:
-      json.dump(dict(cond_max=float(kappa), eps=float(eps), cond_eps=float(kappa * eps), rel_err_states=float(ex), rel_err_covs=float(eP)), fh)
+      json.dump(dict(cond_max=float(kappa), eps=float(eps), cond_eps=float(kappa * eps), rel_err_states=float(ex), rel_err_covs=float(eP),
+                     rel_err_covs_entrywise_correlation_scale=float(eC)), fh)
   assert ex <= kappa * eps and eP <= kappa * eps, (ex, eP, kappa * eps)
+  assert eC <= RTS_ENTRYWISE_BOUND, (eC, RTS_ENTRYWISE_BOUND)

@@ -54,6 +54,8 @@ def unit_text(spec):
       src.append(routine_device_function(r)[0])
   with tuning.using_model(spec):
     src.append(emit_rts4.kernel(spec))
+    if os.environ.get("RTS4_TRI"):
+      src.append(emit_rts4.kernel(spec, tri=True))
   src.append("}  // namespace")
   src.append(f"""extern "C" int rts4_dev_batch_rts(const double *xf, const double *Pf, const double *ts, int64_t T, const double *Q, int64_t n, int norm_quats, double *xs, double *Ps, const double *x_last, const double *P_last, void *stream) {{
 {emit_rts4.launch(spec)}
