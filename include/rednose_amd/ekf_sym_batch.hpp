@@ -70,7 +70,7 @@ class EKFSymBatch {
     for (auto& c : ring_) release(c);
     for (auto& c : spare_) release(c);
     for (double* p : {x_, P_, Q_, R_, pf_.ring_x, pf_.ring_P, pf_.ring_z, pf_.ring_ea, pf_.dt, pf_.stage_z[0], pf_.stage_z[1], pf_.stage_ea[0],
-                      pf_.stage_ea[1], pf_.Rn, pf_.zpack})
+                      pf_.stage_ea[1], pf_.Rn, pf_.zpack, pf_.eapack})
       (void)hipFree(p);
     (void)hipFree(pf_.act);
     (void)hipFree(pf_.slot);
@@ -216,14 +216,32 @@ class EKFSymBatch {
   // observations; ignored() tells which.  Do not mix with the shared-timeline calls on one object.
   int64_t predict_and_update_batch_per_filter(const double* t_host, const uint8_t* active_host, int kind, double* z_dev,
                                               const double* R_host, uint8_t* flags_dev = nullptr, const double* ea_dev = nullptr) {
+    return predict_and_update_batch_per_filter(t_host, active_host, kind, std::vector<double*>{z_dev}, std::vector<const double*>{R_host}, flags_dev,
+                                               ea_dev ? std::vector<const double*>{ea_dev} : std::vector<const double*>{});
+  }
+
+  // The same with n observations per active filter in ONE call, in the reference's argument shape (vectors of z / R / extra_args, ekf_sym.cc:83-85):
+  // every active filter is predicted to its own time once, gets the n observations in order and writes ONE checkpoint into its ring; a late call
+  // rewinds its filter over whole calls and the replay applies every overtaken call with all its observations.  z_devs[j]: (N, Z) device, in z_j /
+  // out y_j; R_hosts[j]: Z x Z host, shared by the batch; flags_dev: n x N bytes (observation j at flags_dev + j * N; a filter that was not active
+  // has 16 in every row) or nullptr.  n may not exceed set_max_observations_per_call() (default 1: the rings are sized by it).
+  int64_t predict_and_update_batch_per_filter(const double* t_host, const uint8_t* active_host, int kind, const std::vector<double*>& z_devs,
+                                              const std::vector<const double*>& R_hosts, uint8_t* flags_dev = nullptr,
+                                              const std::vector<const double*>& ea_devs = {}) {
     const int Z = zdim_.at(kind);
+    const int nobs = (int)z_devs.size();
+    if (nobs < 1 || R_hosts.size() != z_devs.size() || (!ea_devs.empty() && ea_devs.size() != z_devs.size()))
+      throw std::runtime_error("rednose_amd: per-filter call needs n >= 1 observations with one R (and, if any, one extra_args) each");
+    if (nobs > pf_nmax_)
+      throw std::runtime_error("rednose_amd: " + std::to_string(nobs) + " observations per call: call set_max_observations_per_call() before the first per-filter step");
+    if ((size_t)nobs * Z * Z > 64 * 64) throw std::runtime_error("rednose_amd: too many observations in one call for the noise staging buffer");
     pf_init();
     PerFilter& s = pf_;
     const int K = rewind_to_keep_;
     // everything that can be refused is refused HERE, before the rings, the filter times or x / P are touched: a call that throws
     // leaves the object as it was.  (Kinds with different extra-argument counts are refused once, in pf_init; a pending observation
     // was accepted by these same checks when it first arrived.)
-    if (s.ead_of.at(kind) > 0 && ea_dev == nullptr)
+    if (s.ead_of.at(kind) > 0 && ea_devs.empty())
       throw std::runtime_error("rednose_amd: kind " + std::to_string(kind) + " takes extra arguments: ea_dev is null");
     for (int64_t i = 0; i < n_; i++) {
       const bool on = active_host ? active_host[i] != 0 : true;
@@ -235,7 +253,7 @@ class EKFSymBatch {
     if (active_host) act.assign(active_host, active_host + n_);
     std::fill(s.ignored.begin(), s.ignored.end(), 0);
     std::vector<int32_t> slot(n_, 0);
-    std::vector<std::vector<Pending>> rep;           // rep[q]: overtaken observation number q of every rewound filter
+    std::vector<std::vector<Pending>> rep;           // rep[q]: overtaken call number q of every rewound filter
     int64_t n_ignored = 0;
     // ---- late observations: EKFSym::rewind (ekf_sym.cc:119-140) on every late filter's own ring ----
     for (int64_t i = 0; i < n_; i++) {
@@ -254,7 +272,9 @@ class EKFSymBatch {
       s.ft[i] = s.rt[at(ix - 1)];
       for (int32_t j = ix; j < L; j++) {
         if (rep.size() < (size_t)(j - ix + 1)) rep.emplace_back();
-        rep[j - ix].push_back(Pending{i, s.rt[at(j)], s.rkind[at(j)], s.rridx[at(j)], (int32_t)((H + j) % K)});
+        Pending p{i, s.rt[at(j)], s.rkind[at(j)], s.rnobs[at(j)], {}, (int32_t)((H + j) % K)};
+        p.ridx.assign(s.rridx.begin() + at(j) * pf_nmax_, s.rridx.begin() + at(j) * pf_nmax_ + p.nobs);
+        rep[j - ix].push_back(std::move(p));
       }
       s.len[i] = ix;
     }
@@ -264,35 +284,58 @@ class EKFSymBatch {
       ring_copy(s.ring_x, D_, x_, D_, D_, false);
       ring_copy(s.ring_P, (int64_t)E_ * E_, P_, (int64_t)E_ * E_, (int64_t)E_ * E_, false);
     }
-    // every checkpoint written below lands on the ring slot of the NEXT overtaken observation: that one is staged out first
+    // every checkpoint written below lands on the ring slot of the NEXT overtaken call: that one is staged out first
     int cur = 0;
     if (!rep.empty()) stage(rep[0], cur);
     std::vector<double> tt(t_host, t_host + n_);
-    std::vector<int> ridx(n_, rtable_index(R_host, Z));
-    hip(hipMemcpyAsync(R_, R_host, sizeof(double) * Z * Z, hipMemcpyHostToDevice, stream_), "copy R");
-    masked_step(tt, act, kind, Z, z_dev, R_, 0, flags_dev, ea_dev, ridx);
-    // ---- fast-forward (ekf_sym.cc:111-116): position q of every rewound filter, one launch per kind present there ----
+    std::vector<std::vector<int>> ridx(nobs);
+    std::vector<const double*> R_devs;
+    for (int j = 0; j < nobs; j++) {
+      ridx[j].assign(n_, rtable_index(R_hosts[j], Z));
+      hip(hipMemcpyAsync(R_ + (size_t)j * Z * Z, R_hosts[j], sizeof(double) * Z * Z, hipMemcpyHostToDevice, stream_), "copy R");
+      R_devs.push_back(R_ + (size_t)j * Z * Z);
+    }
+    masked_step(tt, act, kind, Z, z_devs, R_devs, 0, flags_dev, ea_devs, ridx, nullptr);
+    // ---- fast-forward (ekf_sym.cc:111-116): position q of every rewound filter, one group of launches per kind present there ----
     for (size_t q = 0; q < rep.size(); q++) {
       if (q + 1 < rep.size()) stage(rep[q + 1], cur ^ 1);
       std::map<int, std::vector<const Pending*>> by_kind;
       for (const Pending& p : rep[q]) by_kind[p.kind].push_back(&p);
       for (auto& kv : by_kind) {
-        const int k = kv.first, Zk = zdim_.at(k);
+        const int k = kv.first, Zk = zdim_.at(k), ek = s.ead_of.at(k);
         std::vector<uint8_t> ra(n_, 0);
-        std::vector<double> tq(s.ft), Rn((size_t)n_ * Zk * Zk, 0.0);
-        std::vector<int> rq(n_, 0);
-        for (const Pending* p : kv.second) {
-          ra[p->f] = 1;
-          tq[p->f] = p->t;
-          rq[p->f] = p->ridx;
-          std::copy(s.rtable[p->ridx].begin(), s.rtable[p->ridx].end(), Rn.begin() + (size_t)p->f * Zk * Zk);
+        std::vector<double> tq(s.ft);
+        std::vector<int32_t> nq(n_, 0);
+        int nmaxq = 0;
+        for (const Pending* p : kv.second) { ra[p->f] = 1; tq[p->f] = p->t; nq[p->f] = p->nobs; nmaxq = std::max(nmaxq, p->nobs); }
+        std::vector<std::vector<int>> rq(nmaxq, std::vector<int>(n_, 0));
+        std::vector<double*> zs;
+        std::vector<const double*> Rs, eas;
+        for (int j = 0; j < nmaxq; j++) {
+          std::vector<double> Rn((size_t)n_ * Zk * Zk, 0.0);
+          for (int64_t f = 0; f < n_; f++)                                  // (filters masked out of launch j: any regular matrix)
+            for (int d = 0; d < Zk; d++) Rn[(size_t)f * Zk * Zk + d * Zk + d] = 1.0;
+          for (const Pending* p : kv.second) {
+            if (p->nobs <= j) continue;
+            rq[j][p->f] = p->ridx[j];
+            std::copy(s.rtable[p->ridx[j]].begin(), s.rtable[p->ridx[j]].end(), Rn.begin() + (size_t)p->f * Zk * Zk);
+          }
+          // staged observations are (N, nmax, zmax) rows, the entry point takes (N, Zk) contiguous
+          double* zj = s.zpack + (size_t)j * obs_stride(s.zmax);
+          hip(hipMemcpy2DAsync(zj, sizeof(double) * Zk, s.stage_z[cur] + (size_t)j * s.zmax, sizeof(double) * pf_nmax_ * s.zmax, sizeof(double) * Zk, n_,
+                               hipMemcpyDeviceToDevice, stream_), "pack z");
+          double* Rj = s.Rn + (size_t)j * n_ * s.zmax * s.zmax;
+          upload(Rj, Rn.data(), sizeof(double) * Rn.size());
+          zs.push_back(zj);
+          Rs.push_back(Rj);
+          if (ek) {
+            double* ej = s.eapack + (size_t)j * obs_stride(s.ead);
+            hip(hipMemcpy2DAsync(ej, sizeof(double) * ek, s.stage_ea[cur] + (size_t)j * s.ead, sizeof(double) * pf_nmax_ * s.ead, sizeof(double) * ek, n_,
+                                 hipMemcpyDeviceToDevice, stream_), "pack ea");
+            eas.push_back(ej);
+          }
         }
-        // staged observations are (N, zmax) rows, the entry point takes (N, Zk) contiguous
-        hip(hipMemcpy2DAsync(s.zpack, sizeof(double) * Zk, s.stage_z[cur], sizeof(double) * s.zmax, sizeof(double) * Zk, n_,
-                             hipMemcpyDeviceToDevice, stream_), "pack z");
-        upload(s.Rn, Rn.data(), sizeof(double) * Rn.size());
-        const int ek = s.ead_of.at(k);
-        masked_step(tq, ra, k, Zk, s.zpack, s.Rn, 1, nullptr, ek ? s.stage_ea[cur] : nullptr, rq);
+        masked_step(tq, ra, k, Zk, zs, Rs, 1, nullptr, eas, rq, &nq);
       }
       cur ^= 1;
     }
@@ -302,9 +345,16 @@ class EKFSymBatch {
       // only the mask of the ignored filters goes up (N bytes; `upload` waits for that one copy because its source is pageable host memory), and a
       // small kernel sets their bytes on the stream: no download of the flags, the other filters' bytes are not rewritten
       upload(s.act, s.ignored.data(), (size_t)n_);
-      check(sym<int (*)(uint8_t*, const uint8_t*, int, int64_t, void*)>("batch_flags_set")(flags_dev, s.act, 16 | 32, n_, stream_), "batch_flags_set");
+      for (int j = 0; j < nobs; j++)
+        check(sym<int (*)(uint8_t*, const uint8_t*, int, int64_t, void*)>("batch_flags_set")(flags_dev + (size_t)j * n_, s.act, 16 | 32, n_, stream_), "batch_flags_set");
     }
     return n_ignored;
+  }
+  // capacity of a per-filter ring entry in observations (the rings, K x N x that many observation slots, are allocated by the first per-filter call)
+  void set_max_observations_per_call(int nmax) {
+    if (pf_.ready) throw std::runtime_error("rednose_amd: set_max_observations_per_call() after the per-filter rings were allocated");
+    if (nmax < 1) throw std::runtime_error("rednose_amd: set_max_observations_per_call(n >= 1)");
+    pf_nmax_ = nmax;
   }
   const std::vector<double>& filter_times() const { return pf_.ft; }          // NaN: the filter has not stepped yet
   const std::vector<uint8_t>& ignored() const { return pf_.ignored; }         // 1: the last per-filter call ignored this filter's observation
@@ -428,7 +478,7 @@ class EKFSymBatch {
   }
 
   // ---- per-filter timelines ---------------------------------------------------------------------------------------------
-  struct Pending { int64_t f; double t; int kind; int ridx; int32_t slot; };   // an overtaken observation still in filter f's ring
+  struct Pending { int64_t f; double t; int kind; int nobs; std::vector<int> ridx; int32_t slot; };   // an overtaken call (its observations' noise indices) still in filter f's ring
   struct PerFilter {
     bool ready = false;
     int zmax = 0, ead = 0;
@@ -436,12 +486,13 @@ class EKFSymBatch {
     std::vector<uint8_t> ignored;
     std::vector<int32_t> head, len;          // circular ring position per filter
     std::vector<double> rt;                  // (K, N) checkpoint times
-    std::vector<int32_t> rkind, rridx;       // (K, N) observation kind / index into rtable
+    std::vector<int32_t> rkind, rnobs;       // (K, N) observation kind / observations of the call
+    std::vector<int32_t> rridx;              // (K, N, nmax) index of every observation's noise matrix in rtable
     std::vector<std::vector<double>> rtable; // distinct noise matrices referenced by live ring slots (row-major Z x Z), see rtable_gc
     size_t rtable_gc_at = 64;
     std::map<int, int> ead_of;               // extra arguments per kind
     double *ring_x = nullptr, *ring_P = nullptr, *ring_z = nullptr, *ring_ea = nullptr;      // (K, N, rec) device
-    double *dt = nullptr, *Rn = nullptr, *zpack = nullptr;
+    double *dt = nullptr, *Rn = nullptr, *zpack = nullptr, *eapack = nullptr;
     double* stage_z[2] = {nullptr, nullptr};
     double* stage_ea[2] = {nullptr, nullptr};
     uint8_t* act = nullptr;
@@ -449,6 +500,7 @@ class EKFSymBatch {
   };
   using masked_fn = int (*)(double*, double*, const double*, const double*, double, double*, const double*, int, const double*,
                             int64_t, int, uint8_t*, const uint8_t*, void*);
+  using masked_update_fn = int (*)(double*, double*, double*, const double*, int, const double*, int64_t, int, uint8_t*, const uint8_t*, void*);
   using ring_fn = int (*)(double*, int64_t, double*, int64_t, int64_t, const int32_t*, const uint8_t*, int64_t, int, void*);
 
   void pf_init() {
@@ -469,19 +521,21 @@ class EKFSymBatch {
     const size_t K = (size_t)std::max(rewind_to_keep_, 0);
     s.rt.assign(K * n_, NAN);
     s.rkind.assign(K * n_, 0);
-    s.rridx.assign(K * n_, 0);
+    s.rnobs.assign(K * n_, 1);
+    s.rridx.assign(K * n_ * (size_t)pf_nmax_, 0);
     auto dmal = [&](double** p, size_t doubles) { hip(hipMalloc((void**)p, sizeof(double) * std::max<size_t>(doubles, 2)), "hipMalloc per-filter buffer"); };
     const size_t ea1 = (size_t)std::max(s.ead, 1);
     if (K > 0) {
       dmal(&s.ring_x, K * n_ * D_);
       dmal(&s.ring_P, K * n_ * E_ * E_);
-      dmal(&s.ring_z, K * n_ * s.zmax);
-      dmal(&s.ring_ea, K * n_ * ea1);
+      dmal(&s.ring_z, K * n_ * (size_t)pf_nmax_ * s.zmax);
+      dmal(&s.ring_ea, K * n_ * (size_t)pf_nmax_ * ea1);
     }
     dmal(&s.dt, n_);
-    dmal(&s.zpack, (size_t)n_ * s.zmax);
-    dmal(&s.Rn, (size_t)n_ * s.zmax * s.zmax);
-    for (int b = 0; b < 2; b++) { dmal(&s.stage_z[b], (size_t)n_ * s.zmax); dmal(&s.stage_ea[b], (size_t)n_ * ea1); }
+    dmal(&s.zpack, (size_t)pf_nmax_ * obs_stride(s.zmax));
+    dmal(&s.eapack, (size_t)pf_nmax_ * obs_stride((int)ea1));
+    dmal(&s.Rn, (size_t)pf_nmax_ * n_ * s.zmax * s.zmax);
+    for (int b = 0; b < 2; b++) { dmal(&s.stage_z[b], (size_t)n_ * pf_nmax_ * s.zmax); dmal(&s.stage_ea[b], (size_t)n_ * pf_nmax_ * ea1); }
     hip(hipMalloc((void**)&s.act, n_ + 16), "hipMalloc mask");
     hip(hipMalloc((void**)&s.slot, sizeof(int32_t) * n_ + 16), "hipMalloc slots");
     ring_copy_ = sym<ring_fn>("batch_ring_copy");
@@ -506,9 +560,12 @@ class EKFSymBatch {
     std::vector<std::vector<double>> kept;
     for (int64_t i = 0; i < n_ && K > 0; i++) {
       for (int32_t j = 0; j < s.len[i]; j++) {
-        int32_t& r = s.rridx[(size_t)((s.head[i] + j) % K) * n_ + i];
-        if (remap[r] < 0) { remap[r] = (int)kept.size(); kept.push_back(std::move(s.rtable[r])); }
-        r = remap[r];
+        const size_t at = (size_t)((s.head[i] + j) % K) * n_ + i;
+        for (int32_t o = 0; o < s.rnobs[at]; o++) {
+          int32_t& r = s.rridx[at * pf_nmax_ + o];
+          if (remap[r] < 0) { remap[r] = (int)kept.size(); kept.push_back(s.rtable[r]); }
+          r = remap[r];
+        }
       }
     }
     s.rtable.swap(kept);
@@ -528,15 +585,18 @@ class EKFSymBatch {
     for (const Pending& p : list) { m[p.f] = 1; sl[p.f] = p.slot; }
     upload(s.slot, sl.data(), sizeof(int32_t) * n_);
     upload(s.act, m.data(), n_);
-    ring_copy(s.ring_z, s.zmax, s.stage_z[b], s.zmax, s.zmax, false);
-    if (s.ead > 0) ring_copy(s.ring_ea, s.ead, s.stage_ea[b], s.ead, s.ead, false);
+    ring_copy(s.ring_z, (int64_t)pf_nmax_ * s.zmax, s.stage_z[b], (int64_t)pf_nmax_ * s.zmax, (int64_t)pf_nmax_ * s.zmax, false);
+    if (s.ead > 0) ring_copy(s.ring_ea, (int64_t)pf_nmax_ * s.ead, s.stage_ea[b], (int64_t)pf_nmax_ * s.ead, (int64_t)pf_nmax_ * s.ead, false);
   }
-  // masked predict + update of the filters in `act`, each to its own time, + their checkpoints (EKFSym::predict_and_update_batch's
-  // inner part, ekf_sym.cc:158-194, per filter)
-  void masked_step(const std::vector<double>& t, const std::vector<uint8_t>& act, int kind, int Z, double* z_dev, const double* R_dev,
-                   int r_per_filter, uint8_t* flags_dev, const double* ea_dev, const std::vector<int>& ridx) {
+  // masked predict + n updates of the filters in `act`, each to its own time, + ONE checkpoint each (EKFSym::predict_and_update_batch's
+  // inner part, ekf_sym.cc:158-194, per filter).  z_devs / R_devs / ea_devs: one entry per observation of the call; nobs_of (replay): filter i
+  // has only its first nobs_of[i] of them -- launch j is masked to the filters that have more than j.
+  void masked_step(const std::vector<double>& t, const std::vector<uint8_t>& act, int kind, int Z, const std::vector<double*>& z_devs,
+                   const std::vector<const double*>& R_devs, int r_per_filter, uint8_t* flags_dev, const std::vector<const double*>& ea_devs,
+                   const std::vector<std::vector<int>>& ridx, const std::vector<int32_t>* nobs_of) {
     PerFilter& s = pf_;
     const int K = rewind_to_keep_;
+    const int nobs = (int)z_devs.size();
     std::vector<double> dt(n_, 0.0);
     std::vector<int32_t> slot(n_, 0);
     for (int64_t i = 0; i < n_; i++) {
@@ -548,20 +608,34 @@ class EKFSymBatch {
         if (s.len[i] == K) s.head[i] = (s.head[i] + 1) % K; else s.len[i]++;
         slot[i] = (s.head[i] + s.len[i] - 1) % K;
         const size_t at = (size_t)slot[i] * n_ + i;
-        s.rt[at] = t[i]; s.rkind[at] = kind; s.rridx[at] = ridx[i];
+        const int ni = nobs_of ? (*nobs_of)[i] : nobs;
+        s.rt[at] = t[i]; s.rkind[at] = kind; s.rnobs[at] = ni;
+        for (int j = 0; j < ni; j++) s.rridx[at * pf_nmax_ + j] = ridx[j][i];
       }
     }
+    auto mask_of = [&](int j) {            // filters that take observation j of this call
+      std::vector<uint8_t> m(act);
+      if (nobs_of) for (int64_t i = 0; i < n_; i++) m[i] = (uint8_t)(act[i] && (*nobs_of)[i] > j);
+      return m;
+    };
     upload(s.dt, dt.data(), sizeof(double) * n_);
-    upload(s.act, act.data(), n_);
     const int ek = sym<int (*)(int)>("kind_eadim")(kind);
-    if (K > 0) {
-      upload(s.slot, slot.data(), sizeof(int32_t) * n_);
-      ring_copy(s.ring_z, s.zmax, z_dev, Z, Z, true);                  // the observation, before the kernel turns it into the residual
-      if (ek > 0 && ea_dev) ring_copy(s.ring_ea, s.ead, const_cast<double*>(ea_dev), ek, ek, true);
+    if (K > 0) upload(s.slot, slot.data(), sizeof(int32_t) * n_);
+    auto fused = sym<masked_fn>("batch_predict_update_" + std::to_string(kind) + "_masked");
+    auto upd = nobs > 1 ? sym<masked_update_fn>("batch_update_" + std::to_string(kind) + "_masked") : nullptr;
+    for (int j = 0; j < nobs; j++) {
+      if (j == 0 || nobs_of) { const std::vector<uint8_t> m = mask_of(j); upload(s.act, m.data(), n_); }
+      if (K > 0) {                          // the observation, before the kernel turns it into the residual
+        ring_copy(s.ring_z + (size_t)j * s.zmax, (int64_t)pf_nmax_ * s.zmax, z_devs[j], Z, Z, true);
+        if (ek > 0 && !ea_devs.empty()) ring_copy(s.ring_ea + (size_t)j * s.ead, (int64_t)pf_nmax_ * s.ead, const_cast<double*>(ea_devs[j]), ek, ek, true);
+      }
+      const double* ea = ea_devs.empty() ? nullptr : ea_devs[j];
+      uint8_t* fl = flags_dev ? flags_dev + (size_t)j * n_ : nullptr;
+      if (j == 0) check(fused(x_, P_, Q_, s.dt, 0.0, z_devs[0], R_devs[0], r_per_filter, ea, n_, norm_quats_, fl, s.act, stream_), "batch_predict_update_masked");
+      else check(upd(x_, P_, z_devs[j], R_devs[j], r_per_filter, ea, n_, norm_quats_, fl, s.act, stream_), "batch_update_masked");
     }
-    auto fn = sym<masked_fn>("batch_predict_update_" + std::to_string(kind) + "_masked");
-    check(fn(x_, P_, Q_, s.dt, 0.0, z_dev, R_dev, r_per_filter, ea_dev, n_, norm_quats_, flags_dev, s.act, stream_), "batch_predict_update_masked");
     if (K > 0) {
+      if (nobs_of && nobs > 1) upload(s.act, act.data(), n_);          // the state of EVERY filter of the call goes into its checkpoint
       ring_copy(s.ring_x, D_, x_, D_, D_, true);
       ring_copy(s.ring_P, (int64_t)E_ * E_, P_, (int64_t)E_ * E_, (int64_t)E_ * E_, true);
     }
@@ -606,6 +680,7 @@ class EKFSymBatch {
   double *x_ = nullptr, *P_ = nullptr, *Q_ = nullptr, *R_ = nullptr;
   double filter_time_ = NAN;
   int rewind_to_keep_ = 0;
+  int pf_nmax_ = 1;                  // observations a per-filter ring entry can hold (set_max_observations_per_call)
   double max_rewind_age_ = 1.0;
   std::deque<Checkpoint> ring_;
   std::vector<Checkpoint> spare_;

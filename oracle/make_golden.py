@@ -569,7 +569,46 @@ def multi_obs_goldens():
         yB[i, j, m, :len(y)] = y
       x1B[i, j], P1B[i, j] = ret[0], ret[2]
       xB[i, j], PB[i, j] = f.state(), f.covs()
-  np.savez_compressed(os.path.join(GOLD, "multi_obs.npz"), A_t=tA, A_kind=kA, A_n=nA, A_z=zA, A_Rscale=sA, A_y=yA, A_x=xA, A_P=PA,
+  # ---- part C: per-filter logs like part A, but the noise of observation m of a call is the kind's matrix times SCALE_C[m] for every filter -- what a
+  # caller with one noise matrix per observation shared by the batch passes (the C++ per-filter entry point takes host matrices)
+  SCALE_C = np.array([1.0, 0.5, 2.0])
+  NC, TC = 6, 30
+  tC = np.zeros((NC, TC)); kC = np.zeros((NC, TC), dtype=np.int32); nC = np.zeros((NC, TC), dtype=np.int32)
+  zC = np.zeros((NC, TC, NM, 3)); yC = np.zeros((NC, TC, NM, 3)); xC = np.empty((NC, TC, 9)); PC = np.empty((NC, TC, 9, 9)); lateC = np.zeros(NC, dtype=np.int32)
+  for i in range(NC):
+    f = ref_filter("kinematic9", K9.Q, K9.initial_x, np.diag(K9.initial_P_diag), 9, 9)
+    tr = np.array([0.5, 0.5, 0.5, 1.0, -0.5, 0.2, 0.3, 0.1, -0.2]) + rng.normal(size=9) * 0.05
+    times = np.cumsum(rng.uniform(0.01, 0.05, size=TC)) + rng.uniform(0, 0.3)
+    late_at = int(rng.integers(6, TC - 2))
+    back = int(rng.integers(2, 5))
+    times[late_at] = 0.5 * (times[late_at - back] + times[late_at - back + 1])
+    lateC[i] = late_at
+    for j in range(TC):
+      t = float(times[j])
+      k = int(rng.integers(1, 4))
+      n = int(rng.integers(1, 4))
+      if j == late_at:
+        n = max(n, 2)
+      p = tr[0:3] + t * tr[3:6] + 0.5 * t * t * tr[6:9]; v = tr[3:6] + t * tr[6:9]
+      Z = K9.obs_noise[k].shape[0]
+      zs, Rs = [], []
+      for m in range(n):
+        sc = float(SCALE_C[m])
+        if k == 1:
+          z = p + rng.normal(size=3) * 0.1 * np.sqrt(sc)
+        elif k == 2:
+          z = np.array([np.linalg.norm(p - np.array(ANCHOR))]) + rng.normal(size=1) * 0.2 * np.sqrt(sc)
+        else:
+          z = v + rng.normal(size=3) * 0.3 * np.sqrt(sc)
+        zs.append(z); Rs.append(K9.obs_noise[k] * sc)
+        zC[i, j, m, :Z] = z
+      ret = f.predict_and_update_batch(t, k, np.array(zs), np.array(Rs), [[]] * n)
+      assert ret is not None and len(ret[6]) == n
+      tC[i, j], kC[i, j], nC[i, j] = t, k, n
+      for m in range(n):
+        yC[i, j, m, :Z] = np.ravel(ret[6][m])
+      xC[i, j], PC[i, j] = f.state(), f.covs()
+  np.savez_compressed(os.path.join(GOLD, "multi_obs.npz"), C_t=tC, C_kind=kC, C_n=nC, C_z=zC, C_y=yC, C_x=xC, C_P=PC[:, ::5], C_late=lateC, C_scale=SCALE_C, A_t=tA, A_kind=kA, A_n=nA, A_z=zA, A_Rscale=sA, A_y=yA, A_x=xA, A_P=PA,
                       A_xk_km1=x1A[:, ::6], A_Pk_km1=P1A[:, ::6], A_xk_k=xkA[:, ::6], A_Pk_k=PkA[:, ::6], A_late=lateA,
                       B_t=tB, B_kind=kB, B_n=nB, B_z=zB, B_ea=eaB, B_y=yB, B_x=xB, B_P=PB, B_xk_km1=x1B[:, ::4], B_Pk_km1=P1B[:, ::4])
   print("multi-observation calls: part A", NB, "x", TB, "calls,", int(nA.sum()), "observations, late calls at", lateA.tolist(),

@@ -168,6 +168,72 @@ static int run_multi(const char* dir, const char* stream, int64_t n) {
   return 0;
 }
 
+// Timelines-multi mode: per-filter logs whose calls carry 1-3 observations (tests/golden/multi_obs.npz part C; the noise of observation m of a call is the
+// kind's matrix x scale[m] for every filter).  File: Q (81), x0 (9), P0 (81), R of kinds 1 / 2 / 3 (9 + 1 + 9), scale (3), "N T", then per arrival N lines
+// "t kind n z(9)".  One group of masked launches per (kind, n) present at an arrival.  Prints per arrival and filter: filter time, x (9), residuals (9).
+static int run_timelines_multi(const char* dir, const char* stream) {
+  std::ifstream in(stream);
+  std::vector<double> Q(81), x0(9), P0(81), R1(9), R2(1), R3(9), scale(3);
+  for (auto* v : {&Q, &x0, &P0, &R1, &R2, &R3, &scale}) for (double& e : *v) in >> e;
+  int64_t n; int T;
+  in >> n >> T;
+  rednose_amd::EKFSymBatch kf(dir, "kinematic9", Q, x0, P0, n, false, nullptr, 64, 1.0);
+  kf.set_max_observations_per_call(3);
+  std::vector<double*> zbuf(3, nullptr);
+  for (auto& p : zbuf) if (hipMalloc((void**)&p, sizeof(double) * n * 3 + 16) != hipSuccess) return 3;
+  for (int a = 0; a < T; a++) {
+    std::vector<double> ts(n), zz((size_t)n * 9), yy((size_t)n * 9, 0.0);
+    std::vector<int> kd(n), no(n);
+    for (int64_t i = 0; i < n; i++) { in >> ts[i] >> kd[i] >> no[i]; for (int e = 0; e < 9; e++) in >> zz[i * 9 + e]; }
+    for (int k = 1; k <= 3; k++) {
+      const int Z = kf.zdim(k);
+      const std::vector<double>& Rk = k == 1 ? R1 : (k == 2 ? R2 : R3);
+      for (int m = 1; m <= 3; m++) {
+        std::vector<uint8_t> act(n, 0);
+        bool any = false;
+        for (int64_t i = 0; i < n; i++) { act[i] = (uint8_t)(kd[i] == k && no[i] == m); any = any || act[i]; }
+        if (!any) continue;
+        std::vector<std::vector<double>> Rs(m);
+        std::vector<double*> zs;
+        std::vector<const double*> Rp;
+        for (int o = 0; o < m; o++) {
+          std::vector<double> host((size_t)n * Z, 0.0);
+          for (int64_t i = 0; i < n; i++) for (int e = 0; e < Z; e++) host[i * Z + e] = zz[i * 9 + o * 3 + e];
+          if (hipMemcpy(zbuf[o], host.data(), sizeof(double) * n * Z, hipMemcpyHostToDevice) != hipSuccess) return 3;
+          Rs[o] = Rk;
+          for (double& e : Rs[o]) e *= scale[o];
+          zs.push_back(zbuf[o]);
+          Rp.push_back(Rs[o].data());
+        }
+        if (kf.predict_and_update_batch_per_filter(ts.data(), act.data(), k, zs, Rp) != 0) return 5;
+        kf.synchronize();
+        for (int o = 0; o < m; o++) {
+          std::vector<double> host((size_t)n * Z);
+          if (hipMemcpy(host.data(), zbuf[o], sizeof(double) * n * Z, hipMemcpyDeviceToHost) != hipSuccess) return 3;
+          for (int64_t i = 0; i < n; i++) if (act[i]) for (int e = 0; e < Z; e++) yy[i * 9 + o * 3 + e] = host[i * Z + e];
+        }
+      }
+    }
+    kf.synchronize();
+    const std::vector<double> x = kf.state();
+    for (int64_t i = 0; i < n; i++) {
+      std::printf("%.17g", kf.filter_times()[i]);
+      for (int e = 0; e < 9; e++) std::printf(" %.17g", x[i * 9 + e]);
+      for (int e = 0; e < 9; e++) std::printf(" %.17g", yy[i * 9 + e]);
+      std::printf("\n");
+    }
+  }
+  bool threw = false;      // more observations than the rings were sized for
+  try {
+    std::vector<double> ts(n, 1e3);
+    kf.predict_and_update_batch_per_filter(ts.data(), nullptr, 1, std::vector<double*>{zbuf[0], zbuf[1], zbuf[2], zbuf[0]},
+                                           std::vector<const double*>{R1.data(), R1.data(), R1.data(), R1.data()});
+  } catch (const std::runtime_error&) { threw = true; }
+  std::printf("too_many_threw %d\n", threw ? 1 : 0);
+  for (auto p : zbuf) (void)hipFree(p);
+  return 0;
+}
+
 // Globals mode: set_global / get_extra_routine on a model generated with global_vars (tests/test_global_vars.py's gv_runtime)
 static int run_globals(const char* dir) {
   rednose_amd::EKFSymBatch kf(dir, "gv_runtime", {0.01, 0.0, 0.0, 4.0}, {0.5, 0.3}, {1.0, 0.0, 0.0, 1.0}, 3);
@@ -195,6 +261,7 @@ int main(int argc, char** argv) {
     if (argc >= 5 && std::string(argv[4]) == "robustness") return run_robustness(argv[1]);
     if (argc >= 5 && std::string(argv[4]) == "timelines") return run_timelines(argv[1], argv[2], n);
     if (argc >= 5 && std::string(argv[4]) == "multi") return run_multi(argv[1], argv[2], n);
+    if (argc >= 5 && std::string(argv[4]) == "timelines_multi") return run_timelines_multi(argv[1], argv[2]);
     rednose_amd::EKFSymBatch kf(argv[1], "kinematic", {0.1 * 0.1, 0.0, 0.0, 2.0 * 2.0}, {0.5, 0.0}, {1.0, 0.0, 0.0, 1.0}, n);
     std::ifstream in(argv[2]);
     std::vector<double> zs(n);

@@ -1118,9 +1118,9 @@ def test_register_broadcast_smoother_on_the_host_live(tmp_path):
 
 
 @pytest.mark.timeout(900, method="thread")
-@pytest.mark.parametrize("name", ["rand8", "randz10", "rand11", "rand17"])
+@pytest.mark.parametrize("name", ["rand8", "rand17"])      # (randz10 and rand11 run on the GPU: tests/test_gpu_random.py::test_smoother_many_shapes; here they cost 20 s of the CPU suite)
 def test_register_broadcast_smoother_on_the_host_one_row_per_lane(tmp_path, name):
-  """k_rts4 on the small test models -- ONE row slot (8 / 10 / 11 error states) and two (17) --: a numpy restatement of ekf_sym.py:651-690 on the
+  """k_rts4 on the small test models -- ONE row slot (8 error states) and two (17, an odd count) --: a numpy restatement of ekf_sym.py:651-690 on the
   oracle's f / F, every filter and step; the newest pair passed in (x_last, P_last) and recomputed; in place (Ps == Pf).  Two of the
   time differences are exactly 0: those steps take the identity-gain path (Ck = I), which the restatement's np.linalg.solve reproduces to
   rounding.  The odd state counts have records of an odd number of doubles: the ragged second tile (3 of 7 filters) ends on a lone double."""

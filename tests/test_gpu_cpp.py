@@ -161,6 +161,40 @@ def test_cpp_orchestrator_n_observations_per_call(tmp_path, filt):
 
 
 @pytest.mark.gpu
+def test_cpp_per_filter_timelines_with_n_observations_per_call(tmp_path):
+  """predict_and_update_batch_per_filter with vectors of observations: 6 filters on their own clocks, calls of 1-3 observations (one noise matrix per
+  observation, shared by the batch), ring entries that hold whole calls, one late multi-observation call per filter that rewinds over 2-4 such
+  entries and replays them with all their observations -- against the reference instances fed the same logs (tests/golden/multi_obs.npz part C)."""
+  from examples import ensure_generated
+  from examples.kinematic9_kf import Kinematic9Kalman as K9
+  gen = ensure_generated(["kinematic9"])
+  g = golden("multi_obs.npz")
+  NC, TC = g["C_t"].shape
+  stream = tmp_path / "timelines_multi.txt"
+  num = lambda a: " ".join(repr(float(v)) for v in np.ravel(a))      # noqa: E731
+  with open(stream, "w", encoding="utf-8") as f:
+    f.write("\n".join([num(K9.Q), num(K9.initial_x), num(np.diag(K9.initial_P_diag)), num(K9.obs_noise[1]), num(K9.obs_noise[2]), num(K9.obs_noise[3]),
+                       num(g["C_scale"]), f"{NC} {TC}"]) + "\n")
+    for j in range(TC):
+      for i in range(NC):
+        f.write(f"{float(g['C_t'][i, j])!r} {int(g['C_kind'][i, j])} {int(g['C_n'][i, j])} " + num(g["C_z"][i, j]) + "\n")
+  out = subprocess.run([_build(), gen, str(stream), "0", "timelines_multi"], check=True, capture_output=True, text=True).stdout.strip().split("\n")
+  assert out[-1] == "too_many_threw 1" and len(out) == NC * TC + 1
+  rows = np.array([[float(v) for v in line.split()] for line in out[:-1]]).reshape(TC, NC, 19)
+  assert any((np.diff(g["C_t"][i]) < 0).any() for i in range(NC)), "the logs must contain late calls"
+  for j in range(TC):
+    for i in range(NC):
+      k, n = int(g["C_kind"][i, j]), int(g["C_n"][i, j])
+      Z = K9.obs_noise[k].shape[0]
+      assert np.abs(rows[j, i, 1:10] - g["C_x"][i, j]).max() < 1e-8 * max(1.0, np.abs(g["C_x"][i, j]).max()), f"arrival {j} filter {i}: state"
+      got = rows[j, i, 10:].reshape(3, 3)[:n, :Z]
+      assert np.abs(got - g["C_y"][i, j, :n, :Z]).max() < 1e-7, f"arrival {j} filter {i}: residuals"
+  # filter times: the newest time each filter has seen so far (a late call leaves it where the replay ends)
+  for i in range(NC):
+    assert np.abs(rows[:, i, 0] - np.maximum.accumulate(g["C_t"][i])).max() < 1e-12
+
+
+@pytest.mark.gpu
 def test_cpp_set_global_and_extra_routine():
   import sympy as sp
   from rednose_amd.helpers.ekf_sym import gen_code

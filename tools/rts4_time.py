@@ -20,7 +20,11 @@ tx[:, :, 3:7] += 0.01 * torch.randn((T, n, 4), dtype=torch.float64, device=dev, 
 A = torch.randn((n, 22, 22), dtype=torch.float64, device=dev, generator=g) * 0.01
 P = torch.diag(torch.as_tensor(L.initial_P_diag, device=dev)) * 1e-2 + A @ A.transpose(1, 2)
 tP = P.repeat(T, 1, 1, 1).contiguous()
-ts = torch.as_tensor(np.arange(T) * 0.01, device=dev)
+if os.environ.get("RTS4_SCHED"):      # config 4's time stamps: gyro + accelerometer at the same tick, a position fix every tenth -- 1.1 of 2.1 steps have dt = 0
+  import bench
+  ts = torch.as_tensor(bench.live_schedule(T)[1], device=dev)
+else:
+  ts = torch.as_tensor(np.arange(T) * 0.01, device=dev)
 Q = torch.as_tensor(np.ascontiguousarray(L.Q), device=dev)
 ref = None
 vp = ctypes.c_void_p
