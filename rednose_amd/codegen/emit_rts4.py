@@ -6,13 +6,14 @@ Reference: the Python-only `EKF_sym.rts_smooth` (/root/reference/rednose/helpers
 with the predicted pair (xk1_k, Pk1_k) recomputed from the filtered one (templates/ekf_hip_rts.h explains the recursion's quirks,
 which are kept: start from the PREDICTED pair of the last step, in-place renormalisation of xk1_n).
 
-Why a fourth smoother.  `k_rts3` (emit_rts3.py) runs ONE wavefront per SIMD (two row sets of 132 registers each + an LDS image per
-filter) and takes every operand another lane owns through LDS: one 8-byte broadcast read feeds three FMAs, four wavefronts share a
-CU's LDS, and a lone wavefront issues an fp64 instruction every ~10 cycles (a dependent one every ~27-40): 0.25 of the HBM roofline
-for two rounds, whatever was moved inside it (profiles/tuning_notes.md).  CDNA3/4 have exactly one cross-lane form for fp64
+Why this layout.  Its predecessor `k_rts3` (the fused run's layout: 8 lanes x 3 rows per filter; deleted in round 6) ran ONE wavefront per
+SIMD (two row sets of 132 registers each + an LDS image per filter) and took every operand another lane owns through LDS: one 8-byte
+broadcast read feeds three FMAs, four wavefronts share a CU's LDS, and a lone wavefront issues an fp64 instruction every ~10 cycles (a
+dependent one every ~27-40): 0.25 of the HBM roofline for two rounds, whatever was moved inside it (profiles/tuning_notes.md).  CDNA3/4 have exactly one cross-lane form for fp64
 arithmetic: `v_fmac_f64_dpp ... row_newbcast:L` -- lane L of every 16-lane row feeds all 16 lanes of that row, at the plain FMA's
 issue rate (tools/dpp_probe.hip: 5.4-5.8 cycles per instruction with two wavefronts per SIMD, 6.5 alone; semantics checked there).
-So here a filter is ONE 16-LANE ROW (4 filters per wavefront), lane c owns rows c and c + 16 of every matrix, and
+So here a filter is ONE 16-LANE ROW (4 filters per wavefront), row r of every matrix lives in slot r // RS of lane r % RS (RS = rows per
+slot: 22 error states = 2 slots x 11 lanes), and
   * the right-looking L D L^T factorisation, both substitutions and both E^3 products read the other lanes' rows straight out of
     their registers: no LDS broadcast, no LDS round trip inside a dependent chain, 22 independent accumulation chains per pass;
   * the smoothed covariance of step k + 1 is CARRIED in registers (k_rts3 stored it and read it back: +11 % traffic, a wait for
@@ -35,6 +36,10 @@ The price: 22 of 32 row slots busy (k_rts3: 22 of 24), i.e. ~1.15 x the vector i
     CK <- I;  U = T Ck^T per row slot (operands: rows of Ck by row_newbcast); symmetric: slot 0 forms columns 0 .. 15 only
     I <- U (mirrored);  Pk_n = Pk_k + U: one coalesced read-add-write over the tile's records, the sum also goes back into I
     PS <- rows of I
+  step k with t[k + 1] == t[k] (models whose predict(0) is the identity; not the recursion's first step): Ck = I, see dt0_path() / kernel():
+    Pk_k HBM -> I;  xk_n = err(xk_k, inv_err(xk_k, xk1_n));  D <- PS - lower(Pk_k);  Pk_n = Pk_k + D row by row in place;  I -> HBM;  PS <- rows of I
+  `k_rts4_tri` (kernel(tri=True)): the same on a trace of PACKED lower triangles -- elements are scattered to / gathered from the images' lower
+  positions through a byte table of row indices in LDS.
 
 Generated for ordinary (non-MSCKF) lane-group models whose 4 images + vectors fit 20 KB of LDS (8 .. 22 error states, odd counts
 included: live, kinematic9); every other lane-group model -- MSCKF, more states, a dense F whose non-zeros do not fit the slot --
