@@ -23,7 +23,10 @@ digest of the library being timed -- a number measured on another build is not p
 (config 3) and its dt > 0 launch alone, the 2-state kinematic model step-granular and fused (K steps per launch, the default
 fast path for tiny models), the fused run of kinematic6 (bound by fp64 VALU issue: the fraction is of the vector fp64 issue
 rate), 1 M filters, kinematic9, the MSCKF model, and config 4 at its stated size: live with the Mahalanobis gate,
-16 384 filters x 2 100 steps, forward pass keeping the filtered trace + RTS backward pass, swept in batch chunks.
+16 384 filters x 2 100 steps, forward pass keeping the filtered trace + RTS backward pass, swept in batch chunks -- with
+`roofline_backward_dt_gt0` (the smoother on a chunk whose steps all advance time: no step takes the identity-gain path) and
+`packed_trace` (the same sweep with the opt-in packed-triangle trace between the passes) next to the stream's two objects.
+Every HBM-bound object carries `frac` (HIP events) and, where a host clock brackets the same launches, `frac_wall`.
 """
 import argparse
 import ctypes
