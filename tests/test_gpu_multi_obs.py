@@ -181,3 +181,44 @@ def test_multi_observation_call_equals_sequential_single_calls(gen):
   with pytest.raises(KalmanError):
     d.predict_and_update_batch(0.1, 1, z[:, :, :2].copy(), K9.obs_noise[1])              # wrong Z
   torch.cuda.synchronize()
+
+
+def test_corner_shapes_of_a_multi_observation_call(gen):
+  """n = 0 (the reference's loop body never runs: a predict and nothing else), per-filter noise (N, n, Z, Z) on the shared timeline (update
+  launches: the fused run takes one noise matrix per step), the same observations for every filter ((1, n, Z)), and the Estimate of the fused
+  and the step-granular service of one call."""
+  import torch
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  K9 = _k9()
+  rng = np.random.default_rng(9)
+  N, n = 21, 2
+  mk = lambda: BatchedEKF(gen, "kinematic9", K9.Q, K9.initial_x, np.diag(K9.initial_P_diag), 9, 9, batch=N)      # noqa: E731
+  a, b = mk(), mk()
+  for f in (a, b):
+    f.predict_and_update_batch(0.0, 1, np.tile(K9.initial_x[None, :3], (N, 1)), K9.obs_noise[1])
+  y0 = a.predict_and_update_batch(0.03, 1, np.zeros((N, 0, 3)), K9.obs_noise[1])
+  b.predict(0.03)
+  assert tuple(y0.shape) == (N, 0, 3) and np.array_equal(a.state(), b.state()) and np.array_equal(a.covs(), b.covs()) and a.filter_time == 0.03
+  # per-filter noise
+  z = K9.initial_x[None, None, :3] + rng.normal(size=(N, n, 3)) * 0.1
+  Rf = K9.obs_noise[1][None, None] * rng.uniform(0.5, 2.0, size=(N, n, 1, 1))
+  ya = a.predict_and_update_batch(0.05, 1, z.copy(), Rf)
+  b.predict_and_update_batch(0.05, 1, z[:, 0].copy(), Rf[:, 0])
+  yb1 = b.update(1, z[:, 1].copy(), Rf[:, 1])
+  assert np.array_equal(a.state(), b.state()) and np.array_equal(a.covs(), b.covs()) and np.array_equal(ya[:, 1].cpu().numpy(), yb1.cpu().numpy())
+  # (1, n, Z): the same observations for every filter
+  z1 = K9.initial_x[None, None, :3] + rng.normal(size=(1, n, 3)) * 0.1
+  c, d = mk(), mk()
+  c.predict_and_update_batch(0.0, 1, z1.copy(), K9.obs_noise[1])
+  d.predict_and_update_batch(0.0, 1, np.tile(z1, (N, 1, 1)), K9.obs_noise[1])
+  assert np.array_equal(c.state(), d.state()) and np.array_equal(c.covs(), d.covs())
+  # Estimate: fused (predict + one batch_run launch) against update launches
+  e, f_ = mk(), mk()
+  f_.multi_obs_fused = False
+  est = [g_.predict_and_update_batch(0.02, 1, z.copy(), K9.obs_noise[1], keep_estimate=True) for g_ in (e, f_)]
+  torch.cuda.synchronize()
+  assert np.array_equal(est[0][0].cpu().numpy(), est[1][0].cpu().numpy()) and np.array_equal(est[0][2].cpu().numpy(), est[1][2].cpu().numpy())      # predicted pair: the same launch
+  assert_close(est[0][1].cpu().numpy(), est[1][1].cpu().numpy(), rtol=1e-11, floor=1e-13, what="xk_k")
+  assert_close(est[0][3].cpu().numpy().reshape(N, -1), est[1][3].cpu().numpy().reshape(N, -1), rtol=1e-11, floor=1e-13, what="Pk_k")
+  assert len(est[0][6]) == n and tuple(est[0][7].shape) == (N, n, 3) and np.array_equal(est[0][7].cpu().numpy(), z)
+
