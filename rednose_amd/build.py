@@ -88,12 +88,12 @@ def compile_filter(folder, name, extra_flags=(), verbose=False):
   usage = kernel_resources(res.stderr)
   if any("k_rts4" in k for k in usage):      # inline-assembly DPP operands: hipcc's hazard pass does not see them (dpp_hazards)
     dis = disassemble(lib)
-    hz = dpp_hazards(dis) if dis is not None else []
     for k in usage:
-      if "k_rts4" in k:
+      if "k_rts4" in k:        # each kernel on its own (k_rts4, k_rts4_tri): <length><identifier>E of the Itanium mangling
+        hz = dpp_hazards(dis, kernel=f"{len(k)}{k}E") if dis is not None else []
         usage[k]["dpp_hazards"] = len(hz)
-    if hz and verbose:
-      print(f"note: k_rts4 has {len(hz)} DPP read-after-write hazard(s), first: {hz[0]}")
+        if hz and verbose:
+          print(f"note: {k} has {len(hz)} DPP read-after-write hazard(s), first: {hz[0]}")
   with open(os.path.join(folder, f"{name}.kernels.txt"), "w", encoding="utf-8") as f:
     f.write("# per-kernel resources reported by hipcc (-Rpass-analysis=kernel-resource-usage) for lib%s.so\n" % name)
     f.write("%-60s %6s %6s %8s %8s %7s %6s\n" % ("kernel", "vgprs", "agprs", "scratch", "lds", "spills", "occ"))
