@@ -431,6 +431,13 @@ def fused_run_extra(torch, model, n, T, dev):
     zc = zs.clone()
     f.init_state(M.initial_x, np.diag(M.initial_P_diag), 0.0)
     torch.cuda.synchronize()
+    # An untimed launch of the same entry point (16 steps) goes into the queue right in front of the first event: the timed launch then starts on a
+    # device that is awake -- a single 0.5 ms launch on a device that idled through init_state + synchronize carries 40-70 us of wake-up
+    # (top-level `cold_launch_us`), which is a property of the idle device, not of the kernel (rocprofv3 reads the kernel's own duration:
+    # profiles/r6_sections_kernel_trace.txt).  Its 16 steps are not counted.
+    zw = zs[:16].clone()
+    f._call("batch_run", f._p(f.x), f._p(f.P), f._p(f.Q), f._p(kd), f._p(dd), min(16, T), f._p(zw), f._p(Rd), n, f.norm_quats,      # pylint: disable=protected-access
+            None, None, None, None, None, f._stream())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     f._call("batch_run", f._p(f.x), f._p(f.P), f._p(f.Q), f._p(kd), f._p(dd), T, f._p(zc), f._p(Rd), n, f.norm_quats,      # pylint: disable=protected-access
@@ -455,7 +462,8 @@ def fused_run_extra(torch, model, n, T, dev):
     if roof["hbm_frac"] > roof["frac"]:          # the 2-state model: 16 B per filter-step against ~30 fp64 instructions
       roof.update(bound="hbm", achieved=roof["hbm_GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=roof["hbm_frac"])
   return {"model": M.name, "batch": n, "T": T, "value": rate, "unit": "steps/s", "ms": best, "hbm_bytes_moved": moved, "roofline": roof,
-          "note": "state resident in VGPRs for T steps (x / P cross HBM once per launch, z / y once per step); priced against fp64 VALU issue "
+          "note": "state resident in VGPRs for T steps (x / P cross HBM once per launch, z / y once per step); one timed launch behind an untimed 16-step launch of "
+                  "the same entry point (device awake); priced against fp64 VALU issue "
                   "(every v_*_f64 instruction of the kernel, llvm-objdump, per step of its unrolled loop) and against the HBM "
                   "bytes of z / y; `bound` names the larger fraction"}
 
