@@ -20,6 +20,146 @@ from conftest import assert_close
 HDR = os.path.join(os.path.dirname(__file__), "..", "rednose_amd", "templates", "ekf_hip_rt.h")
 pytestmark = pytest.mark.timeout(180, method="thread")      # the lane emulations below wait on barriers: a mismatch must fail, not hang
 
+# The lanes of an emulated wavefront (workgroup) are FIBERS of one OS thread, not threads: a barrier between 64 threads on a handful of cores is
+# a round of futex sleeps (~0.2 ms; the smoother's emulation executes ~6 000 of them per step), between fibers it is 64 stack switches.  The
+# translation units keep the pthread spelling; this text replaces <pthread.h>: pthread_create registers a fiber, the first pthread_join runs them
+# all, pthread_barrier_wait blocks the caller until its barrier is complete, sched_yield hands over.  WHICH runnable fiber continues is drawn
+# from a seeded generator at every hand-over, so between two barriers the lanes run whole, in an arbitrary order: a read that is not separated by
+# a barrier from another lane's write (or a write from another lane's read) sees the wrong value for about half of the lane pairs -- sharper than
+# preemptive threads running in near-lockstep, and the same on every run.
+_FIBERS = r"""
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cstdint>
+#include <sys/mman.h>
+extern "C" void rn_fib_switch(void** save_sp, void* load_sp) __attribute__((visibility("hidden")));
+asm(R"ASM(
+.text
+.hidden rn_fib_switch
+.globl rn_fib_switch
+.type rn_fib_switch,@function
+rn_fib_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size rn_fib_switch,.-rn_fib_switch
+)ASM");
+namespace fib {
+constexpr int MAXF = 256, LOCAL = 128;
+constexpr size_t STACK = size_t(2) << 20;
+struct Fiber { void* sp; void* (*fn)(void*); void* arg; bool done, blocked; char local[LOCAL]; };
+struct Local { void* p; int n, off; };
+static Fiber g_f[MAXF + 1];                    // [MAXF]: the caller's context
+static Local g_loc[16];
+static int g_nloc = 0, g_locbytes = 0, g_n = 0, g_cur = MAXF, g_alive = 0;
+static char* g_stacks = nullptr;
+static uint32_t g_rng = 2463534242u;
+struct RegisterLocal { RegisterLocal(void* p, int n) { g_loc[g_nloc++] = Local{p, n, g_locbytes}; g_locbytes += (n + 7) & ~7; if (g_locbytes > LOCAL || g_nloc > 16) abort(); } };
+static void to(int nx) {                       // fiber-local variables travel with their fiber
+  const int me = g_cur;
+  if (nx == me) return;
+  for (int i = 0; i < g_nloc; i++) { std::memcpy(g_f[me].local + g_loc[i].off, g_loc[i].p, g_loc[i].n); std::memcpy(g_loc[i].p, g_f[nx].local + g_loc[i].off, g_loc[i].n); }
+  g_cur = nx;
+  rn_fib_switch(&g_f[me].sp, g_f[nx].sp);
+}
+static int pick() {
+  int runnable = 0;
+  for (int i = 0; i < g_n; i++) runnable += !g_f[i].done && !g_f[i].blocked;
+  if (!runnable) { std::fprintf(stderr, "host emulation: every lane waits at a barrier that cannot complete\n"); abort(); }
+  g_rng ^= g_rng << 13; g_rng ^= g_rng >> 17; g_rng ^= g_rng << 5;
+  int k = (int)(g_rng % (uint32_t)runnable);
+  for (int i = 0; i < g_n; i++) if (!g_f[i].done && !g_f[i].blocked && k-- == 0) return i;
+  return -1;
+}
+static void yield() { to(pick()); }
+static void entry() {
+  Fiber& me = g_f[g_cur];
+  me.fn(me.arg);
+  me.done = true;
+  to(--g_alive == 0 ? MAXF : pick());
+  abort();
+}
+static void spawn(void* (*fn)(void*), void* arg) {
+  if (!g_stacks) g_stacks = static_cast<char*>(mmap(nullptr, STACK * MAXF, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0));
+  if (g_stacks == MAP_FAILED || g_n >= MAXF) abort();
+  Fiber& f = g_f[g_n];
+  f.fn = fn; f.arg = arg; f.done = f.blocked = false;
+  std::memset(f.local, 0, LOCAL);
+  void** top = reinterpret_cast<void**>(g_stacks + STACK * (g_n + 1));      // 16-byte aligned; [-1]: where a return address would be, [-2]: entry, [-8 .. -3]: the six saved registers
+  top[-1] = nullptr; top[-2] = reinterpret_cast<void*>(&entry);
+  for (int i = 3; i <= 8; i++) top[-i] = nullptr;
+  f.sp = top - 8;
+  g_n++; g_alive++;
+}
+static void run_all() {
+  if (g_alive) to(pick());
+  g_n = 0;
+}
+struct Barrier { int need, count, waiting[MAXF]; };
+static void wait(Barrier* b) {
+  if (b->count + 1 == b->need) { for (int i = 0; i < b->count; i++) g_f[b->waiting[i]].blocked = false; b->count = 0; return; }
+  b->waiting[b->count++] = g_cur;
+  g_f[g_cur].blocked = true;
+  yield();
+}
+}  // namespace fib
+inline int fib_barrier_init(fib::Barrier* b, const void*, int n) { b->need = n; b->count = 0; return 0; }
+inline int fib_barrier_wait(fib::Barrier* b) { fib::wait(b); return 0; }
+inline int fib_barrier_destroy(fib::Barrier*) { return 0; }
+inline int fib_create(int* t, const void*, void* (*fn)(void*), void* arg) { *t = fib::g_n; fib::spawn(fn, arg); return 0; }
+inline int fib_join(int, void**) { fib::run_all(); return 0; }
+inline int fib_yield() { fib::yield(); return 0; }
+#define pthread_barrier_t fib::Barrier
+#define pthread_t int
+#define pthread_barrier_init fib_barrier_init
+#define pthread_barrier_wait fib_barrier_wait
+#define pthread_barrier_destroy fib_barrier_destroy
+#define pthread_create fib_create
+#define pthread_join fib_join
+#define sched_yield fib_yield
+"""
+
+
+
+def _once(build):
+  """A host library is built once per (builder, model, variant) and session: parametrisations of one test share the loaded object."""
+  import functools
+  libs = {}
+
+  @functools.wraps(build)
+  def cached(tmp_path, spec, *a, **kw):
+    key = (spec.name, spec.dim_x, spec.dim_err, tuple((k.kind, k.zdim, k.maha_test, k.maha_thresh) for k in spec.kinds), str(spec.f_sym), a, tuple(sorted(kw.items())))
+    if key not in libs:
+      libs[key] = build(tmp_path, spec, *a, **kw)
+    return libs[key]
+  return cached
+
+def _fiberize(src):
+  """The host translation unit with its lanes as fibers (_FIBERS): <pthread.h> / <sched.h> replaced, `thread_local` variables made fiber-local."""
+  assert "#include <pthread.h>" in src
+  src = src.replace("#include <pthread.h>", _FIBERS, 1).replace("#include <sched.h>", "")
+
+  def local(m):
+    names = [n.strip() for n in m.group(2).split(",")]
+    init = m.group(3) or ""
+    return f"static {m.group(1)} {', '.join(n + init for n in names)};" + "".join(f" static fib::RegisterLocal fib_local_{n}(&{n}, sizeof({n}));" for n in names)
+  src = re.sub(r"static thread_local (\w+) ([\w, ]+?)( = \w+)?;", local, src)
+  assert "thread_local" not in src
+  return src
+
 
 def _function_text(text, name):
   """Text of the function `name` of the runtime header, from its `template <...>` line (when it has one) to its closing brace."""
@@ -39,6 +179,7 @@ def _function_text(text, name):
       return text[start:i]
 
 
+@_once
 def _host_library(tmp_path, spec, sym=False):
   """sym=True: the `_sym` flavour the fused multi-step kernels call, behind the symmetrisation they apply when the state enters the
   registers (emit_small.predict_regs)."""
@@ -76,7 +217,7 @@ extern "C" int host_step_{k.kind}(double* gx, double* gP, const double* Q, doubl
                    "inline double safe_recip(const double d) { return 1.0 / d; }", "inline double safe_rsqrt(const double a) { return 1.0 / std::sqrt(a); }",
                    helpers, "}  // namespace rn"] + body + entry)
   cpp, lib = tmp_path / f"{spec.name}{sfx}_host.cpp", tmp_path / f"lib{spec.name}{sfx}_host.so"
-  cpp.write_text(src, encoding="utf-8")
+  cpp.write_text(_fiberize(src) if "#include <pthread.h>" in src else src, encoding="utf-8")
   res = subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", str(cpp), "-o", str(lib)], capture_output=True, text=True)
   assert res.returncode == 0, res.stderr[-3000:]
   return ctypes.CDLL(str(lib))
@@ -159,6 +300,7 @@ def test_generated_lane_per_filter_arithmetic_on_the_host(tmp_path, name, sym):
 # register-lean structure with rows of P in LDS).
 
 
+@_once
 def _wide_host_library(tmp_path, spec):
   from rednose_amd.codegen import emit_wide2, tuning
   hdr = open(HDR, encoding="utf-8").read()
@@ -218,8 +360,8 @@ extern "C" int host_wide_step_{k.kind}(double* x, double* P, const double* Q, do
                    "inline void wave_lds_sync() { if (g_sync_on) pthread_barrier_wait(&g_bar); }      // device: a compiler fence inside one wavefront",
                    "inline double fast_recip(const double d) { return 1.0 / d; }", "inline double fast_rsqrt(const double a) { return 1.0 / std::sqrt(a); }", "inline double safe_recip(const double d) { return 1.0 / d; }", "inline double safe_rsqrt(const double a) { return 1.0 / std::sqrt(a); }", helpers, "}  // namespace rn"] + fns + entry)
   cpp, lib = tmp_path / f"{spec.name}_wide_host.cpp", tmp_path / f"lib{spec.name}_wide_host.so"
-  cpp.write_text(src, encoding="utf-8")
-  res = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", str(cpp), "-o", str(lib)], capture_output=True, text=True)
+  cpp.write_text(_fiberize(src) if "#include <pthread.h>" in src else src, encoding="utf-8")
+  res = subprocess.run(["g++", "-O0", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", str(cpp), "-o", str(lib)], capture_output=True, text=True)
   assert res.returncode == 0, res.stderr[-3000:]
   return ctypes.CDLL(str(lib)), kinds
 
@@ -306,6 +448,7 @@ def test_generated_lane_group_step_on_the_host(tmp_path, name):
 # (general Q read through a pointer, diagonal Q in registers) run the same schedule.
 
 
+@_once
 def _run_host_library(tmp_path, spec):
   from rednose_amd.codegen import emit_wide2 as w2, emit_wide3 as w3, tuning
   hdr = open(HDR, encoding="utf-8").read()
@@ -388,8 +531,8 @@ extern "C" void host_run(double* x, double* P, const double* Q, const double* R,
   for (int i = 0; i < {E * E}; i++) P[i] = sP[i];
 }}"""])
   cpp, lib = tmp_path / f"{spec.name}_run_host.cpp", tmp_path / f"lib{spec.name}_run_host.so"
-  cpp.write_text(src, encoding="utf-8")
-  res = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", str(cpp), "-o", str(lib)], capture_output=True, text=True)
+  cpp.write_text(_fiberize(src) if "#include <pthread.h>" in src else src, encoding="utf-8")
+  res = subprocess.run(["g++", "-O0", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas", str(cpp), "-o", str(lib)], capture_output=True, text=True)
   assert res.returncode == 0, res.stderr[-3000:]
   return ctypes.CDLL(str(lib)), kinds, zmax
 
@@ -511,6 +654,7 @@ inline double safe_rsqrt(const double a) { return 1.0 / std::sqrt(a); }
 """
 
 
+@_once
 def _kernel_host_library(tmp_path, spec):
   from rednose_amd.codegen import emit_small
   hdr = open(HDR, encoding="utf-8").read()
@@ -547,8 +691,8 @@ extern "C" __attribute__((visibility("default"))) void host_step(int grid, doubl
                    "template <int EPF> inline void tile_g2l_async(const double* g, int cnt, double* lds, int lane) { tile_g2l<EPF>(g, cnt, lds, lane); }",
                    "}  // namespace rn", text, launch])
   cpp, lib = tmp_path / f"{spec.name}_kernels_host.cpp", tmp_path / f"lib{spec.name}_kernels_host.so"
-  cpp.write_text(src, encoding="utf-8")
-  res = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fno-gnu-unique", "-fvisibility=hidden", "-Wno-unknown-pragmas", "-Wno-attributes", str(cpp), "-o", str(lib)],
+  cpp.write_text(_fiberize(src) if "#include <pthread.h>" in src else src, encoding="utf-8")
+  res = subprocess.run(["g++", "-O0", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fno-gnu-unique", "-fvisibility=hidden", "-Wno-unknown-pragmas", "-Wno-attributes", str(cpp), "-o", str(lib)],
                        capture_output=True, text=True)
   assert res.returncode == 0, res.stderr[-4000:]
   return ctypes.CDLL(str(lib)), zmax
@@ -707,6 +851,7 @@ inline void sched_barrier_(int) {}
 """
 
 
+@_once
 def _wide_kernel_host_library(tmp_path, spec):
   from rednose_amd.codegen import emit_wide2, tuning
   hdr = open(HDR, encoding="utf-8").read()
@@ -731,8 +876,8 @@ extern "C" __attribute__((visibility("default"))) void host_wide_kernel_{k.kind}
   prelude = _KERNEL_PRELUDE.replace("inline void pin(double&) {}", "inline void pin(double&) {}\n" + _WIDE_COPIES)
   src = "\n".join([prelude, helpers, "}  // namespace rn", text, _RUN_GRID] + entries)
   cpp, lib = tmp_path / f"{spec.name}_wide_kernels_host.cpp", tmp_path / f"lib{spec.name}_wide_kernels_host.so"
-  cpp.write_text(src, encoding="utf-8")
-  res = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fno-gnu-unique", "-fvisibility=hidden", "-Wno-unknown-pragmas", "-Wno-attributes",
+  cpp.write_text(_fiberize(src) if "#include <pthread.h>" in src else src, encoding="utf-8")
+  res = subprocess.run(["g++", "-O0", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fno-gnu-unique", "-fvisibility=hidden", "-Wno-unknown-pragmas", "-Wno-attributes",
                         str(cpp), "-o", str(lib)], capture_output=True, text=True)
   assert res.returncode == 0, res.stderr[-4000:]
   return ctypes.CDLL(str(lib)), kinds, FT
@@ -843,6 +988,7 @@ def _two_wave(text, nw=2):
   return text
 
 
+@_once
 def _wide_run_kernel_host_library(tmp_path, spec, variant="k_run"):
   from rednose_amd.codegen import emit_run2, emit_wide3, tuning
   hdr = open(HDR, encoding="utf-8").read()
@@ -876,8 +1022,8 @@ extern "C" __attribute__((visibility("default"))) void host_wide_run(int grid, d
     prelude, grid_text = _two_wave(prelude, nw), _two_wave(_RUN_GRID, nw)
   src = "\n".join([prelude, helpers, "}  // namespace rn", text, grid_text, entry])
   cpp, lib = tmp_path / f"{spec.name}_{variant}_host.cpp", tmp_path / f"lib{spec.name}_{variant}_host.so"
-  cpp.write_text(src, encoding="utf-8")
-  res = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fno-gnu-unique", "-fvisibility=hidden", "-Wno-unknown-pragmas", "-Wno-attributes",
+  cpp.write_text(_fiberize(src) if "#include <pthread.h>" in src else src, encoding="utf-8")
+  res = subprocess.run(["g++", "-O0", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fno-gnu-unique", "-fvisibility=hidden", "-Wno-unknown-pragmas", "-Wno-attributes",
                         str(cpp), "-o", str(lib)], capture_output=True, text=True)
   assert res.returncode == 0, res.stderr[-4000:]
   return ctypes.CDLL(str(lib)), FPW
@@ -1014,6 +1160,7 @@ inline void __builtin_amdgcn_global_load_lds(const void* g, void* lds_base, int 
 """
 
 
+@_once
 def _rts4_host_library(tmp_path, spec):
   from rednose_amd.codegen import emit_rts4, tuning
   from rednose_amd.codegen.emit_common import routine_device_function
@@ -1042,8 +1189,8 @@ extern "C" __attribute__((visibility("default"))) void host_rts4(int grid, const
   prelude = prelude.replace("namespace rn {", _WAVE_VOTES + _RTS4_HOST + "namespace rn {", 1)
   src = "\n".join([prelude, helpers, "}  // namespace rn", routines, text, _RUN_GRID, entry])
   cpp, lib = tmp_path / f"{spec.name}_rts4_host.cpp", tmp_path / f"lib{spec.name}_rts4_host.so"
-  cpp.write_text(src, encoding="utf-8")
-  res = subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fno-gnu-unique", "-fvisibility=hidden", "-Wno-unknown-pragmas", "-Wno-attributes",
+  cpp.write_text(_fiberize(src) if "#include <pthread.h>" in src else src, encoding="utf-8")
+  res = subprocess.run(["g++", "-O0", "-std=c++17", "-fPIC", "-shared", "-pthread", "-fno-gnu-unique", "-fvisibility=hidden", "-Wno-unknown-pragmas", "-Wno-attributes",
                         "-ffp-contract=off", str(cpp), "-o", str(lib)], capture_output=True, text=True)
   assert res.returncode == 0, res.stderr[-4000:]
   dll = ctypes.CDLL(str(lib))
