@@ -554,10 +554,10 @@ def config4_extra(torch, dev, rank, nb=16384, T=2100, chunk=8192):
     """PMC traffic of the 8 192 x 2 100 chunk launch (profiles/pmc_workload.py), times the chunks swept here (sum over launches, like the bytes)."""
     return traffic_kw(label, "live_maha", gen, scale=nb / chunk) if (chunk == 8192 and T == 2100) else dict(traffic=None)
 
-  try:          # the smoother kernel this library was built with (emit_rts4's k_rts4, its fallbacks: emit_rts3's k_rts3, the lane-group rn::k_rts_group)
+  try:          # the smoother kernel this library was built with (emit_rts4's k_rts4, or its fallback, the lane-group rn::k_rts_group)
     with open(os.path.join(gen, "live_maha.kernels.txt"), encoding="utf-8") as fh:
       kt = fh.read()
-      rts_kernel = "k_rts4" if "k_rts4" in kt else ("k_rts3" if "k_rts3" in kt else "rn::k_rts_group")
+      rts_kernel = "k_rts4" if "k_rts4" in kt else "rn::k_rts_group"
       run_kernel = "k_run2" if "k_run2 " in kt else "k_run"
   except OSError:
     rts_kernel, run_kernel = "k_rts*", "k_run*"

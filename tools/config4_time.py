@@ -1,6 +1,6 @@
 """Timing of ONE chunk of BASELINE config 4 (live_maha, 8 192 filters x 2 100 steps): forward fused run writing the filtered trace
 + gate flags, backward smoother in place -- what bench.py's config4_extra launches per chunk.  RN_GEN_DIR / RN_TUNE select an A/B
-build (e.g. RN_TUNE=nt_trace=1, RN_TUNE=rts3=0)."""
+build (e.g. RN_TUNE=rts_dt0=0: the full solve on every backward step); C4_PACKED=1: the packed-triangle trace."""
 import os
 import sys
 
