@@ -138,6 +138,48 @@ def test_degenerate_sizes(env):
   assert torch.equal(xs, tx) and torch.equal(Ps, tP)
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_degenerate_sizes_lane_group(env, packed):
+  """The two-wavefront fused run and the register-broadcast smoother (live: k_run2 / k_rts4 and their packed-triangle forms) on the smallest
+  inputs: an empty schedule, ONE step, a one-estimate and a two-estimate trace, one filter and a ragged tile -- each against the step-granular
+  path / the same call on a larger batch, none a crash."""
+  torch, gen = env
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  from examples.live_kf import LiveKalman as L
+  g = golden("live_stream.npz")
+  kinds, ts = g["kinds"].astype(np.int32), g["ts"]
+  Rs = {int(k): L.obs_noise[int(k)] for k in set(kinds.tolist())}
+  mk = lambda n: BatchedEKF(gen, "live", L.Q, L.initial_x, np.diag(L.initial_P_diag), 23, 22, batch=n, quaternion_idxs=[3])  # noqa: E731
+  il = np.tril_indices(22)
+  lower = (lambda P: P) if packed else (lambda P: P[..., il[0], il[1]])
+  ref = mk(9); ref.init_state(g["x0"], g["P0"], None)
+  zs9 = np.tile(g["zs"][:, None, :], (1, 9, 1))
+  _, rx, rP, _ = ref.run(ts[:6], kinds[:6], zs9[:6].copy(), Rs, trace=True, packed=packed)
+  sx, sP = ref.rts_smooth(rx, rP, ts[:6], packed=packed)
+  torch.cuda.synchronize()
+  for n in (1, 3):                                     # one filter; a ragged tile of the 8-filter fused run / the 4-filter smoother
+    f = mk(n); f.init_state(g["x0"], g["P0"], None)
+    x0 = f.state().copy()
+    ys, tx0, _, _ = f.run(np.zeros(0), np.zeros(0, dtype=np.int32), np.zeros((0, n, 3)), Rs, trace=True, packed=packed)      # T = 0
+    assert tuple(ys.shape)[0] == 0 and tx0 is None and np.array_equal(f.state(), x0)
+    _, tx, tP, _ = f.run(ts[:1], kinds[:1], zs9[:1, :n].copy(), Rs, trace=True, packed=packed)                                 # T = 1
+    torch.cuda.synchronize()
+    assert torch.equal(tx[0], rx[0, :n]) and torch.equal(tP[0], rP[0, :n])
+    assert np.array_equal(f.state(), tx[0].cpu().numpy())
+    x1, P1 = f.rts_smooth(tx, tP, ts[:1], packed=packed)                                                                     # one estimate: comes back
+    assert torch.equal(x1, tx) and torch.equal(P1, tP)
+    _, tx5, tP5, _ = f.run(ts[1:6], kinds[1:6], zs9[1:6, :n].copy(), Rs, trace=True, packed=packed)
+    fx, fP = torch.cat([tx, tx5]), torch.cat([tP, tP5])
+    assert torch.equal(fx, rx[:, :n]) and torch.equal(fP, rP[:, :n])                                                         # a run continued = the run
+    x6, P6 = f.rts_smooth(fx, fP, ts[:6], packed=packed)
+    assert torch.equal(x6, sx[:, :n]) and np.array_equal(lower(P6.cpu().numpy()), lower(sP[:, :n].cpu().numpy()))
+    x2, P2 = f.rts_smooth(fx[4:], fP[4:], ts[4:6], packed=packed)                                                            # two estimates: one backward step
+    torch.cuda.synchronize()
+    assert torch.equal(x2[1], x6[5]) and np.array_equal(lower(P2[1].cpu().numpy()), lower(P6[5].cpu().numpy()))
+    assert_close(x2[0].cpu().numpy(), x6[4].cpu().numpy(), rtol=1e-13, floor=1e-15, what="two-estimate smoothing, oldest state")
+    assert_close(lower(P2[0].cpu().numpy()).reshape(n, -1), lower(P6[4].cpu().numpy()).reshape(n, -1), rtol=1e-13, floor=1e-15, what="two-estimate smoothing, oldest covariance")
+
+
 def test_million_filter_batch_properties(env):
   """Beyond the 256 MiB Infinity Cache (755 MB of state): grid-stride path, every filter identical -> results identical."""
   torch, gen = env
