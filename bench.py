@@ -27,6 +27,7 @@ rate), 1 M filters, kinematic9, the MSCKF model, and config 4 at its stated size
 `roofline_backward_dt_gt0` (the smoother on a chunk whose steps all advance time: no step takes the identity-gain path) and
 `packed_trace` (the same sweep with the opt-in packed-triangle trace between the passes) next to the stream's two objects.
 Every HBM-bound object carries `frac` (HIP events) and, where a host clock brackets the same launches, `frac_wall`.
+`scalar_abi`: microseconds per predict + update of ONE filter through the reference's scalar host-pointer entry points (a latency, not part of any rate).
 """
 import argparse
 import ctypes
@@ -408,6 +409,44 @@ def run_model(torch, dist, model, n, K, W, dev, rank, world, only_kind=None):
               kinds=sorted(set(s[0] for s in sched[W:W + K])), steady=steady, cold_launch_us=cold_us,
               launch_us_median=float(np.median(groups)) if groups else None, launch_us_groups=len(groups),
               group_us=[round(g_, 3) for g_ in groups] if os.environ.get("RN_BENCH_MARK_EVERY") else None)
+
+
+def scalar_abi_extra(gen):
+  """The drop-in boundary for ONE filter: the reference's scalar host-pointer ABI ({name}_predict + {name}_update_{kind}, what rednose's EKF_sym
+  binds: rednose/helpers/ekf_sym.py:149-165) as a batch of one on the GPU -- host buffers in, host buffers out, PCIe and the launch / wait
+  latency included.  Microseconds per predict + update; not a throughput figure."""
+  import ctypes
+  import time
+  from examples.kinematic_kf import KinematicKalman as K
+  from examples.live_kf import LiveKalman as L
+  dp = ctypes.POINTER(ctypes.c_double)
+  ptr = lambda a: a.ctypes.data_as(dp)      # noqa: E731
+  out = {}
+  for name, M, E, kind, Z in (("kinematic", K, 2, 1, 1), ("live", L, 22, 4, 3)):
+    lib = ctypes.CDLL(os.path.join(gen, f"lib{name}.so"))
+    pred, upd = getattr(lib, f"{name}_predict"), getattr(lib, f"{name}_update_{kind}")
+    pred.argtypes, pred.restype, upd.argtypes, upd.restype = [dp, dp, dp, ctypes.c_double], None, [dp] * 5, None
+    x0 = np.array(M.initial_x, dtype=np.float64)
+    P0 = np.eye(E) if name == "kinematic" else np.diag(np.asarray(M.initial_P_diag, dtype=np.float64))
+    Q, R = np.ascontiguousarray(M.Q, dtype=np.float64), np.ascontiguousarray(np.atleast_2d(M.obs_noise[kind]), dtype=np.float64)
+    x, P, z = x0.copy(), P0.copy(), np.zeros(Z)
+
+    def step():
+      x[:] = x0; P[:] = P0; z[:] = 0.0
+      pred(ptr(x), ptr(P), ptr(Q), 0.01)
+      upd(ptr(x), ptr(P), ptr(z), ptr(R), None)
+    for _ in range(100):
+      step()
+    t0 = time.perf_counter()
+    for _ in range(500):
+      step()
+    us = (time.perf_counter() - t0) / 500 * 1e6
+    if getattr(lib, f"{name}_last_error")() != 0:
+      raise RuntimeError(f"{name}: scalar ABI call failed")
+    out[name] = {"predict_plus_update_us": round(us, 2), "kind": kind}
+  out["note"] = ("one filter through the reference's scalar host-pointer entry points (two calls: predict, update), host buffers in / out, "
+                 "launch + wait + PCIe included; the arguments are packed into a pinned host buffer the kernels work on in place")
+  return out
 
 
 def fused_run_extra(torch, model, n, T, dev):
@@ -797,6 +836,7 @@ def main():
     extra["kinematic_fused"] = fused_run_extra(torch, "kinematic", 65536, 2000, dev)
     extra["fused_run"] = fused_run_extra(torch, "kinematic6", n, 500, dev)
     extra["feature36_msckf"] = msckf_extra(torch, dev)
+    extra["scalar_abi"] = scalar_abi_extra(gen_dir(["kinematic", "live"]))
     extra["live_maha_rts"] = config4_extra(torch, dev, rank)
 
   if rank == 0:

@@ -162,7 +162,7 @@ def _emit(spec):
     k_sig = ", ".join((f"const double* {n}" if kind == "ptr" else f"double {n}") for kind, n, _ in params)
     call = ", ".join(n for _, n, _ in params)
     src.append(f"__global__ void k_fn_{r.name}({k_sig}, double* out) {{ {r.name}({call}, out); }}")
-    # host wrapper: stage inputs in scratch, one single-thread launch, copy the output back
+    # host wrapper: arguments packed into the pinned staging buffer, one single-thread launch that works on it in place, the output unpacked
     offs, cur = {}, 0
     for n, sz in ptr_params:
       offs[n] = cur
@@ -175,10 +175,11 @@ def _emit(spec):
     for n, sz in ptr_params:
       if n.startswith("unused"):
         continue
-      w.append(f"  if (hipMemcpy(s.dev + {offs[n]}, {n}, {sz} * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {{ rn::fail(rn::ERR_HIP, (int)hipGetLastError(), \"H2D {r.name}\", __LINE__); return; }}")
+      w.append(f"  s.put({offs[n]}, {n}, {sz});")
     kargs = ", ".join((f"s.dev + {offs[n]}" if kind == "ptr" else n) for kind, n, _ in params)
     w.append(f"  hipLaunchKernelGGL(k_fn_{r.name}, dim3(1), dim3(1), 0, 0, {kargs}, s.dev + {out_off});")
-    w.append(f"  if (hipMemcpy(out, s.dev + {out_off}, {n_out} * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rn::fail(rn::ERR_HIP, (int)hipGetLastError(), \"D2H {r.name}\", __LINE__);")
+    w.append(f"  if (s.wait(\"{r.name}\", __LINE__) != rn::OK) return;")
+    w.append(f"  s.get(out, {out_off}, {n_out});")
     w.append("}")
     wrappers.append("\n".join(w))
     hdr.append(f"void {name}_{r.name}({c_sig}, double *out);")
@@ -479,16 +480,10 @@ void {name}_predict(double *in_x, double *in_P, double *in_Q, double dt) {{
   rn::Scratch& s = rn::scratch();
   std::lock_guard<std::mutex> hold(s.mu);
   if (s.ensure({Qo + _align2(EE)}) != rn::OK) return;
-  if (hipMemcpy(s.dev + {xo}, in_x, {D} * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(s.dev + {Po}, in_P, {EE} * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(s.dev + {Qo}, in_Q, {EE} * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {{
-    rn::fail(rn::ERR_HIP, (int)hipGetLastError(), "{name}_predict H2D", __LINE__);
-    return;
-  }}
+  s.put({xo}, in_x, {D}); s.put({Po}, in_P, {EE}); s.put({Qo}, in_Q, {EE});
   if ({name}_batch_predict(s.dev + {xo}, s.dev + {Po}, s.dev + {Qo}, nullptr, dt, 1, 0, nullptr) != rn::OK) return;
-  if (hipMemcpy(in_x, s.dev + {xo}, {D} * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemcpy(in_P, s.dev + {Po}, {EE} * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
-    rn::fail(rn::ERR_HIP, (int)hipGetLastError(), "{name}_predict D2H", __LINE__);
+  if (s.wait("{name}_predict", __LINE__) != rn::OK) return;
+  s.get(in_x, {xo}, {D}); s.get(in_P, {Po}, {EE});
 }}""")
   hdr.append(f"void {name}_predict(double *in_x, double *in_P, double *in_Q, double dt);")
   for k in spec.kinds:
@@ -498,25 +493,17 @@ void {name}_predict(double *in_x, double *in_P, double *in_Q, double dt) {{
     eo = Ro + _align2(Z * Z)
     EA = ea_len(k)
     tot = eo + _align2(EA)
-    ea_h2d = f"hipMemcpy(s.dev + {eo}, in_ea, {EA} * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||\n      " if EA else ""
+    ea_put = f" s.put({eo}, in_ea, {EA});" if EA else ""
     ea_arg = f"s.dev + {eo}" if EA else "nullptr"
     abi.append(f"""void {name}_update_{k.kind}(double *in_x, double *in_P, double *in_z, double *in_R, double *in_ea) {{
   (void)in_ea;
   rn::Scratch& s = rn::scratch();
   std::lock_guard<std::mutex> hold(s.mu);
   if (s.ensure({tot}) != rn::OK) return;
-  if ({ea_h2d}hipMemcpy(s.dev + {xo}, in_x, {D} * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(s.dev + {Po}, in_P, {EE} * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(s.dev + {zo}, in_z, {Z} * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(s.dev + {Ro}, in_R, {Z * Z} * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {{
-    rn::fail(rn::ERR_HIP, (int)hipGetLastError(), "{name}_update_{k.kind} H2D", __LINE__);
-    return;
-  }}
+  s.put({xo}, in_x, {D}); s.put({Po}, in_P, {EE}); s.put({zo}, in_z, {Z}); s.put({Ro}, in_R, {Z * Z});{ea_put}
   if ({name}_batch_update_{k.kind}(s.dev + {xo}, s.dev + {Po}, s.dev + {zo}, s.dev + {Ro}, 0, {ea_arg}, 1, 0, nullptr, nullptr) != rn::OK) return;
-  if (hipMemcpy(in_x, s.dev + {xo}, {D} * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemcpy(in_P, s.dev + {Po}, {EE} * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemcpy(in_z, s.dev + {zo}, {Z} * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
-    rn::fail(rn::ERR_HIP, (int)hipGetLastError(), "{name}_update_{k.kind} D2H", __LINE__);
+  if (s.wait("{name}_update_{k.kind}", __LINE__) != rn::OK) return;
+  s.get(in_x, {xo}, {D}); s.get(in_P, {Po}, {EE}); s.get(in_z, {zo}, {Z});
 }}""")
     hdr.append(f"void {name}_update_{k.kind}(double *in_x, double *in_P, double *in_z, double *in_R, double *in_ea);")
   abi += wrappers

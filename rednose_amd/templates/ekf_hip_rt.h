@@ -13,6 +13,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <mutex>
 #include <utility>
 #include <stdint.h>
@@ -749,21 +750,36 @@ __global__ void k_flags_set(uint8_t* __restrict__ flags, const uint8_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// host-side scratch for the single-filter host-pointer entry points
+// host-side staging for the single-filter host-pointer entry points (the reference's scalar ABI)
 // ------------------------------------------------------------------------------------------------
+// One buffer of PINNED host memory mapped into the device's address space: an entry point packs its arguments into `host` with memcpy,
+// launches the batch-of-one kernel on `dev` (the same bytes as the GPU addresses them: the kernel reads and writes host memory in place
+// over PCIe), waits for the null stream and unpacks.  No staging copies: seven blocking hipMemcpy calls of a few hundred bytes each made a
+// predict + update of ONE filter 193 us (81 + 112), whatever the model; profiles/r6_scalar_abi_latency.txt.
 struct Scratch {
   std::mutex mu;
+  double* host = nullptr;
   double* dev = nullptr;
   size_t cap = 0;   // doubles
   int ensure(size_t doubles) {
     if (doubles <= cap) return OK;
-    if (dev) (void)hipFree(dev);
-    dev = nullptr;
+    if (host) (void)hipHostFree(host);
+    host = dev = nullptr;
     cap = 0;
-    RN_HIP(hipMalloc(reinterpret_cast<void**>(&dev), doubles * sizeof(double)));
-    cap = doubles;
+    const size_t want = doubles < 4096 ? 4096 : doubles;
+    RN_HIP(hipHostMalloc(reinterpret_cast<void**>(&host), want * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    RN_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), host, 0));
+    cap = want;
     return OK;
   }
+  // the launches of the entry points go to the null stream; their results are in `host` once it has drained
+  int wait(const char* what, int line) {
+    const hipError_t e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) { fail(ERR_HIP, (int)e, what, line); return ERR_HIP; }
+    return OK;
+  }
+  void put(size_t off, const double* src, size_t n) { std::memcpy(host + off, src, n * sizeof(double)); }
+  void get(double* dst, size_t off, size_t n) const { std::memcpy(dst, host + off, n * sizeof(double)); }
 };
 
 inline Scratch& scratch() {
