@@ -292,7 +292,7 @@ class EKFSymBatch {
     std::vector<const double*> R_devs;
     for (int j = 0; j < nobs; j++) {
       ridx[j].assign(n_, rtable_index(R_hosts[j], Z));
-      hip(hipMemcpyAsync(R_ + (size_t)j * Z * Z, R_hosts[j], sizeof(double) * Z * Z, hipMemcpyHostToDevice, stream_), "copy R");
+      upload_R((size_t)j * Z * Z, R_hosts[j], (size_t)Z * Z);
       R_devs.push_back(R_ + (size_t)j * Z * Z);
     }
     masked_step(tt, act, kind, Z, z_devs, R_devs, 0, flags_dev, ea_devs, ridx, nullptr);
@@ -368,7 +368,7 @@ class EKFSymBatch {
   // Mahalanobis distance of an observation per filter into d2_dev (N), state untouched (EKF_sym.maha_test, ekf_sym.py:626-649)
   void maha_distance(int kind, const double* z_dev, const double* R_host, double* d2_dev, const double* ea_dev = nullptr) {
     const int Z = zdim_.at(kind);
-    hip(hipMemcpyAsync(R_, R_host, sizeof(double) * Z * Z, hipMemcpyHostToDevice, stream_), "copy R");
+    upload_R(0, R_host, (size_t)Z * Z);
     auto fn = sym<int (*)(const double*, const double*, const double*, const double*, int, const double*, int64_t, double*, void*)>(
         "batch_maha_" + std::to_string(kind));
     check(fn(x_, P_, z_dev, R_, 0, ea_dev, n_, d2_dev, stream_), "batch_maha");
@@ -436,7 +436,7 @@ class EKFSymBatch {
     }
     const double dt = advance(t);
     for (int i = 0; i < nobs; i++)
-      hip(hipMemcpyAsync(R_ + (size_t)i * Z * Z, R_hosts[i], sizeof(double) * Z * Z, hipMemcpyHostToDevice, stream_), "copy R");
+      upload_R((size_t)i * Z * Z, R_hosts[i], (size_t)Z * Z);
     int first_update = 1;
     if (estimate) {            // the predicted pair has to exist in memory: predict alone, then every observation as an update
       check(batch_predict_(x_, P_, Q_, nullptr, dt, n_, norm_quats_, stream_), "batch_predict");
@@ -648,9 +648,21 @@ class EKFSymBatch {
 
   template <class F>
   F sym(const std::string& suffix) const {
-    void* p = dlsym(handle_, (name_ + "_" + suffix).c_str());
-    if (!p) throw std::runtime_error("rednose_amd: lib" + name_ + ".so does not export " + name_ + "_" + suffix);
-    return reinterpret_cast<F>(p);
+    auto it = syms_.find(suffix);              // looked up once: a step-granular call is ~9 us of GPU time, dlsym + two string concatenations are not free beside it
+    if (it == syms_.end()) {
+      void* p = dlsym(handle_, (name_ + "_" + suffix).c_str());
+      if (!p) throw std::runtime_error("rednose_amd: lib" + name_ + ".so does not export " + name_ + "_" + suffix);
+      it = syms_.emplace(suffix, p).first;
+    }
+    return reinterpret_cast<F>(it->second);
+  }
+  // noise matrices go to the device staging buffer R_ only when they differ from what is there (the usual caller passes the same R for a kind on
+  // every call; a pageable host-to-device copy per call costs more host time than the launch it feeds)
+  void upload_R(size_t offset, const double* R_host, size_t count) {
+    if (r_mirror_.size() < offset + count) r_mirror_.resize(64 * 64, NAN);
+    if (std::equal(R_host, R_host + count, r_mirror_.begin() + offset)) return;       // (NaN never compares equal: the first call always uploads)
+    hip(hipMemcpyAsync(R_ + offset, R_host, sizeof(double) * count, hipMemcpyHostToDevice, stream_), "copy R");
+    std::copy(R_host, R_host + count, r_mirror_.begin() + offset);
   }
   static void hip(hipError_t e, const char* what) {
     if (e != hipSuccess) throw std::runtime_error(std::string("rednose_amd: ") + what + ": " + hipGetErrorString(e));
@@ -678,6 +690,8 @@ class EKFSymBatch {
   std::map<int, int> zdim_;
   predict_fn batch_predict_ = nullptr;
   double *x_ = nullptr, *P_ = nullptr, *Q_ = nullptr, *R_ = nullptr;
+  std::vector<double> r_mirror_;                       // host copy of what R_ holds (upload_R)
+  mutable std::map<std::string, void*> syms_;          // resolved entry points (sym)
   double filter_time_ = NAN;
   int rewind_to_keep_ = 0;
   int pf_nmax_ = 1;                  // observations a per-filter ring entry can hold (set_max_observations_per_call)
