@@ -24,6 +24,7 @@ int kinematic6_batch_predict_update_1(double *x, double *P, const double *Q, con
 int kinematic6_batch_predict_masked(double *x, double *P, const double *Q, const double *dt_vec, double dt, int64_t n, int norm_quats, const uint8_t *active, void *stream);
 int kinematic6_batch_update_1_masked(double *x, double *P, double *z, const double *R, int r_per_filter, const double *ea, int64_t n, int norm_quats, uint8_t *flags, const uint8_t *active, void *stream);
 int kinematic6_batch_predict_update_1_masked(double *x, double *P, const double *Q, const double *dt_vec, double dt, double *z, const double *R, int r_per_filter, const double *ea, int64_t n, int norm_quats, uint8_t *flags, const uint8_t *active, void *stream);
+int kinematic6_batch_predict_update_1_ckpt(double *x, double *P, const double *Q, const double *dt_vec, double dt, double *z, const double *R, int r_per_filter, const double *ea, int64_t n, int norm_quats, uint8_t *flags, double *ckpt_x, double *ckpt_P, double *ckpt_z, void *stream);
 int kinematic6_batch_ring_copy(double *ring, int64_t ring_stride, double *flat, int64_t flat_stride, int64_t rec, const int32_t *slot, const uint8_t *active, int64_t n, int to_ring, void *stream);
 int kinematic6_batch_flags_set(uint8_t *flags, const uint8_t *mask, int value, int64_t n, void *stream);
 int kinematic6_batch_maha_1(const double *x, const double *P, const double *z, const double *R, int r_per_filter, const double *ea, int64_t n, double *d2, void *stream);

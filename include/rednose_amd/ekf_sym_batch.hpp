@@ -421,6 +421,10 @@ class EKFSymBatch {
     const bool keep = rewind_to_keep_ > 0;
     const int nobs = (int)z_devs.size();
     const int ead = sym<int (*)(int)>("kind_eadim")(kind);
+    // one observation without extra arguments, no Estimate asked for: the fused launch writes the checkpoint itself (k_stepc_{kind} behind
+    // {name}_batch_predict_update_{kind}_ckpt: the observation as it came, the filtered pair) -- no copies in front of or behind it
+    ckpt_fn fused_ckpt = nullptr;
+    if (keep && nobs == 1 && !estimate && (ea_devs.empty() || ead == 0)) fused_ckpt = sym_optional<ckpt_fn>("batch_predict_update_" + std::to_string(kind) + "_ckpt");
     if (keep) {
       c = slot();
       c.obs_t = t; c.kind = kind; c.nobs = nobs; c.ead = ead;
@@ -430,7 +434,7 @@ class EKFSymBatch {
       if (c.has_ea) reserve(&c.ea, &c.eacap, obs_stride(ead) * nobs);
       for (int i = 0; i < nobs; i++) {
         c.R.insert(c.R.end(), R_hosts[i], R_hosts[i] + Z * Z);
-        hip(hipMemcpyAsync(c.z + (size_t)i * obs_stride(Z), z_devs[i], sizeof(double) * n_ * Z, hipMemcpyDeviceToDevice, stream_), "ring z");
+        if (!fused_ckpt) hip(hipMemcpyAsync(c.z + (size_t)i * obs_stride(Z), z_devs[i], sizeof(double) * n_ * Z, hipMemcpyDeviceToDevice, stream_), "ring z");
         if (c.has_ea) hip(hipMemcpyAsync(c.ea + (size_t)i * obs_stride(ead), ea_devs[i], sizeof(double) * n_ * ead, hipMemcpyDeviceToDevice, stream_), "ring ea");
       }
     }
@@ -444,6 +448,8 @@ class EKFSymBatch {
       estimate->xk1 = state();
       estimate->Pk1 = covs();
       first_update = 0;
+    } else if (fused_ckpt) {
+      check(fused_ckpt(x_, P_, Q_, nullptr, dt, z_devs[0], R_, 0, nullptr, n_, norm_quats_, flags_dev, c.x, c.P, c.z, stream_), "batch_predict_update_ckpt");
     } else {
       auto fused = sym<step_fn>("batch_predict_update_" + std::to_string(kind));
       check(fused(x_, P_, Q_, nullptr, dt, z_devs[0], R_, 0, ea_devs.empty() ? nullptr : ea_devs[0], n_, norm_quats_, flags_dev, stream_), "batch_predict_update");
@@ -456,8 +462,10 @@ class EKFSymBatch {
     }
     filter_time_ = t;
     if (keep) {
-      hip(hipMemcpyAsync(c.x, x_, sizeof(double) * n_ * D_, hipMemcpyDeviceToDevice, stream_), "ring x");
-      hip(hipMemcpyAsync(c.P, P_, sizeof(double) * n_ * E_ * E_, hipMemcpyDeviceToDevice, stream_), "ring P");
+      if (!fused_ckpt) {
+        hip(hipMemcpyAsync(c.x, x_, sizeof(double) * n_ * D_, hipMemcpyDeviceToDevice, stream_), "ring x");
+        hip(hipMemcpyAsync(c.P, P_, sizeof(double) * n_ * E_ * E_, hipMemcpyDeviceToDevice, stream_), "ring P");
+      }
       c.t = t;
       ring_.push_back(c);
       while ((int)ring_.size() > rewind_to_keep_) { spare_.push_back(ring_.front()); ring_.pop_front(); }
@@ -645,15 +653,20 @@ class EKFSymBatch {
   using step_fn = int (*)(double*, double*, const double*, const double*, double, double*, const double*, int, const double*,
                           int64_t, int, uint8_t*, void*);
   using update_fn = int (*)(double*, double*, double*, const double*, int, const double*, int64_t, int, uint8_t*, void*);
+  using ckpt_fn = int (*)(double*, double*, const double*, const double*, double, double*, const double*, int, const double*, int64_t, int, uint8_t*,
+                          double*, double*, double*, void*);
 
   template <class F>
   F sym(const std::string& suffix) const {
     auto it = syms_.find(suffix);              // looked up once: a step-granular call is ~9 us of GPU time, dlsym + two string concatenations are not free beside it
-    if (it == syms_.end()) {
-      void* p = dlsym(handle_, (name_ + "_" + suffix).c_str());
-      if (!p) throw std::runtime_error("rednose_amd: lib" + name_ + ".so does not export " + name_ + "_" + suffix);
-      it = syms_.emplace(suffix, p).first;
-    }
+    if (it == syms_.end()) it = syms_.emplace(suffix, dlsym(handle_, (name_ + "_" + suffix).c_str())).first;
+    if (!it->second) throw std::runtime_error("rednose_amd: lib" + name_ + ".so does not export " + name_ + "_" + suffix);
+    return reinterpret_cast<F>(it->second);
+  }
+  template <class F>
+  F sym_optional(const std::string& suffix) const {       // nullptr for an entry point this library was built without
+    auto it = syms_.find(suffix);
+    if (it == syms_.end()) it = syms_.emplace(suffix, dlsym(handle_, (name_ + "_" + suffix).c_str())).first;
     return reinterpret_cast<F>(it->second);
   }
   // noise matrices go to the device staging buffer R_ only when they differ from what is there (the usual caller passes the same R for a kind on

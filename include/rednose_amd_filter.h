@@ -191,7 +191,15 @@ extern "C" {
   int RN_FN(name, batch_predict_update_##k)(double *x, double *P, const double *Q, const double *dt_vec,         \
                                             double dt, double *z, const double *R, int r_per_filter,             \
                                             const double *ea, int64_t n, int norm_quats, uint8_t *flags,         \
-                                            void *stream);
+                                            void *stream);                                                       \
+  /* the same launch also writing the call's CHECKPOINT -- what EKFSym::checkpoint keeps of a call (ekf_sym.cc:142-156, 191): \
+   * ckpt_z (n, Z) the observations as they came (z itself leaves as the residuals), ckpt_x (n, D) / ckpt_P (n, E, E) the   \
+   * filtered pair; DEVICE, 16-byte aligned, distinct from x / P / z.  One launch and 1.5 x the bytes of the plain step      \
+   * instead of the step plus three copies (2 x the bytes, four launches) */                                    \
+  int RN_FN(name, batch_predict_update_##k##_ckpt)(double *x, double *P, const double *Q, const double *dt_vec,  \
+                                                   double dt, double *z, const double *R, int r_per_filter,      \
+                                                   const double *ea, int64_t n, int norm_quats, uint8_t *flags,  \
+                                                   double *ckpt_x, double *ckpt_P, double *ckpt_z, void *stream);
 
 /* Per-filter timelines.  Every filter of the reference is its own instance with its own filter_time and its own rewind ring
  * (EKFSym::predict_and_update_batch / rewind, /root/reference/rednose/helpers/ekf_sym.cc:83-156); a batch fed from n INDEPENDENT

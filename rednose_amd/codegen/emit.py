@@ -121,7 +121,7 @@ def _emit(spec):
       use_tri = False
       fam_mod = types.SimpleNamespace(
         kernels=lambda sp_: emit_wide2.kernels(sp_) + "\n" + emit_wide2.maha_kernels(sp_),
-        launch_predict=emit_wide2.launch_predict, launch_step=emit_wide2.launch_step, launch_run=None,
+        launch_predict=emit_wide2.launch_predict, launch_step=emit_wide2.launch_step, launch_step_ckpt=emit_wide2.launch_step_ckpt, launch_run=None,
         launch_maha=emit_wide2.launch_maha)
     else:
       # step-granular kernels: three-phase structure (emit_wide2); fused multi-step run: state resident in registers, several
@@ -129,14 +129,15 @@ def _emit(spec):
       fam_mod = types.SimpleNamespace(
         kernels=lambda sp_: emit_wide2.kernels(sp_) + "\n" + emit_wide3.kernels(sp_, with_run=not use_run2) + "\n" +
                             (emit_run2.kernels(sp_, tri=use_tri) + "\n" if use_run2 else "") + emit_wide2.maha_kernels(sp_),
-        launch_predict=emit_wide2.launch_predict, launch_step=emit_wide2.launch_step,
+        launch_predict=emit_wide2.launch_predict, launch_step=emit_wide2.launch_step, launch_step_ckpt=emit_wide2.launch_step_ckpt,
         launch_run=emit_run2.launch_run if use_run2 else emit_wide3.launch_run,
         launch_maha=emit_wide2.launch_maha)
   else:
     use_tri = False
     fam_mod = types.SimpleNamespace(
       kernels=lambda sp_: emit_small.kernels(sp_) + "\n" + emit_small.maha_kernels(sp_),
-      launch_predict=emit_small.launch_predict, launch_step=emit_small.launch_step, launch_run=lambda: emit_small.launch_run(spec),
+      launch_predict=emit_small.launch_predict, launch_step=emit_small.launch_step, launch_step_ckpt=emit_small.launch_step_ckpt,
+      launch_run=lambda: emit_small.launch_run(spec),
       launch_maha=emit_small.launch_maha)
 
   hdr = ["#pragma once", "#include <stdint.h>", "#ifdef __cplusplus", 'extern "C" {', "#endif"]
@@ -339,6 +340,21 @@ int {name}_batch_predict_update_{k.kind}{sfx}(double *x, double *P, const double
 }}""")
       hdr.append(f"int {name}_batch_update_{k.kind}{sfx}(double *x, double *P, double *z, const double *R, int r_per_filter, const double *ea, int64_t n, int norm_quats, uint8_t *flags, {act_param}void *stream);")
       hdr.append(f"int {name}_batch_predict_update_{k.kind}{sfx}(double *x, double *P, const double *Q, const double *dt_vec, double dt, double *z, const double *R, int r_per_filter, const double *ea, int64_t n, int norm_quats, uint8_t *flags, {act_param}void *stream);")
+
+  # the fused step that also writes the call's checkpoint (k_stepc_{kind}): what a rewind ring keeps of a call -- the observations as they came and the
+  # filtered pair (ekf_sym.cc:142-156, 191) -- leaves with the step's own stores instead of three copies behind it
+  for k in spec.kinds:
+    abi.append(f"""int {name}_batch_predict_update_{k.kind}_ckpt(double *x, double *P, const double *Q, const double *dt_vec, double dt, double *z, const double *R, int r_per_filter, const double *ea, int64_t n, int norm_quats, uint8_t *flags, double *ckpt_x, double *ckpt_P, double *ckpt_z, void *stream) {{
+  RN_REQUIRE(n >= 0 && x && P && Q && z && R && ckpt_x && ckpt_P && ckpt_z{ea_req(k)}, rn::ERR_ARG);
+  RN_REQUIRE(ckpt_x != x && ckpt_P != P && ckpt_z != z, rn::ERR_ARG);
+  if (n == 0) return rn::OK;
+  RN_REQUIRE(rn::aligned16(x) && rn::aligned16(P) && rn::aligned16(z) && (!r_per_filter || rn::aligned16(R)) && rn::aligned16(ckpt_x) && rn::aligned16(ckpt_P) && rn::aligned16(ckpt_z), rn::ERR_ALIGN);
+  const uint8_t *active = nullptr;
+{fam_mod.launch_step_ckpt(k.kind)}
+  RN_HIP(hipGetLastError());
+  return rn::OK;
+}}""")
+    hdr.append(f"int {name}_batch_predict_update_{k.kind}_ckpt(double *x, double *P, const double *Q, const double *dt_vec, double dt, double *z, const double *R, int r_per_filter, const double *ea, int64_t n, int norm_quats, uint8_t *flags, double *ckpt_x, double *ckpt_P, double *ckpt_z, void *stream);")
 
   abi.append(f"""int {name}_batch_ring_copy(double *ring, int64_t ring_stride, double *flat, int64_t flat_stride, int64_t rec, const int32_t *slot, const uint8_t *active, int64_t n, int to_ring, void *stream) {{
   RN_REQUIRE(n >= 0 && rec >= 0 && rec <= ring_stride && rec <= flat_stride && ring && flat && slot, rn::ERR_ARG);

@@ -349,13 +349,20 @@ __global__ __launch_bounds__(64) void k_predict(double* __restrict__ gx, double*
     ZZ = Z * Z
     # extra arguments are per observation, i.e. per filter of the batch: (n, len(ea)) row-major
     ea = f", gea + (base + (lane < cnt ? lane : 0)) * {int(sp.Matrix(k.ea_sym).shape[0])}" if k.ea_sym is not None else ""
-    out.append(f"""
-// ---- kind {k.kind}: [predict +] update, state round-trips HBM once per launch --------------------------
+    # k_stepc_{kind}: the same kernel writing a CHECKPOINT on its way -- the observations as they came (cz) and the filtered pair (cx, cP): what the
+    # orchestrators' rewind rings keep of every call (ekf_sym.cc:142-156, 191).  A kernel of its own, so that k_step_{kind} stays as it is.
+    for ckpt in (False, True):
+      kn = f"k_stepc_{k.kind}" if ckpt else f"k_step_{k.kind}"
+      cargs = ", double* __restrict__ cx, double* __restrict__ cP, double* __restrict__ cz" if ckpt else ""
+      cz_store = f"\n    rn::tile_l2g<{Z}>(cz + base * {Z}, cnt, s_z, lane);      // the observations, before the residuals take their place" if ckpt else ""
+      c_store = f"\n    rn::tile_l2g<{D}>(cx + base * {D}, cnt, s_x, lane);\n    rn::tile_l2g<{EE}>(cP + base * {EE}, cnt, s_P, lane);" if ckpt else ""
+      out.append(f"""
+// ---- kind {k.kind}: [predict +] update{" + checkpoint" if ckpt else ""}, state round-trips HBM once per launch --------------------------
 template <bool DO_PREDICT>
-__global__ __launch_bounds__(64){kattr} void k_step_{k.kind}(double* __restrict__ gx, double* __restrict__ gP,
+__global__ __launch_bounds__(64){kattr} void {kn}(double* __restrict__ gx, double* __restrict__ gP,
     double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const double* __restrict__ gea,
     const double* __restrict__ gQ, const double* __restrict__ gdt, const double dt_scalar, const int64_t n,
-    const int norm_quats, uint8_t* __restrict__ flags, const uint8_t* __restrict__ active) {{
+    const int norm_quats, uint8_t* __restrict__ flags, const uint8_t* __restrict__ active{cargs}) {{
   __shared__ __attribute__((aligned(16))) double s_x[64 * {D | 1}];
   __shared__ __attribute__((aligned(16))) double s_P[64 * {EE | 1}];
   __shared__ __attribute__((aligned(16))) double s_z[64 * {Z | 1}];
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(64){kattr} void k_step_{k.kind}(double* __restrict_
     double dt = dt_scalar;
     if (DO_PREDICT && gdt != nullptr && lane < cnt) dt = gdt[base + lane];
     rn::async_wait();
-    rn::wave_lds_sync();
+    rn::wave_lds_sync();{cz_store}
     double x[{D}], P[{EE}], z[{Z}], R[{ZZ}];
     rn::lds_to_regs<{D}>(s_x, lane, x);
     rn::lds_to_regs<{EE}>(s_P, lane, P);
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(64){kattr} void k_step_{k.kind}(double* __restrict_
     rn::wave_lds_sync();
     rn::tile_l2g<{D}>(gx + base * {D}, cnt, s_x, lane);
     rn::tile_l2g<{EE}>(gP + base * {EE}, cnt, s_P, lane);
-    rn::tile_l2g<{Z}>(gz + base * {Z}, cnt, s_z, lane);
+    rn::tile_l2g<{Z}>(gz + base * {Z}, cnt, s_z, lane);{c_store}
     if (flags != nullptr && lane < cnt) {{
       double acc = 0.0;
 #pragma unroll
@@ -760,6 +767,12 @@ def launch_predict():
   return """  const int64_t tiles = (n + 63) >> 6;
   hipLaunchKernelGGL(k_predict, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
                      x, P, Q, dt_vec, dt, n, norm_quats, active);"""
+
+
+def launch_step_ckpt(kind):
+  return f"""  const int64_t tiles = (n + 63) >> 6;
+  hipLaunchKernelGGL(k_stepc_{kind}<true>, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     x, P, z, R, r_per_filter, ea, Q, dt_vec, dt, n, norm_quats, flags, active, ckpt_x, ckpt_P, ckpt_z);"""
 
 
 def launch_step(kind, do_predict):

@@ -603,7 +603,9 @@ def kernels(spec):
     out.append("__device__ unsigned long long g_tl[256 * 64 * 2];      // debug timeline (tuning knob wide_timeline)")
     out.append("__device__ unsigned long long g_tlb[4096 * 2];         // start / end of EVERY workgroup's first tile")
 
-  def kernel(kname, k=None):
+  def kernel(kname, k=None, ckpt=False):
+    # ckpt: the kernel also writes a CHECKPOINT -- the observations as they came (cz), the filtered pair (cx, cP) --, what the orchestrators' rewind
+    # rings keep of every call (ekf_sym.cc:142-156, 191); a kernel of its own (k_stepc_{kind}), k_step_{kind} stays as it is
     upd = k is not None
     Z = k.zdim if upd else 1
     ZZ = Z * Z
@@ -613,6 +615,8 @@ def kernels(spec):
     sig_obs = ("double* __restrict__ gz, const double* __restrict__ gR, const int r_per_filter, const double* __restrict__ gea,\n    "
                if upd else "")
     flags_arg = (", uint8_t* __restrict__ flags" if upd else "") + ", const uint8_t* __restrict__ active"
+    if ckpt:
+      flags_arg += ", double* __restrict__ cx, double* __restrict__ cP, double* __restrict__ cz"
     L = []
     A = L.append
     TLK = tune.wide_timeline
@@ -673,6 +677,8 @@ def kernels(spec):
     if DB:
       A(f"    {CPIN}<{PBUF}>(gP + base * {EE}, (cnt < {FPW} ? cnt : {FPW}) * {EE}, s_P[0], lane);")
     A("    rn::wave_lds_sync();")
+    if ckpt:
+      A(f"    rn::copy_l2g<FT2 * {Z}>(cz + base * {Z}, cnt * {Z}, s_z, lane);      // the observations, before the residuals take their place")
     TL(1)
     A("    if (lane < cnt) {")
     A("      double* sl = s_sl + lane * SLOT;")
@@ -731,6 +737,8 @@ def kernels(spec):
       A(f"      mat_update_{k.kind}(sPc + gg * {EE}, r_per_filter ? gR + (base + {FPW} * p + gg) * {ZZ} : gR, sl, sl, s_G + gg * {Z * E}, s_K + gg * {Z * E}{ss_}, cc, on);")
     TL("6 + 4 * p")
     A(f"      rn::copy_l2g_any<{PBUF}>(gPp, pcnt * {EE}, sPb, sh, lane);" if ODD else f"      rn::copy_l2g<{PBUF}>(gPp, pcnt * {EE}, sPb, lane);")
+    if ckpt:      # (cP is 16-byte aligned like gP: the group's record starts on the same parity)
+      A(f"      rn::copy_l2g_any<{PBUF}>(cP + (base + {FPW} * p) * {EE}, pcnt * {EE}, sPb, sh, lane);" if ODD else f"      rn::copy_l2g<{PBUF}>(cP + (base + {FPW} * p) * {EE}, pcnt * {EE}, sPb, lane);")
     TL("7 + 4 * p")
     A("      rn::wave_lds_sync();")
     A("    }")
@@ -754,6 +762,8 @@ def kernels(spec):
     A(f"    rn::copy_l2g<FT2 * {D}>(gx + base * {D}, cnt * {D}, s_x, lane);")
     if upd:
       A(f"    rn::copy_l2g<FT2 * {Z}>(gz + base * {Z}, cnt * {Z}, s_z, lane);")
+    if ckpt:
+      A(f"    rn::copy_l2g<FT2 * {D}>(cx + base * {D}, cnt * {D}, s_x, lane);")
     A("    rn::wave_lds_sync();")
     TL(63)
     if TLK:
@@ -765,6 +775,7 @@ def kernels(spec):
   out.append(kernel("k_predict"))
   for k in spec.kinds:
     out.append(kernel(f"k_step_{k.kind}", k))
+    out.append(kernel(f"k_stepc_{k.kind}", k, ckpt=True))
   return "\n".join(out)
 
 
@@ -870,3 +881,9 @@ def launch_step(kind, do_predict):
   return f"""  const int64_t tiles = (n + FT2 - 1) / FT2;
   hipLaunchKernelGGL(k_step_{kind}<{tf}>, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
                      {args});"""
+
+
+def launch_step_ckpt(kind):
+  return f"""  const int64_t tiles = (n + FT2 - 1) / FT2;
+  hipLaunchKernelGGL(k_stepc_{kind}<true>, dim3(rn::grid_for_tiles(tiles)), dim3(64), 0, (hipStream_t)stream,
+                     x, P, z, R, r_per_filter, ea, Q, dt_vec, dt, n, norm_quats, flags, active, ckpt_x, ckpt_P, ckpt_z);"""

@@ -1068,7 +1068,23 @@ class BatchedEKF:
       self.rewind_states.append((self.x.clone(), self.P.clone()))
       self.rewind_obscache.append((t, kind, z_keep, R, extra_args))
       return ret
-    zin, Rd, _ = self._obs_args(kind, z, R)
+    zin, Rd, per = self._obs_args(kind, z, R)
+    ea = self._ea(kind, extra_args)
+    ck = f"batch_predict_update_{kind}_ckpt"
+    if not keep_estimate and ea is None and hasattr(self._lib, f"{self.name}_{ck}"):
+      # one launch: the step writes its own checkpoint -- the observation as it came, the filtered pair -- next to its results
+      # (k_stepc_{kind}: 1.5 x the bytes of the plain step instead of the step plus three copies)
+      torch = self._torch
+      dt = self._dt(t)
+      cx, cP, cz = torch.empty_like(self.x), torch.empty_like(self.P), torch.empty_like(zin)
+      dt_ptr, dt_s = self._dt_args(dt)
+      self._call(ck, self._p(self.x), self._p(self.P), self._p(self.Q), dt_ptr, dt_s, self._p(zin), self._p(Rd), per, None, self.batch,
+                 self.norm_quats, self._p(self.flags), self._p(cx), self._p(cP), self._p(cz), self._stream())
+      self.filter_time = t
+      self.rewind_t.append(self.filter_time)
+      self.rewind_states.append((cx, cP))
+      self.rewind_obscache.append((t, kind, cz, Rd, None))
+      return zin
     z_keep = zin.clone()                     # the kernel overwrites z with the residual; the ring needs the observation
     ret = self._predict_and_update(t, kind, zin, Rd, extra_args, keep_estimate)
     self.rewind_t.append(self.filter_time)

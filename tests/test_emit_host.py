@@ -686,6 +686,10 @@ extern "C" __attribute__((visibility("default"))) void host_step(int grid, doubl
                           int64_t n, int norm_quats, uint8_t* flags, const uint8_t* active) {{
   run_grid(grid, [&] {{ k_step_{k0.kind}<true>(x, P, z, R, r_per_filter, nullptr, Q, dt_vec, dt, n, norm_quats, flags, active); }});
 }}
+extern "C" __attribute__((visibility("default"))) void host_step_ckpt(int grid, double* x, double* P, double* z, const double* R, const double* Q, const double* dt_vec,
+                          int64_t n, uint8_t* flags, double* cx, double* cP, double* cz) {{
+  run_grid(grid, [&] {{ k_stepc_{k0.kind}<true>(x, P, z, R, 0, nullptr, Q, dt_vec, 0.0, n, 0, flags, nullptr, cx, cP, cz); }});
+}}
 """
   src = "\n".join([_KERNEL_PRELUDE, helpers, prefetch,
                    "template <int EPF> inline void tile_g2l_async(const double* g, int cnt, double* lds, int lane) { tile_g2l<EPF>(g, cnt, lds, lane); }",
@@ -787,6 +791,16 @@ def test_lane_per_filter_kernels_on_the_host(tmp_path, name):
   assert_close(xh[on], xr[on], rtol=1e-11, floor=1e-13, what=f"{name} masked step x")
   assert_close(Ph[on].reshape(int(on.sum()), -1), Pr[on].reshape(int(on.sum()), -1), rtol=1e-11, floor=1e-13, what=f"{name} masked step P")
   assert_close(zh[on], zr[on], rtol=1e-11, atol=1e-13 * max(1.0, np.abs(z0).max()), what=f"{name} masked step y")
+  # k_stepc: the same step (unmasked here) writing its checkpoint -- the plain step's bits, the observations as they came, the filtered pair
+  xp, Pp, zp, flp = x0.copy(), P0.copy(), z0.copy(), np.full(n, 99, dtype=np.uint8)
+  lib.host_step(grid, ptr(xp), ptr(Pp), ptr(zp), ptr(R), 0, ptr(Q), ptr(dtv), 0.0, n, 0, ptr(flp, bp), None)
+  xc, Pc, zc, flc = x0.copy(), P0.copy(), z0.copy(), np.full(n, 99, dtype=np.uint8)
+  cx, cP, cz = np.full((n + 1, D), 7.0), np.full((n + 1, E, E), 7.0), np.full((n + 1, Z), 7.0)
+  lib.host_step_ckpt.argtypes = [ctypes.c_int, dp, dp, dp, dp, dp, dp, ctypes.c_int64, bp, dp, dp, dp]
+  lib.host_step_ckpt(grid, ptr(xc), ptr(Pc), ptr(zc), ptr(R), ptr(Q), ptr(dtv), n, ptr(flc, bp), ptr(cx), ptr(cP), ptr(cz))
+  assert np.array_equal(xc, xp) and np.array_equal(Pc, Pp) and np.array_equal(zc, zp) and np.array_equal(flc, flp), f"{name}: checkpointing step vs plain step"
+  assert np.array_equal(cx[:n], xc) and np.array_equal(cP[:n], Pc) and np.array_equal(cz[:n], z0), f"{name}: checkpoint"
+  assert (cx[n] == 7.0).all() and (cP[n] == 7.0).all() and (cz[n] == 7.0).all(), f"{name}: checkpoint guard rows"
 
 
 def test_blocked_traced_run_on_the_host(tmp_path):
@@ -872,6 +886,10 @@ extern "C" __attribute__((visibility("default"))) void host_wide_kernel_{k.kind}
     int r_per_filter, const double* Q, const double* dt_vec, double dt, int64_t n, int norm_quats, uint8_t* flags, const uint8_t* active) {{
   if (do_predict) run_grid(grid, [&] {{ k_step_{k.kind}<true>(x, P, z, R, r_per_filter, nullptr, Q, dt_vec, dt, n, norm_quats, flags, active); }});
   else run_grid(grid, [&] {{ k_step_{k.kind}<false>(x, P, z, R, r_per_filter, nullptr, nullptr, nullptr, 0.0, n, norm_quats, flags, active); }});
+}}
+extern "C" __attribute__((visibility("default"))) void host_wide_kernel_ckpt_{k.kind}(int grid, double* x, double* P, double* z, const double* R,
+    const double* Q, double dt, int64_t n, int norm_quats, uint8_t* flags, double* cx, double* cP, double* cz) {{
+  run_grid(grid, [&] {{ k_stepc_{k.kind}<true>(x, P, z, R, 0, nullptr, Q, nullptr, dt, n, norm_quats, flags, nullptr, cx, cP, cz); }});
 }}""")
   prelude = _KERNEL_PRELUDE.replace("inline void pin(double&) {}", "inline void pin(double&) {}\n" + _WIDE_COPIES)
   src = "\n".join([prelude, helpers, "}  // namespace rn", text, _RUN_GRID] + entries)
@@ -940,6 +958,15 @@ def test_lane_group_step_kernels_on_the_host(tmp_path, name):
       assert_close(xh[on], xr[on], rtol=1e-10, floor=1e-12, what=what + " x")
       assert_close(Ph[on].reshape(m, -1), Pr[on].reshape(m, -1), rtol=1e-9, floor=1e-11, what=what + " P")
       assert_close(zh[on], zr[on], rtol=1e-10, atol=1e-12 * max(1.0, np.abs(z0).max()), what=what + " y")
+      if mode == "scalar dt":      # k_stepc: the same step writing its checkpoint -- same bits, the observations as they came, the filtered pair
+        fc = getattr(lib, f"host_wide_kernel_ckpt_{k.kind}")
+        fc.argtypes = [ctypes.c_int, dp, dp, dp, dp, dp, ctypes.c_double, ctypes.c_int64, ctypes.c_int, bp, dp, dp, dp]
+        xc, Pc, zc, flc = x0.copy(), P0.copy(), z0.copy(), np.full(n, 99, dtype=np.uint8)
+        cx, cP, cz = np.full((n + 1, D), 7.0), np.full((n + 1, E, E), 7.0), np.full((n + 1, Z), 7.0)
+        fc(grid, ptr(xc), ptr(Pc), ptr(zc), ptr(R), ptr(Q), 0.01, n, int(quat_idx >= 0), ptr(flc, bp), ptr(cx), ptr(cP), ptr(cz))
+        assert np.array_equal(xc, xh) and np.array_equal(Pc, Ph) and np.array_equal(zc, zh) and np.array_equal(flc, fl), what + ": checkpointing step vs plain step"
+        assert np.array_equal(cx[:n], xc) and np.array_equal(cP[:n], Pc) and np.array_equal(cz[:n], z0), what + ": checkpoint"
+        assert (cx[n] == 7.0).all() and (cP[n] == 7.0).all() and (cz[n] == 7.0).all(), what + ": checkpoint guard rows"
   assert (gated > 0) == (name == "live_maha")
 
 
