@@ -27,6 +27,7 @@ rate), 1 M filters, kinematic9, the MSCKF model, and config 4 at its stated size
 `roofline_backward_dt_gt0` (the smoother on a chunk whose steps all advance time: no step takes the identity-gain path) and
 `packed_trace` (the same sweep with the opt-in packed-triangle trace between the passes) next to the stream's two objects.
 Every HBM-bound object carries `frac` (HIP events) and, where a host clock brackets the same launches, `frac_wall`.
+`kinematic6_ring`: the headline step with the reference's rewind ring on (one fused step + checkpoint launch per call).
 `scalar_abi`: microseconds per predict + update of ONE filter through the reference's scalar host-pointer entry points (a latency, not part of any rate).
 """
 import argparse
@@ -449,6 +450,37 @@ def scalar_abi_extra(gen):
   return out
 
 
+def ring_extra(torch, gen, n, K, dev):
+  """The headline step with the reference's rewind ring ON (EKFSym keeps a checkpoint of every call, ekf_sym.cc:142-156,191; BatchedEKF(rewind_to_keep=..)):
+  BatchedEKF.predict_and_update_batch on kinematic6, one launch per call -- the fused step that writes its own checkpoint
+  ({name}_batch_predict_update_{kind}_ckpt).  Algorithmic bytes per filter-step: the plain step's 720 B + the checkpoint's x, P and observation written (360 B)."""
+  import time
+  from examples.kinematic6_kf import Kinematic6Kalman as K6
+  from rednose_amd.helpers.ekf_sym import BatchedEKF
+  f = BatchedEKF(gen, "kinematic6", K6.Q, K6.initial_x, np.diag(K6.initial_P_diag), 6, 6, batch=n, device=dev, rewind_to_keep=8)
+  R = np.ascontiguousarray(K6.obs_noise[1], dtype=np.float64)
+  zs = torch.randn((64, n, 3), dtype=torch.float64, device=dev)      # a pool of observation buffers (the kernel overwrites its own with the residuals)
+  t = 0.0
+  for i in range(200):
+    t += 0.01
+    f.predict_and_update_batch(t, 1, zs[i % 64], R)
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  t0 = time.perf_counter()
+  e0.record()
+  for i in range(K):
+    t += 0.01
+    f.predict_and_update_batch(t, 1, zs[i % 64], R)
+  e1.record()
+  torch.cuda.synchronize()
+  wall = (time.perf_counter() - t0) / K
+  per = 8.0 * (2 * (6 + 36 + 3) + (6 + 36 + 3))
+  return {"batch": n, "steps": K, "value": n / wall, "unit": "steps/s", "rewind_to_keep": 8, "algorithmic_bytes_per_filter_step": per,
+          "roofline": hbm_roofline(per * n, e0.elapsed_time(e1) * 1e-3 / K, "k_stepc_1<true>", wall_s=wall, **traffic_kw(f"kinematic6_ring_b{n}", "kinematic6", gen)),
+          "note": "the headline step through BatchedEKF.predict_and_update_batch with the rewind ring on: one launch per call (step + checkpoint); "
+                  "the same calls as step + three copies took 26 us before the checkpointing kernel existed"}
+
+
 def fused_run_extra(torch, model, n, T, dev):
   """{name}_batch_run: x and P stay in registers for T steps, only z / y cross HBM.  Bound by fp64 VALU issue."""
   from rednose_amd.helpers.ekf_sym import BatchedEKF
@@ -837,6 +869,7 @@ def main():
     extra["fused_run"] = fused_run_extra(torch, "kinematic6", n, 500, dev)
     extra["feature36_msckf"] = msckf_extra(torch, dev)
     extra["scalar_abi"] = scalar_abi_extra(gen_dir(["kinematic", "live"]))
+    extra["kinematic6_ring"] = ring_extra(torch, gen_dir(["kinematic6"]), 65536, 1000, dev)
     extra["live_maha_rts"] = config4_extra(torch, dev, rank)
 
   if rank == 0:

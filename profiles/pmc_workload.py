@@ -33,14 +33,16 @@ def section(label, lib, n, nbytes, steps, warmup):
   print(f"SECTION {label} {lib} {n} {nbytes:.0f} {steps} {warmup}", flush=True)
 
 
-def stepwise(label, model, n, reps, only_kind=None):
+def stepwise(label, model, n, reps, only_kind=None, ring=0):
+  """ring > 0: the same launches with the rewind ring on -- every call is ONE launch of the step that writes its own checkpoint (k_stepc_{kind}); the
+  section's algorithmic bytes then include the checkpoint's x, P and observation (written once)."""
   if not want(label):
     return
   M = bench.model_class(model)
   gen = bench.gen_dir([model])
   D, E = M.initial_x.shape[0], M.initial_P_diag.shape[0]
   f = BatchedEKF(gen, M.name, M.Q, M.initial_x, np.diag(M.initial_P_diag), D, E, batch=n, device=dev,
-                 quaternion_idxs=list(getattr(M, "quaternion_idxs", [])))
+                 quaternion_idxs=list(getattr(M, "quaternion_idxs", [])), **({"rewind_to_keep": ring} if ring else {}))
   if model == "live":
     x0, P0, sched = bench.live_stream(torch, M, gen, n, reps + 21, dev, 0)
     if only_kind is not None:
@@ -54,7 +56,7 @@ def stepwise(label, model, n, reps, only_kind=None):
   for i, (k, t, z) in enumerate(sched):       # 21 warm-up launches (a whole 10-tick pattern of the live stream), then the section
     if i == 21:
       zd = [f.zdims[s[0]] for s in sched[21:]]
-      section(label, M.name, reps, 8.0 * (2 * (D + E * E) + 2 * float(np.mean(zd))) * n, n, 21)
+      section(label, M.name, reps, 8.0 * ((3 if ring else 2) * (D + E * E) + (3 if ring else 2) * float(np.mean(zd))) * n, n, 21)
     f.predict_and_update_batch(t if tp is None or t >= tp else tp, k, z.clone(), Rs[k])
     tp = t
   torch.cuda.synchronize()
@@ -155,6 +157,7 @@ def calibration():
 if __name__ == "__main__":
   stepwise("kinematic6_b65536", "kinematic6", 65536, 20)
   stepwise("kinematic6_b1048576", "kinematic6", 1 << 20, 5)
+  stepwise("kinematic6_ring_b65536", "kinematic6", 65536, 20, ring=8)
   stepwise("kinematic_b65536", "kinematic", 65536, 20)
   stepwise("kinematic9_b65536", "kinematic9", 65536, 10)
   stepwise("live_b16384", "live", 16384, 21)
