@@ -60,6 +60,29 @@ def _renamed(cls, name, folder, **kw):
 
 
 _ENSURED = set()      # (name, folder, tuning) checked in THIS process
+_INPUTS = {}          # tuning key -> digest of everything a generated library depends on
+
+
+def inputs_digest():
+  """Digest of everything the text and the build of a model's library depend on: the emitters, the runtime headers, the build module, the helpers
+  (gen_code, KalmanFilter.generate_code), the model definitions, sympy's version and the tuning environment.  A library stamped with it ({name}.inputs) is up to date without re-emitting the model --
+  the comparison gen_code itself makes needs the emitted text, i.e. 23 s of sympy for the live model, once per process and model."""
+  key = (os.environ.get("RN_TUNE", ""), os.environ.get("RN_HIPCC_FLAGS", ""), os.environ.get("RN_ALLOW_SPILLS", ""))
+  if key not in _INPUTS:
+    import glob
+    import hashlib
+    import sympy
+    repo = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    files = sorted(glob.glob(os.path.join(repo, "rednose_amd", "codegen", "*.py")) + glob.glob(os.path.join(repo, "rednose_amd", "templates", "*.h")) +
+                   glob.glob(os.path.join(repo, "examples", "*.py")) +
+                   glob.glob(os.path.join(repo, "rednose_amd", "helpers", "*.py")) + [os.path.join(repo, "rednose_amd", "build.py")])
+    h = hashlib.sha256(repr((key, sympy.__version__)).encode())
+    for fn in files:
+      h.update(os.path.relpath(fn, repo).encode())
+      with open(fn, "rb") as f:
+        h.update(f.read())
+    _INPUTS[key] = h.hexdigest()
+  return _INPUTS[key]
 
 
 def ensure_generated(names=None, folder=GENERATED_DIR):
@@ -71,7 +94,15 @@ def ensure_generated(names=None, folder=GENERATED_DIR):
     key = (n, os.path.abspath(folder), os.environ.get("RN_TUNE", ""), os.environ.get("RN_HIPCC_FLAGS", ""), os.environ.get("RN_ALLOW_SPILLS", ""))
     if key in _ENSURED:
       continue
-    table[n](folder)
+    stamp = os.path.join(folder, f"{n}.inputs")
+    fresh = False
+    if os.path.exists(stamp) and os.path.exists(os.path.join(folder, f"lib{n}.so")) and os.path.exists(os.path.join(folder, f"{n}.digest")):
+      with open(stamp, encoding="utf-8") as f:
+        fresh = f.read().strip() == inputs_digest()
+    if not fresh:
+      table[n](folder)
+      with open(stamp, "w", encoding="utf-8") as f:
+        f.write(inputs_digest())
     _ENSURED.add(key)
   return folder
 
