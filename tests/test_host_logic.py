@@ -542,3 +542,31 @@ def test_two_wavefront_fused_run_is_chosen_where_it_applies_and_falls_back():
   assert not emit_run2.applicable(build_spec(**Kinematic9Kalman.model()))        # 9 error states: k_run measured faster
   from examples.feature_kf import FeatureKalman
   assert not emit_run2.applicable(build_spec(**FeatureKalman.model()))           # feature-track kinds, window shift
+
+
+def test_up_to_date_stamp_follows_everything_a_library_depends_on(tmp_path, monkeypatch):
+  """examples.ensure_generated skips a model whose `{name}.inputs` stamp equals examples.inputs_digest() -- the digest of the emitters, runtime headers,
+  helpers, model definitions, sympy's version and the tuning environment -- and regenerates it otherwise; a missing library or digest file voids the stamp."""
+  import examples
+  calls = []
+  monkeypatch.setattr(examples, "model_table", lambda: {"toy": lambda d: calls.append(d)})
+  monkeypatch.setattr(examples, "_ENSURED", set())
+  d = str(tmp_path)
+  examples.ensure_generated(["toy"], folder=d)
+  assert calls == [d] and open(os.path.join(d, "toy.inputs"), encoding="utf-8").read() == examples.inputs_digest()
+  examples._ENSURED.clear()      # pylint: disable=protected-access
+  examples.ensure_generated(["toy"], folder=d)
+  assert len(calls) == 2, "no library next to the stamp: the model is generated again"
+  for fn in ("libtoy.so", "toy.digest"):
+    open(os.path.join(d, fn), "w", encoding="utf-8").close()
+  examples._ENSURED.clear()      # pylint: disable=protected-access
+  examples.ensure_generated(["toy"], folder=d)
+  assert len(calls) == 2, "stamped, library and digest present: skipped"
+  base = examples.inputs_digest()
+  monkeypatch.setenv("RN_TUNE", "rts_dt0=0")
+  assert examples.inputs_digest() != base, "the tuning environment is part of the digest"
+  examples._ENSURED.clear()      # pylint: disable=protected-access
+  examples.ensure_generated(["toy"], folder=d)
+  assert len(calls) == 3, "another tuning: generated again"
+  monkeypatch.delenv("RN_TUNE")
+  assert examples.inputs_digest() == base
