@@ -866,15 +866,16 @@ class BatchedEKF:
     ft = self.filter_times()
     self.filter_time = ft
     late = act & ~torch.isnan(ft) & (tt < ft)
-    dropped = torch.zeros(N, dtype=torch.bool, device=self.device)
+    dropped, any_dropped = None, False
     replay = None
-    if bool(late.any()):
+    if bool(late.any()):                   # (the one host round trip of an in-order call: whether any filter has to rewind decides what is launched)
       if self.rewind_to_keep <= 0:
         raise AssertionError("observation older than a filter's time (enable rewind_to_keep to reorder late observations)")
       dropped, replay = self._ring_rewind(late, tt)
-      if bool(dropped.any()):
+      any_dropped = bool(dropped.any())
+      if any_dropped:
         self.logger.error(f"observation too old for {int(dropped.sum())} filter(s) of the batch, ignoring it for them")
-      act = act & ~dropped
+        act = act & ~dropped
       ft = self.filter_time
     dt = torch.where(act, torch.nan_to_num(tt - ft, nan=0.0), torch.zeros_like(tt))
     est = self._masked_step(kind, zl, Rl, per, eal, dt, act.to(torch.uint8), keep_estimate)
@@ -889,7 +890,7 @@ class BatchedEKF:
       fl_new = self.flags.clone()
       self._ring_replay(replay)
       self.flags.copy_(fl_new)        # (into the SAME buffer: bind_step() captured its address)
-    if bool(dropped.any()):
+    if any_dropped:
       self.flags |= dropped.to(torch.uint8) * 32
     if multi:
       y = torch.stack(zl, 1)
